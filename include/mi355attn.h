@@ -1,0 +1,156 @@
+/* mi355attn.h -- C ABI of libmi355attn.so: MI355X (gfx950 / CDNA4) forward kernels for the
+ * changzy00/pytorch-attention block zoo.
+ *
+ * The reference has no FFI of its own: its boundary is the Python nn.Module surface.  Each
+ * entry point below therefore replaces the *body of one reference forward()* (file:line cited per
+ * function, paths relative to the reference checkout); the host-side nn.Module mirror in
+ * pytorch-attention_amd/mi355attn/modules/ keeps the class name / ctor / state_dict / forward signature
+ * and calls these through ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer on the calling thread's current
+ *     HIP device; tensors are dense, row-major in the layout named per function, fp32 unless noted;
+ *   - the caller owns every buffer (inputs, parameters, output, workspace).  The library allocates
+ *     nothing, frees nothing and keeps no pointer after return;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream), with
+ *     no implicit device synchronisation;
+ *   - `ws` must hold at least mi355_<op>_workspace_bytes(...) bytes and be 16-byte aligned; it is scratch
+ *     (contents undefined after return) and may be shared between calls on the same stream;
+ *   - return 0 on success, <0 on failure: MI355_EINVAL (bad argument), MI355_EUNSUPPORTED (shape outside the
+ *     kernel's envelope), MI355_EHIP (HIP runtime error).  mi355_last_error() returns a thread-local,
+ *     NUL-terminated description of the last failure on this thread.  Nothing throws or aborts across the ABI.
+ *   - precision: 0 = strict (3-way split-bf16 MFMA, fp32-class accuracy), 1 = fp16 MFMA operands with fp32
+ *     accumulate (default of the modules; within the 1e-3 parity tolerance), 2 = bf16 MFMA operands (fast,
+ *     outside the tolerance; reported separately).  Vector (non-MFMA) math is always fp32.
+ */
+#ifndef MI355ATTN_H
+#define MI355ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK            0
+#define MI355_EINVAL       -1
+#define MI355_EUNSUPPORTED -2
+#define MI355_EHIP         -3
+
+#define MI355_PREC_STRICT 0
+#define MI355_PREC_FP16   1
+#define MI355_PREC_BF16   2
+
+#define MI355_ACT_NONE 0
+#define MI355_ACT_GELU 1
+
+typedef void* mi355_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int         mi355_version(void);            /* ABI version, bumped on any signature change */
+const char* mi355_last_error(void);         /* thread-local message of the last failing call */
+/* Tuning knobs (process-global, read at launch): "chunk_images" (images per pool->scale chunk of the
+ * channel-attention family; 0 = library default).  Unknown key -> MI355_EINVAL. */
+int         mi355_set_option(const char* key, long value);
+long        mi355_get_option(const char* key);
+
+/* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
+
+/* SELayer.forward  (attention_mechanisms/se_module.py:29-33)
+ *   y = x * sigmoid(W2 relu(W1 mean_hw(x)));  x,y (B,C,H,W);  w1 (Cr,C) = fc.0.weight;  w2 (C,Cr) = fc.2.weight. */
+size_t mi355_se_workspace_bytes(int B, int C, int H, int W);
+int    mi355_se_fwd(const float* x, const float* w1, const float* w2, float* y,
+                    int B, int C, int Cr, int H, int W, void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ECALayer.forward  (attention_mechanisms/eca.py:26-30; kernel-size rule :21-22 stays on the host)
+ *   y = x * sigmoid(conv1d_k(mean_hw(x)) across the channel axis, zero pad (k-1)/2, no bias); wconv (k,) = conv.weight. */
+size_t mi355_eca_workspace_bytes(int B, int C, int H, int W);
+int    mi355_eca_fwd(const float* x, const float* wconv, float* y,
+                     int B, int C, int k, int H, int W, void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* CBAM.forward  (attention_mechanisms/cbam.py:56-59 = SpatialAttention :43-48 o ChannelAttention :31-35)
+ *   w1 (Cr,C) = ca.fc.0.weight, w2 (C,Cr) = ca.fc.2.weight (1x1 convs, no bias), wconv (2,ks,ks) = sa.conv.weight.
+ *   stage: 0 = full CBAM, 1 = ChannelAttention only (wconv ignored), 2 = SpatialAttention only (w1,w2 ignored). */
+size_t mi355_cbam_workspace_bytes(int B, int C, int H, int W);
+int    mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float* wconv, float* y,
+                      int B, int C, int Cr, int ks, int H, int W, int stage,
+                      void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* DoubleAttention.forward  (attention_mechanisms/double_attention.py:32-48)
+ *   wA (cm,C) bA (cm) | wB (cn,C) bB (cn) | wV (cn,C) bV (cn) | wP (C,cm) bP (C);  x,y (B,C,H,W). */
+size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, int W);
+int    mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB,
+                             const float* wV, const float* bV, const float* wP, const float* bP, float* y,
+                             int B, int C, int cm, int cn, int H, int W, int precision,
+                             void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ---- dense building blocks used by the transformer blocks ---------------------------------------- */
+
+/* nn.Linear (+ optional GELU, LayerScale, residual):  Y = resid + gamma * act(X W^T + bias)
+ *   X (M,K) row-major with row stride ldx, W (N,K) row-major (nn.Linear layout), Y (M,N) row stride ldy.
+ *   bias (N) / gamma (N) / resid (M,N; row stride ldy) may be NULL.  Covers ViT.py:58-65,81,87;
+ *   cswin.py:185,192,40-48; xcit.py:32-38,248,263; mlp_mixer.py:26-33. */
+int mi355_linear_fwd(const float* X, const float* W, const float* bias, const float* gamma, const float* resid,
+                     float* Y, int M, int N, int K, int ldx, int ldy, int act, int precision,
+                     mi355_stream_t stream);
+
+/* Batched left-multiplication used by MLP-Mixer token mixing (mlp_mixer.py:47):
+ *   Y_b = resid_b + act(W X_b + bias 1^T)   with W (T,N), X_b (N,C), Y_b (T,C), bias (T), b = 0..B-1. */
+int mi355_token_mix_fwd(const float* W, const float* X, const float* bias, const float* resid, float* Y,
+                        int B, int T, int N, int C, int act, int precision, mi355_stream_t stream);
+
+/* nn.LayerNorm over the last axis, eps inside the sqrt (ViT.py:111-114, cswin.py:139, xcit.py:271). */
+int mi355_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                        int rows, int cols, float eps, mi355_stream_t stream);
+
+/* ---- attention cores ------------------------------------------------------------------------------ */
+
+/* ViT Attention core (ViT.py:82-86): qkv (B,N,3,h,d) fp32 as produced by the qkv Linear; out (B,N,h*d).
+ *   out[b,n,i*d+j] = (softmax((Q_i K_i^T) * scale) V_i)[n,j].  d in {32,64}. */
+int mi355_sdpa_fwd(const float* qkv, float* out, int B, int N, int heads, int d, float scale, int precision,
+                   mi355_stream_t stream);
+
+/* CSWin LePEAttention.forward (cswin.py:101-127, im2cswin :78-84, get_lepe :86-99, windows :199-216).
+ *   qkv: token-major (B,L,3,Ctot) buffer of the block's qkv Linear; this call handles the channel slice
+ *   [c0, c0+Cb) with `heads` heads of width Cb/heads, stripe window (Hsp x Wsp) on a (reso x reso) token
+ *   grid; writes out[b,l,c0+...] of a (B,L,Ctot) buffer.  getv_w (Cb,3,3), getv_b (Cb): depth-wise 3x3
+ *   LePE conv, zero padded at the WINDOW border. */
+int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float* getv_b, float* out,
+                              int B, int reso, int Ctot, int c0, int Cb, int heads, int Hsp, int Wsp,
+                              float scale, int precision, mi355_stream_t stream);
+
+/* XCA core (xcit.py:249-262): qkv (B,N,3,h,d); temperature (h); out (B,N,h*d).
+ *   per head: L2-normalise q,k over N; A = softmax((q^ k^T) * temp_h) (d x d); out = (A v)^T. */
+int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B, int N, int heads, int d,
+                  int precision, mi355_stream_t stream);
+
+/* XCiT LPI.forward (xcit.py:149-157) with BatchNorm2d in eval mode (running statistics):
+ *   tokens (B,N=H*W,C) -> dw3x3(w1,b1) -> GELU -> (v - bn_mean)/sqrt(bn_var + bn_eps)*bn_w + bn_b -> dw3x3(w2,b2) -> tokens.
+ *   w1,w2 (C,3,3); y = resid + gamma * LPI(x) when gamma / resid are non-NULL (XCABlock :292). */
+size_t mi355_lpi_workspace_bytes(int B, int H, int W, int C);
+int    mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const float* bn_w, const float* bn_b,
+                     const float* bn_mean, const float* bn_var, float bn_eps, const float* w2, const float* b2,
+                     const float* gamma, const float* resid, float* y, int B, int H, int W, int C,
+                     void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ViT PatchEmbedding + token assembly (ViT.py:101-105,183-185):
+ *   tokens[b, p, :] = patch_p(img_b) . Wp^T + bp + pos[p]   for p < P = (H/ps)*(W/ps);
+ *   tokens[b, P, :] = cls + pos[P]                         (cls token LAST).
+ *   img (B,Cin,H,W), Wp (E, Cin*ps*ps), bp (E), cls (E), pos (P+1,E), tokens (B,P+1,E). */
+int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
+                          float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
+                          mi355_stream_t stream);
+
+/* ---- measurement helpers --------------------------------------------------------------------------- */
+/* float4 streaming copy of `bytes` (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py. */
+int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t stream);
+/* HIP-event stopwatch ON `stream` (torch.cuda.Event only sees torch's current stream): begin records an event and
+ * returns an opaque handle; end records the closing event, waits for it and returns elapsed milliseconds. */
+int mi355_event_time_begin(mi355_stream_t stream, void** handle);
+int mi355_event_time_end(mi355_stream_t stream, void* handle, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355ATTN_H */

@@ -1,0 +1,29 @@
+"""oracle/ -- CPU restatement of the reference's hot-path arithmetic.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package, and there only as the *checker*.  Nothing under ``pytorch-attention_amd/`` imports it; the product
+path fails loudly when the HIP library is missing instead of falling back here.
+
+What it is: an independent, functional (weights-in, tensor-out) restatement of the forward math of the
+reference modules named by SURVEY.md section 8(a), written from the formulas in SURVEY.md section 9 with
+explicit index math where the reference uses view/permute chains.  Every function cites the reference
+file:line it follows (paths relative to the reference checkout).  It runs on torch-CPU tensors in fp32 or
+fp64 (``dtype=`` argument) -- the reference's own arithmetic lives in ATen CPU kernels, so torch-CPU is
+the faithful restatement vehicle for a floating-point path.
+
+Pinning: the reference has no tests and pins no numeric result ("parity unpinned by
+the reference's tests").  We pin the oracle ourselves against outputs of the *real* reference imported in
+the build container under the seed protocol of SURVEY.md section 8(c): ``tests/golden/make_golden.py`` is
+the generating script, ``tests/golden/golden.json`` + ``tests/golden/small/*.npz`` are its committed
+outputs, and ``tests/test_oracle_golden.py`` checks every oracle function against them (``-m "not gpu"``).
+"""
+from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, cbam_channel_forward, \
+    cbam_spatial_forward, double_attention_forward
+from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_mlp_forward,
+                          vit_encoder_forward, vit_patch_embed_forward, vit_forward,
+                          mixer_layer_forward, sdpa_core)
+from .cswin import lepe_attention_forward, cswin_block_forward, window_token_index
+from .xcit import xca_forward, lpi_forward, xca_block_forward
+from .params import seeded_module_inputs, strip_prefix
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,119 @@
+"""Oracle (test infrastructure): channel / spatial attention family -- SE, ECA, CBAM, DoubleAttention.
+
+All functions take NCHW tensors and raw weight tensors (state_dict values) and return the block output.
+``dtype`` selects the arithmetic type (torch.float32 to mimic the reference, torch.float64 for a tight
+reference when judging which of two fp32 answers is closer to the truth).
+"""
+import math
+import torch
+
+
+def _prep(t, dtype):
+    return t.detach().to("cpu", dtype)
+
+
+def se_forward(x, w1, w2, dtype=torch.float32):
+    """SELayer.forward -- attention_mechanisms/se_module.py:29-33 (ctor :19-27).
+
+    p[b,c] = mean_hw x ; g = sigmoid(W2 relu(W1 p)) ; y = x * g.   w1:(C/r,C)  w2:(C,C/r), no biases.
+    """
+    x, w1, w2 = _prep(x, dtype), _prep(w1, dtype), _prep(w2, dtype)
+    b, c, h, w = x.shape
+    pooled = x.reshape(b, c, h * w).mean(dim=2)                      # (B,C)
+    hidden = torch.clamp_min(pooled @ w1.t(), 0)                     # (B,C/r)
+    gate = torch.sigmoid(hidden @ w2.t())                            # (B,C)
+    return x * gate[:, :, None, None]
+
+
+def eca_kernel_size(channels, gamma=2, b=1):
+    """Kernel-size rule of ECALayer.__init__ -- attention_mechanisms/eca.py:21-22."""
+    t = int(abs((math.log(channels, 2) + b) / gamma))
+    return t if t % 2 else t + 1
+
+
+def eca_forward(x, wconv, dtype=torch.float32):
+    """ECALayer.forward -- attention_mechanisms/eca.py:26-30.
+
+    g[b,c] = sigmoid(sum_j w[j] * p[b, c + j - (k-1)/2]) with zero padding; y = x * g.  wconv:(1,1,k).
+    """
+    x, wk = _prep(x, dtype), _prep(wconv, dtype).reshape(-1)
+    b, c, h, w = x.shape
+    k = wk.numel()
+    pad = (k - 1) // 2
+    pooled = x.reshape(b, c, h * w).mean(dim=2)
+    padded = torch.zeros(b, c + 2 * pad, dtype=dtype)
+    padded[:, pad:pad + c] = pooled
+    z = torch.zeros(b, c, dtype=dtype)
+    for j in range(k):                                               # cross-correlation, no flip
+        z = z + wk[j] * padded[:, j:j + c]
+    return x * torch.sigmoid(z)[:, :, None, None]
+
+
+def cbam_channel_forward(x, w1, w2, dtype=torch.float32):
+    """ChannelAttention.forward -- attention_mechanisms/cbam.py:31-35.
+
+    fc = 1x1conv(C->C/r) -> ReLU -> 1x1conv(C/r->C), no bias, applied to the avg- and the max-pooled
+    vector, summed *after* the second conv (kept as two W2 products here to follow the reference's
+    rounding order), then sigmoid and broadcast multiply.
+    """
+    x = _prep(x, dtype)
+    w1 = _prep(w1, dtype).reshape(w1.shape[0], w1.shape[1])
+    w2 = _prep(w2, dtype).reshape(w2.shape[0], w2.shape[1])
+    b, c, h, w = x.shape
+    flat = x.reshape(b, c, h * w)
+    avg = flat.mean(dim=2)
+    mx = flat.amax(dim=2)
+    fa = torch.clamp_min(avg @ w1.t(), 0) @ w2.t()
+    fm = torch.clamp_min(mx @ w1.t(), 0) @ w2.t()
+    gate = torch.sigmoid(fa + fm)
+    return x * gate[:, :, None, None]
+
+
+def cbam_spatial_forward(x, wconv, dtype=torch.float32):
+    """SpatialAttention.forward -- attention_mechanisms/cbam.py:43-48.
+
+    s = [mean_c x, max_c x] (that order, :46) -> KxK cross-correlation 2->1, zero pad K//2, no bias ->
+    sigmoid -> multiply.  wconv:(1,2,K,K).
+    """
+    x, wk = _prep(x, dtype), _prep(wconv, dtype)
+    b, c, h, w = x.shape
+    ks = wk.shape[-1]
+    pad = ks // 2
+    smap = torch.stack([x.mean(dim=1), x.amax(dim=1)], dim=1)        # (B,2,H,W)
+    padded = torch.zeros(b, 2, h + 2 * pad, w + 2 * pad, dtype=dtype)
+    padded[:, :, pad:pad + h, pad:pad + w] = smap
+    acc = torch.zeros(b, h, w, dtype=dtype)
+    for ch in range(2):
+        for dy in range(ks):
+            for dx in range(ks):
+                acc = acc + wk[0, ch, dy, dx] * padded[:, ch, dy:dy + h, dx:dx + w]
+    return x * torch.sigmoid(acc)[:, None, :, :]
+
+
+def cbam_forward(x, w1, w2, wconv, dtype=torch.float32):
+    """CBAM.forward -- attention_mechanisms/cbam.py:56-59: spatial stage consumes the channel stage output."""
+    return cbam_spatial_forward(cbam_channel_forward(x, w1, w2, dtype), wconv, dtype)
+
+
+def double_attention_forward(x, wA, bA, wB, bB, wV, bV, wP, bP, dtype=torch.float32):
+    """DoubleAttention.forward -- attention_mechanisms/double_attention.py:32-48.
+
+    A = WA X + bA (c_m x HW); Bm = softmax_HW(WB X + bB) (c_n x HW); V = softmax_{c_n}(WV X + bV);
+    G = A Bm^T (c_m x c_n); Z = G V (c_m x HW); y = WP Z + bP (C x HW).
+    """
+    x = _prep(x, dtype)
+    b, c, h, w = x.shape
+    X = x.reshape(b, c, h * w)
+
+    def pw(wt, bs):                                                  # 1x1 conv as a channel GEMM
+        wt = _prep(wt, dtype).reshape(wt.shape[0], wt.shape[1])
+        return torch.einsum("oc,bcn->bon", wt, X) + _prep(bs, dtype)[None, :, None]
+
+    A = pw(wA, bA)
+    Bm = torch.softmax(pw(wB, bB), dim=2)
+    V = torch.softmax(pw(wV, bV), dim=1)
+    G = torch.einsum("bmn,bkn->bmk", A, Bm)                          # (B,c_m,c_n)
+    Z = torch.einsum("bmk,bkn->bmn", G, V)                           # (B,c_m,HW)
+    wp = _prep(wP, dtype).reshape(wP.shape[0], wP.shape[1])
+    out = torch.einsum("om,bmn->bon", wp, Z) + _prep(bP, dtype)[None, :, None]
+    return out.reshape(b, wp.shape[0], h, w)

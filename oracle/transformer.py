@@ -1,0 +1,128 @@
+"""Oracle (test infrastructure): ViT attention / encoder / full model and the MLP-Mixer layer.
+
+Parameters are passed as a dict ``p`` whose keys are the reference's state_dict names relative to the
+module (e.g. ``qkv.weight``).  Missing optional keys (``qkv.bias``) mean "no bias", as in the reference.
+"""
+import math
+import torch
+
+
+def _t(v, dtype):
+    return v.detach().to("cpu", dtype)
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last axis (biased variance, eps inside the sqrt), as used at ViT.py:111-114."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * weight + bias
+
+
+def gelu(x):
+    """nn.GELU() default = exact erf form (ViT.py:53, cswin.py:35 act_layer=nn.GELU)."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def sdpa_core(q, k, v, scale, pre_scale=False):
+    """softmax(q k^T * scale) v over (..., N, d) tensors.
+
+    ``pre_scale=False``: scale multiplies the product (ViT.py:83).  ``pre_scale=True``: q is scaled
+    before the product (cswin.py:116-117).  Kept separate because fp32 rounding differs.
+    """
+    if pre_scale:
+        s = (q * scale) @ k.transpose(-1, -2)
+    else:
+        s = (q @ k.transpose(-1, -2)) * scale
+    s = s - s.amax(dim=-1, keepdim=True)
+    e = torch.exp(s)
+    return (e / e.sum(dim=-1, keepdim=True)) @ v
+
+
+def vit_attention_forward(x, p, num_heads, dtype=torch.float32):
+    """Attention.forward -- vision_transformers/ViT.py:79-89 (ctor :68-77).
+
+    Channel index of q/k/v for head i lane j in the qkv GEMM output is s*C + i*d + j (s=0,1,2).
+    """
+    x = _t(x, dtype)
+    B, N, C = x.shape
+    d = C // num_heads
+    qkv = linear(x, _t(p["qkv.weight"], dtype), _t(p["qkv.bias"], dtype) if "qkv.bias" in p else None)
+    out = torch.empty(B, N, C, dtype=dtype)
+    scale = d ** -0.5
+    for i in range(num_heads):
+        q = qkv[:, :, 0 * C + i * d: 0 * C + (i + 1) * d]
+        k = qkv[:, :, 1 * C + i * d: 1 * C + (i + 1) * d]
+        v = qkv[:, :, 2 * C + i * d: 2 * C + (i + 1) * d]
+        out[:, :, i * d:(i + 1) * d] = sdpa_core(q, k, v, scale)
+    return linear(out, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))
+
+
+def vit_mlp_forward(x, p, dtype=torch.float32):
+    """Mlp.forward -- vision_transformers/ViT.py:58-65: GELU after fc1 AND after fc2 (reference quirk)."""
+    x = _t(x, dtype)
+    h = gelu(linear(x, _t(p["fc1.weight"], dtype), _t(p["fc1.bias"], dtype)))
+    return gelu(linear(h, _t(p["fc2.weight"], dtype), _t(p["fc2.bias"], dtype)))
+
+
+def _sub(p, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def vit_encoder_forward(x, p, num_heads, dtype=torch.float32):
+    """TransformerEncoder.forward -- vision_transformers/ViT.py:116-119 (pre-LN residual block)."""
+    x = _t(x, dtype)
+    u = layernorm(x, _t(p["layernorm1.weight"], dtype), _t(p["layernorm1.bias"], dtype))
+    x = x + vit_attention_forward(u, _sub(p, "attn."), num_heads, dtype)
+    u = layernorm(x, _t(p["layernorm2.weight"], dtype), _t(p["layernorm2.bias"], dtype))
+    return x + vit_mlp_forward(u, _sub(p, "mlp."), dtype)
+
+
+def vit_patch_embed_forward(img, w, b, dtype=torch.float32):
+    """PatchEmbedding.forward -- vision_transformers/ViT.py:101-105.
+
+    Conv2d(k=P,s=P) == per-patch GEMM with K = Cin*P*P in (c, ky, kx) order; tokens row-major over the
+    patch grid.
+    """
+    img, w, b = _t(img, dtype), _t(w, dtype), _t(b, dtype)
+    B, Cin, H, W = img.shape
+    E, _, P, _ = w.shape
+    gh, gw = H // P, W // P
+    patches = img.reshape(B, Cin, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * P * P)
+    return patches @ w.reshape(E, Cin * P * P).t() + b
+
+
+def vit_forward(img, p, num_heads, depth, dtype=torch.float32):
+    """VisionTransformer.forward -- vision_transformers/ViT.py:180-192 at the native resolution.
+
+    Tokens = [patch_0..patch_{n-1}, cls] (cls appended LAST, :183), + position_embedding, `depth`
+    encoder blocks, logits = head(token 0) (global_pool="token", :187-188); no final LayerNorm.
+    """
+    x = vit_patch_embed_forward(img, p["patch_embedding.proj.weight"], p["patch_embedding.proj.bias"], dtype)
+    B = x.shape[0]
+    cls = _t(p["cls_token"], dtype).expand(B, -1, -1)
+    x = torch.cat([x, cls], dim=1) + _t(p["position_embedding"], dtype)
+    for i in range(depth):
+        x = vit_encoder_forward(x, _sub(p, f"blocks.{i}."), num_heads, dtype)
+    return linear(x[:, 0], _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))
+
+
+def mixer_layer_forward(x, p, dtype=torch.float32):
+    """MixerLayer.forward -- mlps/mlp_mixer.py:45-50 (Mlp :26-33, single GELU).
+
+    Token mixing is a LEFT multiplication of the (N x C) matrix: x_b += W2 gelu(W1 LN1(x_b) + b1) + b2.
+    """
+    x = _t(x, dtype)
+    u = layernorm(x, _t(p["norm1.weight"], dtype), _t(p["norm1.bias"], dtype))
+    w1, b1 = _t(p["token_mlp.fc1.weight"], dtype), _t(p["token_mlp.fc1.bias"], dtype)
+    w2, b2 = _t(p["token_mlp.fc2.weight"], dtype), _t(p["token_mlp.fc2.bias"], dtype)
+    hid = gelu(torch.einsum("tn,bnc->btc", w1, u) + b1[None, :, None])
+    x = x + torch.einsum("nt,btc->bnc", w2, hid) + b2[None, :, None]
+    u = layernorm(x, _t(p["norm2.weight"], dtype), _t(p["norm2.bias"], dtype))
+    h = gelu(linear(u, _t(p["channel_mlp.fc1.weight"], dtype), _t(p["channel_mlp.fc1.bias"], dtype)))
+    return x + linear(h, _t(p["channel_mlp.fc2.weight"], dtype), _t(p["channel_mlp.fc2.bias"], dtype))

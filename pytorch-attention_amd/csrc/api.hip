@@ -1,0 +1,74 @@
+// api.hip -- library-level entry points: version, thread-local error text, tuning options, HIP-event stopwatch.
+#include "common.h"
+#include <atomic>
+#include <cstring>
+
+namespace mi355 {
+static thread_local char g_err[512] = "";
+static std::atomic<long> g_chunk_images{0};
+
+char* err_buf() { return g_err; }
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+long opt_chunk_images() { return g_chunk_images.load(std::memory_order_relaxed); }
+}  // namespace mi355
+
+struct mi355_timer {
+    hipEvent_t a, b;
+};
+
+extern "C" {
+
+int mi355_version(void) { return MI355_ABI_VERSION; }
+const char* mi355_last_error(void) { return mi355::err_buf(); }
+
+int mi355_set_option(const char* key, long value) {
+    MI355_CHECK_ARG(key != nullptr);
+    if (std::strcmp(key, "chunk_images") == 0) {
+        MI355_CHECK_ARG(value >= 0);
+        mi355::g_chunk_images.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
+    return mi355::fail(MI355_EINVAL, "mi355_set_option: unknown key '%s'", key);
+}
+
+long mi355_get_option(const char* key) {
+    if (key && std::strcmp(key, "chunk_images") == 0) return mi355::opt_chunk_images();
+    mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
+    return -1;
+}
+
+int mi355_event_time_begin(mi355_stream_t stream, void** handle) {
+    MI355_CHECK_ARG(handle != nullptr);
+    mi355_timer* t = new mi355_timer;
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e == hipSuccess) e = hipEventRecord(t->a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        delete t;
+        return mi355::fail(MI355_EHIP, "mi355_event_time_begin: %s", hipGetErrorString(e));
+    }
+    *handle = t;
+    return MI355_OK;
+}
+
+int mi355_event_time_end(mi355_stream_t stream, void* handle, float* ms_out) {
+    MI355_CHECK_ARG(handle != nullptr && ms_out != nullptr);
+    mi355_timer* t = static_cast<mi355_timer*>(handle);
+    hipError_t e = hipEventRecord(t->b, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipEventSynchronize(t->b);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms_out, t->a, t->b);
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    if (e != hipSuccess) return mi355::fail(MI355_EHIP, "mi355_event_time_end: %s", hipGetErrorString(e));
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// chan_attn.hip -- HBM-bound channel / spatial attention family for gfx950: SELayer, ECALayer, CBAM.
+//
+// Data layout: x, y are NCHW fp32; one (b,c) "row" is HW contiguous floats.  All kernels stream rows with
+// 16-byte-per-lane loads (1 KiB per wave instruction) when HW % 4 == 0, and fall back to 4-byte lanes
+// otherwise.  Reductions are wave-level __shfl_xor trees (64 lanes) plus LDS partials across the 4 waves
+// of a 256-thread workgroup.  The gate math (2-layer excite / k-tap conv / 7x7 stencil) is tiny and is
+// recomputed per workgroup from the pooled vectors so that no extra launch sits between the two streaming
+// passes.
+//
+// Algorithmic HBM traffic per image: read x once + write y once = 2*C*H*W*4 bytes.  The
+// gate of image b depends on all of image b (3.2 MB at the C2 shape, larger than LDS), so the data is
+// streamed twice (SE/ECA) or three times (CBAM); the launcher therefore walks the batch in chunks of
+// `chunk_images` images so that the re-read of a chunk is served by the 256 MiB Infinity Cache instead of
+// HBM (DESIGN.md section "channel attention").
+#include "common.h"
+
+namespace {
+
+constexpr int RPB = 16;   // rows (channels) per workgroup in the scale kernels
+
+using v4f = float __attribute__((ext_vector_type(4)));   // 16-byte lane vector (global_load/store_dwordx4)
+
+// ---------------------------------------------------------------------------------------------------
+// K1: per-row global pooling.  One wave per row, grid-strided.  avg[row] = sum/HW (true division, like
+// ATen's mean), mx[row] = max (CBAM only).
+// ---------------------------------------------------------------------------------------------------
+template <bool WITH_MAX, bool VEC>
+__global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ x, float* __restrict__ avg,
+                                                       float* __restrict__ mx, long rows, int HW) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long row = wave0; row < rows; row += nwaves) {
+        const float* p = x + row * HW;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float m = -INFINITY;
+        if constexpr (VEC) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const int n4 = HW >> 2;
+            int i = lane;
+            for (; i + 192 < n4; i += 256) {
+                float4 a = p4[i], b = p4[i + 64], c = p4[i + 128], d = p4[i + 192];
+                s0 += (a.x + b.x) + (c.x + d.x);
+                s1 += (a.y + b.y) + (c.y + d.y);
+                s2 += (a.z + b.z) + (c.z + d.z);
+                s3 += (a.w + b.w) + (c.w + d.w);
+                if constexpr (WITH_MAX) {
+                    m = fmaxf(m, fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+                    m = fmaxf(m, fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
+                }
+            }
+            for (; i < n4; i += 64) {
+                float4 a = p4[i];
+                s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
+                if constexpr (WITH_MAX) m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+            }
+        } else {
+            for (int i = lane; i < HW; i += 64) {
+                float a = p[i];
+                s0 += a;
+                if constexpr (WITH_MAX) m = fmaxf(m, a);
+            }
+        }
+        float s = wave_sum((s0 + s1) + (s2 + s3));
+        if constexpr (WITH_MAX) m = wave_max(m);
+        if (lane == 0) {
+            avg[row] = s / (float)HW;
+            if constexpr (WITH_MAX) mx[row] = m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Excite helpers (run by one whole 256-thread workgroup; smem: p[C] | h[Cr]).
+// hidden_j = relu(sum_c w1[j,c] * p[c]) computed by 16-lane groups (16 j's per pass).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot16(const float* __restrict__ wrow, const float* s_p, int C, int part) {
+    float acc = 0.f;
+    for (int c = part; c < C; c += 16) acc += wrow[c] * s_p[c];
+    acc += __shfl_xor(acc, 8, WAVE);
+    acc += __shfl_xor(acc, 4, WAVE);
+    acc += __shfl_xor(acc, 2, WAVE);
+    acc += __shfl_xor(acc, 1, WAVE);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2 (SE / ECA): recompute the gates of this workgroup's RPB channels from the pooled vector, then
+// stream y = x * g.  grid = B * ceil(C / RPB).
+//   MODE 0: SE   gate_c = sigmoid(sum_j w2[c,j] relu(sum_c' w1[j,c'] p[c']))
+//   MODE 1: ECA  gate_c = sigmoid(sum_j wk[j] p[c + j - pad])
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
+                                                        const float* __restrict__ wa, const float* __restrict__ wb,
+                                                        float* __restrict__ y, int C, int Cr, int HW, int groups) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_p = smem;            // C
+    float* s_h = smem + C;        // Cr (SE)
+    float* s_g = s_h + Cr;        // RPB
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * RPB;
+    const float* pb = pooled + (long)b * C;
+
+    if constexpr (MODE == 0) {
+        for (int c = t; c < C; c += 256) s_p[c] = pb[c];
+        __syncthreads();
+        const int part = t & 15, jl = t >> 4;
+        for (int j0 = 0; j0 < Cr; j0 += 16) {
+            const int j = j0 + jl;
+            float acc = (j < Cr) ? dot16(wa + (long)j * C, s_p, C, part) : 0.f;
+            if (part == 0 && j < Cr) s_h[j] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        if (t < RPB && c0 + t < C) {
+            const float* w2r = wb + (long)(c0 + t) * Cr;
+            float z = 0.f;
+            for (int j = 0; j < Cr; ++j) z += w2r[j] * s_h[j];
+            s_g[t] = sigmoidf_(z);
+        }
+    } else {
+        if (t < RPB && c0 + t < C) {
+            const int k = Cr, pad = (k - 1) / 2, c = c0 + t;
+            float z = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const int cc = c + j - pad;
+                if (cc >= 0 && cc < C) z += wa[j] * pb[cc];
+            }
+            s_g[t] = sigmoidf_(z);
+        }
+    }
+    __syncthreads();
+
+    const int lane = t & 63, wave = t >> 6;
+    for (int r = wave; r < RPB && c0 + r < C; r += 4) {
+        const float g = s_g[r];
+        const long off = ((long)b * C + c0 + r) * HW;
+        if constexpr (VEC) {
+            const v4f* xr = reinterpret_cast<const v4f*>(x + off);
+            v4f* yr = reinterpret_cast<v4f*>(y + off);
+            const int n4 = HW >> 2;
+            int i = lane;
+            for (; i + 192 < n4; i += 256) {
+                v4f a = __builtin_nontemporal_load(&xr[i]), bq = __builtin_nontemporal_load(&xr[i + 64]);
+                v4f c = __builtin_nontemporal_load(&xr[i + 128]), d = __builtin_nontemporal_load(&xr[i + 192]);
+                __builtin_nontemporal_store(a * g, &yr[i]);
+                __builtin_nontemporal_store(bq * g, &yr[i + 64]);
+                __builtin_nontemporal_store(c * g, &yr[i + 128]);
+                __builtin_nontemporal_store(d * g, &yr[i + 192]);
+            }
+            for (; i < n4; i += 64) {
+                v4f a = __builtin_nontemporal_load(&xr[i]);
+                __builtin_nontemporal_store(a * g, &yr[i]);
+            }
+        } else {
+            for (int i = lane; i < HW; i += 64) y[off + i] = x[off + i] * g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CBAM K2: channel gate gc[b,c] = sigmoid(W2 (relu(W1 avg) + relu(W1 max)))  (cbam.py:31-35; fc has no
+// bias so fc(avg)+fc(max) collapses to one W2 product).  grid = B, 256 threads.  smem: a[C] | m[C] | h[Cr].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_channel_gate_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                               const float* __restrict__ w1, const float* __restrict__ w2,
+                                                               float* __restrict__ gc, int C, int Cr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_a = smem;
+    float* s_m = smem + C;
+    float* s_h = s_m + C;
+    const int t = threadIdx.x, b = blockIdx.x;
+    for (int c = t; c < C; c += 256) {
+        s_a[c] = avg[(long)b * C + c];
+        s_m[c] = mx[(long)b * C + c];
+    }
+    __syncthreads();
+    const int part = t & 15, jl = t >> 4;
+    for (int j0 = 0; j0 < Cr; j0 += 16) {
+        const int j = j0 + jl;
+        float ha = 0.f, hm = 0.f;
+        if (j < Cr) {
+            ha = dot16(w1 + (long)j * C, s_a, C, part);
+            hm = dot16(w1 + (long)j * C, s_m, C, part);
+        }
+        if (part == 0 && j < Cr) s_h[j] = fmaxf(ha, 0.f) + fmaxf(hm, 0.f);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const float* w2r = w2 + (long)c * Cr;
+        float z = 0.f;
+        for (int j = 0; j < Cr; ++j) z += w2r[j] * s_h[j];
+        gc[(long)b * C + c] = sigmoidf_(z);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CBAM K3: per-pixel statistics over channels of x' = x * gc:  smap[b,0,p] = mean_c x', smap[b,1,p] = max_c x'
+// (order [avg,max], cbam.py:46).  Workgroup = (image, tile of 64 lanes x VW pixels); the 4 waves split the
+// channel range and combine through LDS.  gc may be NULL (stage 2: SpatialAttention alone).
+// ---------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __restrict__ x, const float* __restrict__ gc,
+                                                                float* __restrict__ smap, int C, int HW, int tiles) {
+    constexpr int VW = VEC ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) float s_sum[4][64 * VW];
+    __shared__ __attribute__((aligned(16))) float s_max[4][64 * VW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int nv = HW / VW;                       // vector elements per row
+    const int iv = tile * 64 + lane;
+    const bool ok = iv < nv;
+    float s[VW], m[VW];
+#pragma unroll
+    for (int q = 0; q < VW; ++q) { s[q] = 0.f; m[q] = -INFINITY; }
+    const float* xb = x + (long)b * C * HW;
+    const float* gb = gc ? gc + (long)b * C : nullptr;
+    if (ok) {
+#pragma unroll 8
+        for (int c = wave; c < C; c += 4) {
+            const float g = gb ? gb[c] : 1.0f;
+            if constexpr (VEC) {
+                const float4 v = reinterpret_cast<const float4*>(xb + (long)c * HW)[iv];
+                const float a0 = v.x * g, a1 = v.y * g, a2 = v.z * g, a3 = v.w * g;
+                s[0] += a0; s[1] += a1; s[2] += a2; s[3] += a3;
+                m[0] = fmaxf(m[0], a0); m[1] = fmaxf(m[1], a1); m[2] = fmaxf(m[2], a2); m[3] = fmaxf(m[3], a3);
+            } else {
+                const float a0 = xb[(long)c * HW + iv] * g;
+                s[0] += a0; m[0] = fmaxf(m[0], a0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < VW; ++q) { s_sum[wave][lane * VW + q] = s[q]; s_max[wave][lane * VW + q] = m[q]; }
+    __syncthreads();
+    // 64*VW outputs per tile, combined by the first 64*VW threads
+    const int o = threadIdx.x;
+    if (o < 64 * VW) {
+        const int pix = tile * 64 * VW + o;
+        if (pix < HW) {
+            const float ss = (s_sum[0][o] + s_sum[1][o]) + (s_sum[2][o] + s_sum[3][o]);
+            const float mm = fmaxf(fmaxf(s_max[0][o], s_max[1][o]), fmaxf(s_max[2][o], s_max[3][o]));
+            smap[((long)b * 2 + 0) * HW + pix] = ss / (float)C;
+            smap[((long)b * 2 + 1) * HW + pix] = mm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CBAM K4: spatial gate gs[b,p] = sigmoid(conv_ks x ks (smap[b]) ), 2->1 channels, zero pad ks/2, no bias,
+// cross-correlation.  Workgroup = (image, band of TR full-width rows); the band plus halo sits in LDS.
+// smem: w[2*ks*ks] | tile[2][(TR+ks-1)][(W+ks-1)]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __restrict__ smap, const float* __restrict__ wconv,
+                                                               float* __restrict__ gs, int H, int W, int ks, int TR, int bands) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int kk = ks * ks, pad = ks / 2;
+    const int TW = W + ks - 1, TH = TR + ks - 1;
+    float* s_w = smem;
+    float* s_t = smem + ((2 * kk + 3) & ~3);
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / bands, r0 = (blockIdx.x % bands) * TR;
+    for (int i = t; i < 2 * kk; i += 256) s_w[i] = wconv[i];
+    const float* sb = smap + (long)b * 2 * H * W;
+    for (int i = t; i < 2 * TH * TW; i += 256) {
+        const int ch = i / (TH * TW), rem = i % (TH * TW);
+        const int ty = rem / TW, tx = rem % TW;
+        const int gy = r0 + ty - pad, gx = tx - pad;
+        s_t[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? sb[((long)ch * H + gy) * W + gx] : 0.f;
+    }
+    __syncthreads();
+    const int rows_here = min(TR, H - r0);
+    for (int o = t; o < rows_here * W; o += 256) {
+        const int r = o / W, col = o % W;
+        float acc = 0.f;
+        for (int ch = 0; ch < 2; ++ch)
+            for (int dy = 0; dy < ks; ++dy) {
+                const float* trow = s_t + (ch * TH + r + dy) * TW + col;
+                const float* wrow = s_w + ch * kk + dy * ks;
+                for (int dx = 0; dx < ks; ++dx) acc += wrow[dx] * trow[dx];
+            }
+        gs[(long)b * H * W + (long)(r0 + r) * W + col] = sigmoidf_(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CBAM K5: y = (x * gc[b,c]) * gs[b,p]   (same rounding order as the reference: channel stage output is
+// rounded to fp32 before the spatial multiply).  Workgroup = (image, RPB channels); waves walk pixel
+// chunks (gs stays in 4 VGPRs) and loop the RPB rows inside.  gc or gs may be NULL (= 1).
+// ---------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gc,
+                                                        const float* __restrict__ gs, float* __restrict__ y,
+                                                        int C, int HW, int groups) {
+    __shared__ float s_g[RPB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * RPB;
+    const int nrows = min(RPB, C - c0);
+    if (t < RPB) s_g[t] = (gc && t < nrows) ? gc[(long)b * C + c0 + t] : 1.0f;
+    __syncthreads();
+    const float* xb = x + ((long)b * C + c0) * HW;
+    float* yb = y + ((long)b * C + c0) * HW;
+    const float* gsb = gs ? gs + (long)b * HW : nullptr;
+    if constexpr (VEC) {
+        const int n4 = HW >> 2;
+        const int chunks = (n4 + 63) >> 6;
+        for (int ch = wave; ch < chunks; ch += 4) {
+            const int i = ch * 64 + lane;
+            if (i >= n4) continue;
+            v4f s4 = {1.f, 1.f, 1.f, 1.f};
+            if (gsb) s4 = reinterpret_cast<const v4f*>(gsb)[i];
+#pragma unroll 4
+            for (int r = 0; r < nrows; ++r) {
+                const float g = s_g[r];
+                v4f v = __builtin_nontemporal_load(&reinterpret_cast<const v4f*>(xb + (long)r * HW)[i]);
+                v = (v * g) * s4;
+                __builtin_nontemporal_store(v, &reinterpret_cast<v4f*>(yb + (long)r * HW)[i]);
+            }
+        }
+    } else {
+        for (int i = t; i < HW; i += 256) {
+            const float sp = gsb ? gsb[i] : 1.0f;
+            for (int r = 0; r < nrows; ++r) yb[(long)r * HW + i] = (xb[(long)r * HW + i] * s_g[r]) * sp;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+inline int pool_grid(long rows) { return (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096); }
+
+inline int resolve_chunk(int B, long bytes_per_image) {
+    long ci = mi355::opt_chunk_images();
+    if (ci <= 0) {
+        // default: keep one chunk's input well inside the 256 MiB Infinity Cache (~96 MiB of x)
+        ci = (96L << 20) / (bytes_per_image > 0 ? bytes_per_image : 1);
+        if (ci < 1) ci = 1;
+    }
+    return (int)(ci > B ? B : ci);
+}
+
+}  // namespace
+
+// ===================================================================================================
+// C ABI
+// ===================================================================================================
+extern "C" {
+
+size_t mi355_se_workspace_bytes(int B, int C, int, int) { return (size_t)B * C * sizeof(float); }
+size_t mi355_eca_workspace_bytes(int B, int C, int, int) { return (size_t)B * C * sizeof(float); }
+
+static int se_eca_common(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr,
+                         int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int HW = H * W;
+    const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+    float* pooled = static_cast<float*>(ws);
+    const int groups = cdiv(C, RPB);
+    const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
+    if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
+    const int chunk = resolve_chunk(B, (long)C * HW * 4);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const float* xc = x + (long)b0 * C * HW;
+        float* yc = y + (long)b0 * C * HW;
+        float* pc = pooled + (long)b0 * C;
+        const long rows = (long)nb * C;
+        if (vec) pool_rows_kernel<false, true><<<pool_grid(rows), 256, 0, st>>>(xc, pc, nullptr, rows, HW);
+        else     pool_rows_kernel<false, false><<<pool_grid(rows), 256, 0, st>>>(xc, pc, nullptr, rows, HW);
+        const int grid = nb * groups;
+        if (mode == 0) {
+            if (vec) gate_scale_kernel<0, true><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups);
+            else     gate_scale_kernel<0, false><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups);
+        } else {
+            if (vec) gate_scale_kernel<1, true><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups);
+            else     gate_scale_kernel<1, false><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups);
+        }
+    }
+    MI355_LAUNCH_CHECK();
+    (void)ws_bytes;
+    return MI355_OK;
+}
+
+int mi355_se_fwd(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W,
+                 void* ws, size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && w1 && w2 && y && ws);
+    MI355_CHECK_ARG(B > 0 && C > 0 && Cr > 0 && H > 0 && W > 0);
+    MI355_CHECK_ARG(ws_bytes >= mi355_se_workspace_bytes(B, C, H, W));
+    return se_eca_common(0, x, w1, w2, y, B, C, Cr, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int mi355_eca_fwd(const float* x, const float* wconv, float* y, int B, int C, int k, int H, int W, void* ws,
+                  size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && wconv && y && ws);
+    MI355_CHECK_ARG(B > 0 && C > 0 && k > 0 && (k & 1) && H > 0 && W > 0);
+    MI355_CHECK_ARG(ws_bytes >= mi355_eca_workspace_bytes(B, C, H, W));
+    return se_eca_common(1, x, wconv, nullptr, y, B, C, k, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+// workspace: avg[B*C] | max[B*C] | gc[B*C] | smap[B*2*HW] | gs[B*HW]   (each region rounded to 16 B)
+static inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
+size_t mi355_cbam_workspace_bytes(int B, int C, int H, int W) {
+    const size_t bc = r16((size_t)B * C * 4), hw = (size_t)H * W;
+    return 3 * bc + r16((size_t)B * 2 * hw * 4) + r16((size_t)B * hw * 4);
+}
+
+int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr,
+                   int ks, int H, int W, int stage, void* ws, size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && y && ws);
+    MI355_CHECK_ARG(stage >= 0 && stage <= 2);
+    MI355_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0);
+    const bool do_c = stage != 2, do_s = stage != 1;
+    if (do_c) MI355_CHECK_ARG(w1 && w2 && Cr > 0);
+    if (do_s) MI355_CHECK_ARG(wconv && ks > 0 && (ks & 1));
+    MI355_CHECK_ARG(ws_bytes >= mi355_cbam_workspace_bytes(B, C, H, W));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int HW = H * W;
+    const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+    char* wsp = static_cast<char*>(ws);
+    const size_t bc = r16((size_t)B * C * 4);
+    float* avg = reinterpret_cast<float*>(wsp);
+    float* mx = reinterpret_cast<float*>(wsp + bc);
+    float* gc = reinterpret_cast<float*>(wsp + 2 * bc);
+    float* smap = reinterpret_cast<float*>(wsp + 3 * bc);
+    float* gs = reinterpret_cast<float*>(wsp + 3 * bc + r16((size_t)B * 2 * HW * 4));
+
+    // spatial-gate band geometry: LDS tile (2 ch) of (TR + ks - 1) x (W + ks - 1) floats <= 48 KiB
+    int TR = H, bands = 1;
+    size_t smem_gate = 0;
+    if (do_s) {
+        const int TW = W + ks - 1;
+        const long budget = (48L * 1024 / 4 - ((2 * ks * ks + 3) & ~3)) / (2L * TW);
+        if (budget < ks) return mi355::fail(MI355_EUNSUPPORTED, "W=%d too wide for the %dx%d spatial-gate tile", W, ks, ks);
+        TR = (int)(budget - (ks - 1));
+        if (TR > H) TR = H;
+        bands = cdiv(H, TR);
+        smem_gate = (size_t)(((2 * ks * ks + 3) & ~3) + 2 * (TR + ks - 1) * TW) * 4;
+    }
+    const size_t smem_cg = (size_t)(2 * C + Cr) * 4;
+    if (do_c && smem_cg > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
+
+    const int groups = cdiv(C, RPB);
+    const int VW = vec ? 4 : 1;
+    const int tiles = cdiv(HW / VW, 64);
+    const int chunk = resolve_chunk(B, (long)C * HW * 4);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const float* xc = x + (long)b0 * C * HW;
+        float* yc = y + (long)b0 * C * HW;
+        float* avgc = avg + (long)b0 * C;
+        float* mxc = mx + (long)b0 * C;
+        float* gcc = gc + (long)b0 * C;
+        float* smc = smap + (long)b0 * 2 * HW;
+        float* gsc = gs + (long)b0 * HW;
+        const long rows = (long)nb * C;
+        if (do_c) {
+            if (vec) pool_rows_kernel<true, true><<<pool_grid(rows), 256, 0, st>>>(xc, avgc, mxc, rows, HW);
+            else     pool_rows_kernel<true, false><<<pool_grid(rows), 256, 0, st>>>(xc, avgc, mxc, rows, HW);
+            cbam_channel_gate_kernel<<<nb, 256, smem_cg, st>>>(avgc, mxc, w1, w2, gcc, C, Cr);
+        }
+        if (do_s) {
+            if (vec) cbam_spatial_stats_kernel<true><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
+            else     cbam_spatial_stats_kernel<false><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
+            cbam_spatial_gate_kernel<<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
+        }
+        if (vec) cbam_apply_kernel<true><<<nb * groups, 256, 0, st>>>(xc, do_c ? gcc : nullptr, do_s ? gsc : nullptr, yc, C, HW, groups);
+        else     cbam_apply_kernel<false><<<nb * groups, 256, 0, st>>>(xc, do_c ? gcc : nullptr, do_s ? gsc : nullptr, yc, C, HW, groups);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(src && dst && bytes % 16 == 0 && aligned16(src) && aligned16(dst));
+    const long n4 = (long)(bytes / 16);
+    if (n4 == 0) return MI355_OK;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    stream_copy_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const float4*>(src),
+                                                                            static_cast<float4*>(dst), n4);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+"""ctypes binding of libmi355attn.so (the C ABI declared in include/mi355attn.h).
+
+The library is loaded lazily at the first op call.  There is NO fallback: if the shared object is missing
+or the input is not a CUDA(HIP) tensor the call raises -- the product path never routes through a CPU
+implementation (see DESIGN.md "boundary").
+
+`import torch` happens before the CDLL load on purpose: torch's wheel bundles libamdhip64.so (same SONAME
+as /opt/rocm's), so loading torch first makes our library bind to the runtime torch already initialised --
+one HIP runtime per process, shared streams and device pointers.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355attn.so")
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+c_f32p = ctypes.c_void_p      # device pointers travel as void*
+c_int = ctypes.c_int
+c_size = ctypes.c_size_t
+c_vp = ctypes.c_void_p
+c_float = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/mi355attn.h one-to-one (tests/test_abi.py checks the match)
+SIGNATURES = {
+    "mi355_version": (c_int, []),
+    "mi355_last_error": (ctypes.c_char_p, []),
+    "mi355_set_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
+    "mi355_get_option": (ctypes.c_long, [ctypes.c_char_p]),
+    "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_se_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
+    "mi355_eca_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_eca_fwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
+    "mi355_cbam_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_cbam_fwd": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp, c_size, c_vp]),
+    "mi355_double_attn_workspace_bytes": (c_size, [c_int] * 6),
+    "mi355_double_attn_fwd": (c_int, [c_vp] * 10 + [c_int] * 7 + [c_vp, c_size, c_vp]),
+    "mi355_linear_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
+    "mi355_token_mix_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),
+    "mi355_layernorm_fwd": (c_int, [c_vp] * 4 + [c_int, c_int, c_float, c_vp]),
+    "mi355_sdpa_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_int, c_vp]),
+    "mi355_cswin_lepe_attn_fwd": (c_int, [c_vp] * 4 + [c_int] * 8 + [c_float, c_int, c_vp]),
+    "mi355_xca_fwd": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp]),
+    "mi355_lpi_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_lpi_fwd": (c_int, [c_vp] * 7 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp, c_size, c_vp]),
+    "mi355_patch_embed_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
+    "mi355_stream_copy": (c_int, [c_vp, c_vp, c_size, c_vp]),
+    "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
+    "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
+}
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Return the loaded library, loading (and type-annotating) it on first use.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise Mi355Error(
+                f"{LIB_PATH} is missing: build it with `python pytorch-attention_amd/build.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU/eager fallback for the MI355X path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError here = header/library drift: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        v = handle.mi355_version()
+        if v != ABI_VERSION:
+            raise Mi355Error(f"libmi355attn ABI version {v} != binding version {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mi355_last_error()
+        raise Mi355Error(f"{what} failed (code {code}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device`, as an int for ctypes."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_device_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise Mi355Error(
+            f"{name} lives on {t.device}: the mi355attn modules only run on an MI355X device tensor "
+            "(move the module and its input to 'cuda'); there is no CPU path in this package.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Per-(device, stream) scratch tensor, grown on demand.  Reuse is safe because every op that uses it
+    is enqueued on the same stream, in order."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def set_option(key, value):
+    check(lib().mi355_set_option(key.encode(), int(value)), f"set_option({key})")
+
+
+def get_option(key):
+    return lib().mi355_get_option(key.encode())
+
+
+class StreamTimer:
+    """HIP-event stopwatch on torch's current stream (events are recorded by the library on that stream)."""
+
+    def __init__(self, device=None):
+        self.device = device
+        self.h = ctypes.c_void_p()
+
+    def start(self):
+        check(lib().mi355_event_time_begin(stream_ptr(self.device), ctypes.byref(self.h)), "event_time_begin")
+
+    def stop_ms(self):
+        ms = ctypes.c_float()
+        check(lib().mi355_event_time_end(stream_ptr(self.device), self.h, ctypes.byref(ms)), "event_time_end")
+        return float(ms.value)

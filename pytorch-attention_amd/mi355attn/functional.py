@@ -1,0 +1,248 @@
+"""Functional layer: tensor-in / tensor-out wrappers over the C ABI (one per entry point of mi355attn.h).
+
+Every function validates dtype/device, makes inputs contiguous, allocates the output (and borrows the
+per-stream workspace) with torch -- device memory and streams are torch's job, the arithmetic is the
+library's -- and raises ``Mi355Error`` on any non-zero return code.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+from ._ffi import check, dptr, lib, require_device_f32, stream_ptr, workspace
+
+PREC_STRICT, PREC_FP16, PREC_BF16 = 0, 1, 2
+ACT_NONE, ACT_GELU = 0, 1
+
+_default_precision = PREC_FP16
+
+
+def set_default_precision(p):
+    """Process-wide default MFMA operand precision for modules that do not pin one (0 strict / 1 fp16 / 2 bf16)."""
+    global _default_precision
+    if p not in (PREC_STRICT, PREC_FP16, PREC_BF16):
+        raise ValueError("precision must be 0 (strict), 1 (fp16) or 2 (bf16)")
+    _default_precision = p
+
+
+def default_precision():
+    return _default_precision
+
+
+def _prec(p):
+    return _default_precision if p is None else p
+
+
+def _opt(t, name):
+    return None if t is None else require_device_f32(t, name)
+
+
+# ---- channel / spatial attention -------------------------------------------------------------------------
+def se_forward(x, w1, w2):
+    """SELayer forward: x (B,C,H,W), w1 (C/r,C), w2 (C,C/r)."""
+    x = require_device_f32(x, "x")
+    w1 = require_device_f32(w1, "fc.0.weight")
+    w2 = require_device_f32(w2, "fc.2.weight")
+    B, C, H, W = x.shape
+    Cr = w1.shape[0]
+    if tuple(w1.shape) != (Cr, C) or tuple(w2.shape) != (C, Cr):
+        raise ValueError(f"SE weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not match C={C}")
+    y = torch.empty_like(x)
+    n = lib().mi355_se_workspace_bytes(B, C, H, W)
+    ws = workspace(n, x.device)
+    check(lib().mi355_se_fwd(dptr(x), dptr(w1), dptr(w2), dptr(y), B, C, Cr, H, W, dptr(ws), ws.numel(),
+                             stream_ptr(x.device)), "mi355_se_fwd")
+    return y
+
+
+def eca_forward(x, wconv):
+    """ECALayer forward: x (B,C,H,W), wconv (1,1,k) or (k,)."""
+    x = require_device_f32(x, "x")
+    wconv = require_device_f32(wconv, "conv.weight").reshape(-1)
+    B, C, H, W = x.shape
+    k = wconv.numel()
+    y = torch.empty_like(x)
+    n = lib().mi355_eca_workspace_bytes(B, C, H, W)
+    ws = workspace(n, x.device)
+    check(lib().mi355_eca_fwd(dptr(x), dptr(wconv), dptr(y), B, C, k, H, W, dptr(ws), ws.numel(),
+                              stream_ptr(x.device)), "mi355_eca_fwd")
+    return y
+
+
+def cbam_forward(x, w1=None, w2=None, wconv=None, stage=0):
+    """CBAM forward (stage 0), ChannelAttention alone (1) or SpatialAttention alone (2)."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    Cr, ks = 0, 0
+    if stage != 2:
+        w1 = require_device_f32(w1, "ca.fc.0.weight").reshape(w1.shape[0], -1)
+        w2 = require_device_f32(w2, "ca.fc.2.weight").reshape(w2.shape[0], -1)
+        Cr = w1.shape[0]
+        if tuple(w1.shape) != (Cr, C) or tuple(w2.shape) != (C, Cr):
+            raise ValueError(f"CBAM channel weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not match C={C}")
+    if stage != 1:
+        wconv = require_device_f32(wconv, "sa.conv.weight")
+        ks = wconv.shape[-1]
+        if wconv.numel() != 2 * ks * ks:
+            raise ValueError(f"CBAM spatial conv weight must be (1,2,k,k), got {tuple(wconv.shape)}")
+    y = torch.empty_like(x)
+    n = lib().mi355_cbam_workspace_bytes(B, C, H, W)
+    ws = workspace(n, x.device)
+    check(lib().mi355_cbam_fwd(dptr(x), dptr(w1 if stage != 2 else None), dptr(w2 if stage != 2 else None),
+                               dptr(wconv if stage != 1 else None), dptr(y), B, C, Cr, ks, H, W, stage,
+                               dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_cbam_fwd")
+    return y
+
+
+def double_attention_forward(x, wA, bA, wB, bB, wV, bV, wP, bP, precision=None):
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    wA = require_device_f32(wA, "convA.weight").reshape(wA.shape[0], -1)
+    wB = require_device_f32(wB, "convB.weight").reshape(wB.shape[0], -1)
+    wV = require_device_f32(wV, "convV.weight").reshape(wV.shape[0], -1)
+    wP = require_device_f32(wP, "proj.weight").reshape(wP.shape[0], -1)
+    bA, bB, bV, bP = (require_device_f32(t, n) for t, n in ((bA, "convA.bias"), (bB, "convB.bias"),
+                                                           (bV, "convV.bias"), (bP, "proj.bias")))
+    cm, cn = wA.shape[0], wB.shape[0]
+    Cout = wP.shape[0]
+    if wV.shape[0] != cn or wP.shape[1] != cm or wA.shape[1] != C:
+        raise ValueError("DoubleAttention weight shapes are inconsistent")
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    n = lib().mi355_double_attn_workspace_bytes(B, C, cm, cn, H, W)
+    ws = workspace(n, x.device)
+    check(lib().mi355_double_attn_fwd(dptr(x), dptr(wA), dptr(bA), dptr(wB), dptr(bB), dptr(wV), dptr(bV),
+                                      dptr(wP), dptr(bP), dptr(y), B, C, cm, cn, H, W, _prec(precision),
+                                      dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_double_attn_fwd")
+    return y
+
+
+# ---- dense building blocks ---------------------------------------------------------------------------------
+def linear(x, weight, bias=None, act=ACT_NONE, gamma=None, resid=None, precision=None, out=None):
+    """Y = resid + gamma * act(x @ weight^T + bias) over the last axis of x (any leading shape)."""
+    ldx = None
+    if isinstance(x, torch.Tensor) and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 \
+            and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and not x.is_contiguous():
+        ldx = x.stride(0)                       # row-strided view (e.g. tokens[:, 0]) is consumed in place
+    else:
+        x = require_device_f32(x, "x")
+    weight = require_device_f32(weight, "weight")
+    bias, gamma = _opt(bias, "bias"), _opt(gamma, "gamma")
+    N, K = weight.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"linear: x last dim {x.shape[-1]} != weight in_features {K}")
+    lead = x.shape[:-1]
+    M = x.numel() // K
+    ldx = K if ldx is None else ldx
+    if resid is not None:
+        resid = require_device_f32(resid, "resid")
+        if resid.numel() != M * N:
+            raise ValueError("linear: residual shape mismatch")
+    y = out if out is not None else torch.empty(*lead, N, dtype=torch.float32, device=x.device)
+    check(lib().mi355_linear_fwd(dptr(x), dptr(weight), dptr(bias), dptr(gamma), dptr(resid), dptr(y),
+                                 M, N, K, ldx, N, act, _prec(precision), stream_ptr(x.device)), "mi355_linear_fwd")
+    return y
+
+
+def token_mix(weight, x, bias=None, act=ACT_NONE, resid=None, precision=None):
+    """Y_b = resid_b + act(weight @ x_b + bias[:,None]) for x (B,N,C), weight (T,N) -> (B,T,C)."""
+    x = require_device_f32(x, "x")
+    weight = require_device_f32(weight, "weight")
+    bias, resid = _opt(bias, "bias"), _opt(resid, "resid")
+    B, N, C = x.shape
+    T = weight.shape[0]
+    if weight.shape[1] != N:
+        raise ValueError("token_mix: weight in_features != sequence length")
+    y = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+    check(lib().mi355_token_mix_fwd(dptr(weight), dptr(x), dptr(bias), dptr(resid), dptr(y), B, T, N, C, act,
+                                    _prec(precision), stream_ptr(x.device)), "mi355_token_mix_fwd")
+    return y
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    x = require_device_f32(x, "x")
+    weight = require_device_f32(weight, "weight")
+    bias = require_device_f32(bias, "bias")
+    cols = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().mi355_layernorm_fwd(dptr(x), dptr(weight), dptr(bias), dptr(y), x.numel() // cols, cols,
+                                    float(eps), stream_ptr(x.device)), "mi355_layernorm_fwd")
+    return y
+
+
+# ---- attention cores ----------------------------------------------------------------------------------------
+def sdpa(qkv, num_heads, scale, precision=None):
+    """qkv (B,N,3*C) straight from the qkv Linear -> (B,N,C) = concat_heads(softmax(QK^T*scale) V)."""
+    qkv = require_device_f32(qkv, "qkv")
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    d = C // num_heads
+    out = torch.empty(B, N, C, dtype=torch.float32, device=qkv.device)
+    check(lib().mi355_sdpa_fwd(dptr(qkv), dptr(out), B, N, num_heads, d, float(scale), _prec(precision),
+                               stream_ptr(qkv.device)), "mi355_sdpa_fwd")
+    return out
+
+
+def cswin_lepe_attention(qkv, getv_w, getv_b, out, reso, c0, Cb, heads, Hsp, Wsp, scale, precision=None):
+    """One LePEAttention branch on the channel slice [c0, c0+Cb) of a (B,L,3,Ctot) qkv buffer; writes `out` (B,L,Ctot)."""
+    qkv = require_device_f32(qkv, "qkv")
+    getv_w = require_device_f32(getv_w, "get_v.weight")
+    getv_b = require_device_f32(getv_b, "get_v.bias")
+    B, L = qkv.shape[0], qkv.shape[1]
+    Ctot = qkv.shape[-1] // 3 if qkv.dim() == 3 else qkv.shape[-1]
+    check(lib().mi355_cswin_lepe_attn_fwd(dptr(qkv), dptr(getv_w), dptr(getv_b), dptr(out), B, reso, Ctot, c0, Cb,
+                                          heads, Hsp, Wsp, float(scale), _prec(precision), stream_ptr(qkv.device)),
+          "mi355_cswin_lepe_attn_fwd")
+    return out
+
+
+def xca_core(qkv, temperature, num_heads, precision=None):
+    qkv = require_device_f32(qkv, "qkv")
+    temperature = require_device_f32(temperature, "temperature").reshape(-1)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(B, N, C, dtype=torch.float32, device=qkv.device)
+    check(lib().mi355_xca_fwd(dptr(qkv), dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
+                              _prec(precision), stream_ptr(qkv.device)), "mi355_xca_fwd")
+    return out
+
+
+def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None, resid=None):
+    """XCiT LPI on tokens x (B,N,C) with eval-mode BatchNorm; optional fused `resid + gamma * LPI(x)`."""
+    x = require_device_f32(x, "x")
+    B, N, C = x.shape
+    if N != H * W:
+        raise ValueError(f"lpi: {N} tokens do not form a {H}x{W} grid")
+    pre = [require_device_f32(t, n) for t, n in ((w1, "conv1.weight"), (b1, "conv1.bias"), (bn_w, "bn.weight"),
+                                                 (bn_b, "bn.bias"), (bn_mean, "bn.running_mean"),
+                                                 (bn_var, "bn.running_var"))]
+    post = [require_device_f32(t, n) for t, n in ((w2, "conv2.weight"), (b2, "conv2.bias"))]
+    gamma, resid = _opt(gamma, "gamma"), _opt(resid, "resid")
+    y = torch.empty_like(x)
+    n = lib().mi355_lpi_workspace_bytes(B, H, W, C)
+    ws = workspace(n, x.device)
+    check(lib().mi355_lpi_fwd(dptr(x), *[dptr(a) for a in pre], float(bn_eps), *[dptr(a) for a in post], dptr(gamma),
+                              dptr(resid), dptr(y), B, H, W, C, dptr(ws), ws.numel(), stream_ptr(x.device)),
+          "mi355_lpi_fwd")
+    return y
+
+
+def patch_embed(img, wp, bp, cls, pos, patch, precision=None):
+    img = require_device_f32(img, "img")
+    wp = require_device_f32(wp, "proj.weight")
+    E = wp.shape[0]
+    wp = wp.reshape(E, -1)
+    bp, cls, pos = (require_device_f32(t, n) for t, n in ((bp, "proj.bias"), (cls, "cls_token"), (pos, "pos")))
+    B, Cin, H, W = img.shape
+    P = (H // patch) * (W // patch)
+    if pos.numel() != (P + 1) * E:
+        raise ValueError("patch_embed: position embedding does not match the patch grid")
+    tokens = torch.empty(B, P + 1, E, dtype=torch.float32, device=img.device)
+    check(lib().mi355_patch_embed_fwd(dptr(img), dptr(wp), dptr(bp), dptr(cls), dptr(pos), dptr(tokens), B, Cin, H, W,
+                                      patch, E, _prec(precision), stream_ptr(img.device)), "mi355_patch_embed_fwd")
+    return tokens
+
+
+def stream_copy(src, dst):
+    check(lib().mi355_stream_copy(dptr(src), dptr(dst), src.numel() * src.element_size(), stream_ptr(src.device)),
+          "mi355_stream_copy")
+    return dst

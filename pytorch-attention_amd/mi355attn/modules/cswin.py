@@ -1,0 +1,101 @@
+"""Drop-in CSWin modules (reference: vision_transformers/cswin.py), forward routed to libmi355attn.
+
+  LePEAttention  cswin.py:51-127   stripe-window MHSA + locally-enhanced positional encoding (dw 3x3 on v)
+  CSWinBlock     cswin.py:130-197  LN -> qkv -> two stripe branches on channel halves -> proj -> MLP
+
+The window partition (img2windows / windows2img, cswin.py:199-216) never materialises: the attention
+kernel gathers q/k/v straight from the (B,L,3,C) qkv buffer with window index math and scatters its
+output back in (B,L,C) order.
+"""
+import torch
+from torch import nn
+
+from .. import functional as F
+
+
+def _stripe(resolution, idx, split_size):
+    if idx == -1:
+        return resolution, resolution
+    if idx == 0:
+        return resolution, split_size
+    if idx == 1:
+        return split_size, resolution
+    raise ValueError(f"LePEAttention: idx must be -1, 0 or 1, got {idx}")
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("only the exact-erf GELU epilogue is built")
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.precision = None
+
+    def forward(self, x, resid=None):
+        h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
+        return F.linear(h, self.fc2.weight, self.fc2.bias, resid=resid, precision=self.precision)
+
+
+class LePEAttention(nn.Module):
+    def __init__(self, dim, resolution, idx, split_size=7, dim_out=None, num_heads=8, attn_drop=0., proj_drop=0.,
+                 qk_scale=None, precision=None):
+        super().__init__()
+        self.dim, self.dim_out = dim, dim_out or dim
+        self.resolution, self.split_size, self.num_heads = resolution, split_size, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.H_sp, self.W_sp = _stripe(resolution, idx, split_size)
+        self.get_v = nn.Conv2d(dim, dim, kernel_size=3, stride=1, padding=1, groups=dim)
+        self.precision = precision
+
+    def run(self, qkv_blc, out, c0):
+        """Attend over channels [c0, c0+dim) of a (B,L,3,Ctot) buffer, writing the same slice of `out` (B,L,Ctot)."""
+        return F.cswin_lepe_attention(qkv_blc, self.get_v.weight, self.get_v.bias, out, self.resolution, c0, self.dim,
+                                      self.num_heads, self.H_sp, self.W_sp, self.scale, self.precision)
+
+    def forward(self, qkv):
+        """qkv: (3,B,L,C) as in the reference (cswin.py:101-105); returns (B,L,C)."""
+        three, B, L, C = qkv.shape
+        assert three == 3 and C == self.dim and L == self.resolution * self.resolution, "flatten img_tokens has wrong size"
+        buf = qkv.permute(1, 2, 0, 3).contiguous().view(B, L, 3 * C)     # no copy when qkv is the usual permuted view
+        out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+        return self.run(buf, out, 0)
+
+
+class CSWinBlock(nn.Module):
+    def __init__(self, dim, reso, num_heads, split_size=7, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0.,
+                 attn_drop=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, last_stage=False, precision=None):
+        super().__init__()
+        if norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("only nn.LayerNorm is built")
+        self.dim, self.num_heads, self.patches_resolution = dim, num_heads, reso
+        self.split_size, self.mlp_ratio, self.precision = split_size, mlp_ratio, precision
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.norm1 = norm_layer(dim)
+        last_stage = last_stage or reso == split_size                   # cswin.py:146-147
+        self.branch_num = 1 if last_stage else 2
+        self.proj = nn.Linear(dim, dim)
+        if last_stage:
+            branches = [LePEAttention(dim, reso, -1, split_size, dim, num_heads, attn_drop, drop, qk_scale, precision)]
+        else:
+            branches = [LePEAttention(dim // 2, reso, i, split_size, dim // 2, num_heads // 2, attn_drop, drop, qk_scale,
+                                      precision) for i in range(2)]
+        self.attns = nn.ModuleList(branches)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), dim, act_layer, drop)
+        self.mlp.precision = precision
+        self.norm2 = norm_layer(dim)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        assert L == self.patches_resolution ** 2, "flatten img_tokens has wrong size"
+        u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = F.linear(u, self.qkv.weight, self.qkv.bias, precision=self.precision)        # (B,L,3C) == (B,L,3,C)
+        att = torch.empty(B, L, C, dtype=torch.float32, device=x.device)
+        if self.branch_num == 2:
+            self.attns[0].run(qkv, att, 0)
+            self.attns[1].run(qkv, att, C // 2)
+        else:
+            self.attns[0].run(qkv, att, 0)
+        x = F.linear(att, self.proj.weight, self.proj.bias, resid=x, precision=self.precision)
+        u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp(u, resid=x)

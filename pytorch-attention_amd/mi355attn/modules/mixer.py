@@ -1,0 +1,39 @@
+"""Drop-in MLP-Mixer layer (reference: mlps/mlp_mixer.py:16-50), forward routed to libmi355attn.
+
+Token mixing is a LEFT multiplication of each image's (N x C) matrix, so the reference's two transposes
+(mlp_mixer.py:47) never materialise: the batched GEMM reads the activation as its K-major operand.
+"""
+from torch import nn
+
+from .. import functional as F
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.precision = None
+
+    def forward(self, x, resid=None):
+        h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
+        return F.linear(h, self.fc2.weight, self.fc2.bias, resid=resid, precision=self.precision)
+
+
+class MixerLayer(nn.Module):
+    def __init__(self, embedding_dim, sequence_len, mlp_ratio=[0.5, 4], drop=0, precision=None):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(embedding_dim)
+        self.token_mlp = Mlp(sequence_len, int(embedding_dim * mlp_ratio[0]), drop=drop)
+        self.norm2 = nn.LayerNorm(embedding_dim)
+        self.channel_mlp = Mlp(embedding_dim, int(embedding_dim * mlp_ratio[1]), drop=drop)
+        self.precision = precision
+        self.channel_mlp.precision = precision
+
+    def forward(self, x):
+        t = self.token_mlp
+        u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        hid = F.token_mix(t.fc1.weight, u, t.fc1.bias, act=F.ACT_GELU, precision=self.precision)     # (B,T,C)
+        x = F.token_mix(t.fc2.weight, hid, t.fc2.bias, resid=x, precision=self.precision)            # (B,N,C)
+        u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.channel_mlp(u, resid=x)

@@ -1,0 +1,135 @@
+"""Drop-in ViT modules (reference: vision_transformers/ViT.py), forward composed from libmi355attn ops.
+
+  Attention           ViT.py:67-89      qkv GEMM -> fused QK^T-softmax-PV core -> proj GEMM(+bias)
+  Mlp                 ViT.py:47-65      GELU after fc1 AND after fc2 (reference behaviour, kept)
+  TransformerEncoder  ViT.py:107-119    pre-LN block, residual adds fused into the GEMM epilogues
+  PatchEmbedding      ViT.py:91-105     per-patch GEMM, im2col folded into the A-operand load
+  VisionTransformer   ViT.py:121-192    cls token appended LAST, logits from token 0, no final LayerNorm
+
+Sub-modules hold parameters only (same creation order as the reference => same init stream under a seed).
+``precision`` (None = package default) selects the MFMA operand format for every GEMM of the module.
+"""
+import torch
+from torch import nn
+
+from .. import functional as F
+
+
+def _bias(lin):
+    return lin.bias if lin.bias is not None else None
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.precision = None
+        self.drop = drop                     # inference engine: dropout is the identity (eval semantics)
+
+    def forward(self, x, resid=None):
+        h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
+        return F.linear(h, self.fc2.weight, self.fc2.bias, act=F.ACT_GELU, resid=resid, precision=self.precision)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=4, qkv_bias=False, attn_drop=0, proj_drop=0, precision=None):
+        super().__init__()
+        assert dim % num_heads == 0
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.precision = precision
+        self.attn_drop, self.proj_drop = attn_drop, proj_drop   # identity at inference
+
+    def forward(self, x, resid=None):
+        qkv = F.linear(x, self.qkv.weight, _bias(self.qkv), precision=self.precision)      # (B,N,3C)
+        ctx = F.sdpa(qkv, self.num_heads, self.scale, precision=self.precision)             # (B,N,C)
+        return F.linear(ctx, self.proj.weight, self.proj.bias, resid=resid, precision=self.precision)
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, image_size=224, patch_size=16, in_channels=3, embedding_dim=768):
+        super().__init__()
+        assert image_size % patch_size == 0
+        self.patch_size = patch_size
+        self.num_patches = (image_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_channels, embedding_dim, kernel_size=patch_size, stride=patch_size)
+        self.precision = None
+
+    def forward(self, x):
+        E = self.proj.weight.shape[0]
+        B, _, H, W = x.shape
+        P = (H // self.patch_size) * (W // self.patch_size)
+        # stand-alone use: no cls/pos -> feed zeros and drop the extra token
+        zeros = torch.zeros(P + 1, E, dtype=torch.float32, device=x.device)
+        tok = F.patch_embed(x, self.proj.weight, self.proj.bias, zeros[0], zeros, self.patch_size, self.precision)
+        return tok[:, :P]
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, dim, num_heads=4, mlp_ratio=4, qkv_bias=False, attn_drop=0, proj_drop=0, precision=None):
+        super().__init__()
+        self.attn = Attention(dim, num_heads, qkv_bias, attn_drop, proj_drop, precision)
+        self.layernorm1 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.mlp.precision = precision
+        self.layernorm2 = nn.LayerNorm(dim)
+
+    def forward(self, x):
+        u = F.layernorm(x, self.layernorm1.weight, self.layernorm1.bias, self.layernorm1.eps)
+        x = self.attn(u, resid=x)
+        u = F.layernorm(x, self.layernorm2.weight, self.layernorm2.bias, self.layernorm2.eps)
+        return self.mlp(u, resid=x)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, image_size=224, patch_size=16, in_channels=3, depths=12, num_heads=4, mlp_ratio=4,
+                 embedding_dim=768, qkv_bias=False, attn_drop=0, proj_drop=0, global_pool="token",
+                 num_classes=1000, precision=None):
+        super().__init__()
+        self.patch_embedding = PatchEmbedding(image_size, patch_size, in_channels, embedding_dim)
+        self.patch_embedding.precision = precision
+        self.global_pool = global_pool
+        self.precision = precision
+        n = self.patch_embedding.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embedding_dim))
+        self.position_embedding = nn.Parameter(torch.zeros(1, n + 1, embedding_dim))
+        self.blocks = nn.Sequential(*(TransformerEncoder(embedding_dim, num_heads, mlp_ratio, qkv_bias, attn_drop,
+                                                         proj_drop, precision) for _ in range(depths)))
+        self.head = nn.Linear(embedding_dim, num_classes)
+        # same init stream as ViT.py:147-158: pos, cls, then every Linear (trunc-normal .02, zero bias) / LayerNorm
+        nn.init.trunc_normal_(self.position_embedding, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._reset)
+
+    @staticmethod
+    def _reset(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.zeros_(m.bias)
+            nn.init.ones_(m.weight)
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        ps = self.patch_embedding.patch_size
+        n = self.position_embedding.shape[1] - 1
+        if (H // ps) * (W // ps) != n or H != W:
+            raise NotImplementedError("position-embedding interpolation (ViT.py:160-178) is outside the MI355X "
+                                      "hot path: run at the native resolution")
+        tok = F.patch_embed(x, self.patch_embedding.proj.weight, self.patch_embedding.proj.bias,
+                            self.cls_token.reshape(-1), self.position_embedding.reshape(n + 1, -1), ps,
+                            self.precision)
+        for blk in self.blocks:
+            tok = blk(tok)
+        if self.global_pool == "token":
+            pooled = tok[:, 0]                                   # row-strided view, consumed in place by the GEMM
+        elif self.global_pool == "avg":
+            pooled = tok[:, 1:].mean(dim=1)
+        else:
+            raise ValueError(self.global_pool)
+        return F.linear(pooled, self.head.weight, self.head.bias, precision=self.precision)

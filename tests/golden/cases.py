@@ -1,0 +1,75 @@
+"""Parity case table shared by the golden generator, the oracle tests and the GPU parity tests.
+
+Every case names the reference class (import path relative to the reference checkout -- the same path
+works against ``pytorch-attention_amd/`` because the drop-in keeps the reference's module layout), its
+constructor arguments, the input shape of the seed protocol (oracle/params.py) and the oracle call that
+restates the forward.  ``small`` cases also get their full output tensor committed under
+``tests/golden/small/``; all cases get fp64 checksums + strided samples in ``golden.json``.
+"""
+import oracle as O
+
+
+def _sd(sd, *keys):
+    return [sd[k] for k in keys]
+
+
+CASES = [
+    # ---- channel / spatial attention ---------------------------------------
+    dict(id="se64", mod="attention_mechanisms.se_module", cls="SELayer", args=(64,), shape=(2, 64, 32, 32),
+         small=True, oracle=lambda x, sd, dt: O.se_forward(x, sd["fc.0.weight"], sd["fc.2.weight"], dt)),
+    dict(id="cbam64", mod="attention_mechanisms.cbam", cls="CBAM", args=(64,), shape=(2, 64, 32, 32),
+         small=True, oracle=lambda x, sd, dt: O.cbam_forward(
+             x, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"], sd["sa.conv.weight"], dt)),
+    dict(id="eca64", mod="attention_mechanisms.eca", cls="ECALayer", args=(64,), shape=(2, 64, 32, 32),
+         small=True, oracle=lambda x, sd, dt: O.eca_forward(x, sd["conv.weight"], dt)),
+    dict(id="da64", mod="attention_mechanisms.double_attention", cls="DoubleAttention", args=(64, 32, 32),
+         shape=(2, 64, 32, 32), small=True,
+         oracle=lambda x, sd, dt: O.double_attention_forward(
+             x, *_sd(sd, "convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight",
+                     "convV.bias", "proj.weight", "proj.bias"), dtype=dt)),
+    dict(id="se256", mod="attention_mechanisms.se_module", cls="SELayer", args=(256,), shape=(4, 256, 56, 56),
+         oracle=lambda x, sd, dt: O.se_forward(x, sd["fc.0.weight"], sd["fc.2.weight"], dt)),
+    dict(id="cbam256", mod="attention_mechanisms.cbam", cls="CBAM", args=(256,), shape=(4, 256, 56, 56),
+         oracle=lambda x, sd, dt: O.cbam_forward(
+             x, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"], sd["sa.conv.weight"], dt)),
+    dict(id="eca256", mod="attention_mechanisms.eca", cls="ECALayer", args=(256,), shape=(4, 256, 56, 56),
+         oracle=lambda x, sd, dt: O.eca_forward(x, sd["conv.weight"], dt)),
+    # ---- ViT (a7-a11) ------------------------------------------------------------------------------
+    dict(id="vit_attn", mod="vision_transformers.ViT", cls="Attention", args=(768, 12), shape=(4, 197, 768),
+         oracle=lambda x, sd, dt: O.vit_attention_forward(x, sd, 12, dt)),
+    dict(id="vit_enc", mod="vision_transformers.ViT", cls="TransformerEncoder", args=(768, 12),
+         shape=(4, 197, 768), oracle=lambda x, sd, dt: O.vit_encoder_forward(x, sd, 12, dt)),
+    dict(id="vit_full", mod="vision_transformers.ViT", cls="VisionTransformer", kwargs=dict(num_heads=12),
+         shape=(2, 3, 224, 224), slow=True, oracle=lambda x, sd, dt: O.vit_forward(x, sd, 12, 12, dt)),
+    # ---- CSWin (a12-a13) ---------------------------------------------------------------------------
+    dict(id="cswin_s1", mod="vision_transformers.cswin", cls="CSWinBlock", args=(64, 56, 2),
+         kwargs=dict(split_size=1, qkv_bias=True), shape=(2, 3136, 64),
+         oracle=lambda x, sd, dt: O.cswin_block_forward(x, sd, 56, 2, 1, False, dt)),
+    dict(id="cswin_s2", mod="vision_transformers.cswin", cls="CSWinBlock", args=(128, 28, 4),
+         kwargs=dict(split_size=2, qkv_bias=True), shape=(2, 784, 128),
+         oracle=lambda x, sd, dt: O.cswin_block_forward(x, sd, 28, 4, 2, False, dt)),
+    dict(id="cswin_s3", mod="vision_transformers.cswin", cls="CSWinBlock", args=(256, 14, 8),
+         kwargs=dict(split_size=7, qkv_bias=True), shape=(2, 196, 256),
+         oracle=lambda x, sd, dt: O.cswin_block_forward(x, sd, 14, 8, 7, False, dt)),
+    dict(id="cswin_s4", mod="vision_transformers.cswin", cls="CSWinBlock", args=(512, 7, 16),
+         kwargs=dict(split_size=7, qkv_bias=True, last_stage=True), shape=(2, 49, 512),
+         oracle=lambda x, sd, dt: O.cswin_block_forward(x, sd, 7, 16, 7, True, dt)),
+    # ---- XCiT (a14-a15) ----------------------------------------------------------------------------
+    dict(id="xca", mod="vision_transformers.xcit", cls="XCA", args=(384, 8), kwargs=dict(qkv_bias=True),
+         shape=(2, 196, 384), oracle=lambda x, sd, dt: O.xca_forward(x, sd, 8, dt)),
+    dict(id="xca_block", mod="vision_transformers.xcit", cls="XCABlock", args=(384, 8),
+         kwargs=dict(qkv_bias=True, eta=1.0), shape=(2, 196, 384), fwd_args=(14, 14),
+         oracle=lambda x, sd, dt: O.xca_block_forward(x, sd, 8, 14, 14, dt)),
+    # ---- MLP-Mixer (a16) ---------------------------------------------------------------------------
+    dict(id="mixer", mod="mlps.mlp_mixer", cls="MixerLayer", args=(512, 196), shape=(2, 196, 512),
+         oracle=lambda x, sd, dt: O.mixer_layer_forward(x, sd, dt)),
+]
+
+BY_ID = {c["id"]: c for c in CASES}
+
+N_SAMPLES = 257            # strided sample positions recorded per case (prime -> hits every residue class)
+
+
+def sample_index(numel, n=N_SAMPLES):
+    """Deterministic sample positions: i * (numel-1) // (n-1), i = 0..n-1 (first and last included)."""
+    return [i * (numel - 1) // (n - 1) for i in range(n)]
