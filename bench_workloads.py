@@ -1,0 +1,108 @@
+"""Extra bench.py workloads: BASELINE.json configs[2..4] plus the class-surface blocks without a BASELINE config.
+
+Each builder returns dict(name, blocks, gather, dtype) like bench.workload_c2.  `work` is the ALGORITHMIC FLOP count per
+call from SURVEY.md 8(d) (FLOP = 2*MAC; softmax / GELU / LayerNorm not counted), `bound` = "mfma" (divided by the dense
+bf16/fp16 MFMA peak regardless of the precision mode in use).
+"""
+import torch
+
+import oracle as O
+
+
+def _seeded(ctor, seed=1234):
+    torch.manual_seed(seed)
+    return ctor().eval()
+
+
+def _sd(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def workload_c3(B, dev):
+    from mi355attn.modules import Attention
+    m = _seeded(lambda: Attention(768, 12))
+    torch.manual_seed(4321)
+    x = torch.randn(B, 197, 768, device=dev)
+    sd = _sd(m)
+    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B,
+                   cpu=lambda xs: O.vit_attention_forward(xs, sd, 12))]
+    return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, gather=None, dtype="f16")
+
+
+def workload_c4(B, dev):
+    from mi355attn.modules import CSWinBlock, XCA, XCABlock
+    cfgs = [("CSWinBlock s1 (64,56,h2,sp1)", (64, 56, 2), dict(split_size=1, qkv_bias=True), (3136, 64), 356.9e6,
+             lambda sd: (lambda xs: O.cswin_block_forward(xs, sd, 56, 2, 1))),
+            ("CSWinBlock s2 (128,28,h4,sp2)", (128, 28, 4), dict(split_size=2, qkv_bias=True), (784, 128), 332.6e6,
+             lambda sd: (lambda xs: O.cswin_block_forward(xs, sd, 28, 4, 2))),
+            ("CSWinBlock s3 (256,14,h8,sp7)", (256, 14, 8), dict(split_size=7, qkv_bias=True), (196, 256), 328.9e6,
+             lambda sd: (lambda xs: O.cswin_block_forward(xs, sd, 14, 8, 7))),
+            ("CSWinBlock s4 (512,7,h16,sp7,last)", (512, 7, 16), dict(split_size=7, qkv_bias=True, last_stage=True), (49, 512),
+             313.65e6, lambda sd: (lambda xs: O.cswin_block_forward(xs, sd, 7, 16, 7, True)))]
+    blocks = []
+    for name, args, kw, shp, flop, mk in cfgs:
+        m = _seeded(lambda: CSWinBlock(*args, **kw))
+        torch.manual_seed(4321)
+        x = torch.randn(B, *shp, device=dev)
+        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m))))
+    xb = _seeded(lambda: XCABlock(384, 8, qkv_bias=True, eta=1.0))
+    xa = _seeded(lambda: XCA(384, 8, qkv_bias=True))
+    torch.manual_seed(4321)
+    x = torch.randn(B, 196, 384, device=dev)
+    sdb, sda = _sd(xb), _sd(xa)
+    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B,
+                       cpu=lambda xs: O.xca_block_forward(xs, sdb, 8, 14, 14)))
+    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B,
+                       cpu=lambda xs: O.xca_forward(xs, sda, 8)))
+    return dict(name="CSWin-T blocks s1-s4 + XCiT-S XCABlock/XCA fwd, B=%d (BASELINE configs[3])" % B, blocks=blocks,
+                gather=None, dtype="f16")
+
+
+def workload_c5(B, dev):
+    from mi355attn.modules import VisionTransformer
+    m = _seeded(lambda: VisionTransformer(num_heads=12))
+    torch.manual_seed(4321)
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    sd = _sd(m)
+
+    def gather(logits, dist):
+        out = torch.empty(dist.get_world_size() * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, logits.contiguous())          # RCCL all-gather over xGMI, 1 MB per rank
+        return out
+
+    blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
+                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12))]
+    return dict(name="ViT-Base full fwd, %d images per GPU, logits all-gathered (BASELINE configs[4])" % B, blocks=blocks,
+                gather=gather, dtype="f16")
+
+
+def workload_mixer(B, dev):
+    from mi355attn.modules import MixerLayer
+    m = _seeded(lambda: MixerLayer(512, 196))
+    torch.manual_seed(4321)
+    x = torch.randn(B, 196, 512, device=dev)
+    sd = _sd(m)
+    blocks = [dict(name="MixerLayer(512,196)", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B,
+                   cpu=lambda xs: O.mixer_layer_forward(xs, sd))]
+    return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, gather=None, dtype="f16")
+
+
+def workload_da(B, dev):
+    from mi355attn.modules import DoubleAttention
+    blocks = []
+    for C, cm, cn, hw, flop in ((64, 32, 32, 32, 21.0e6), (256, 128, 128, 56, 0.0)):
+        m = _seeded(lambda: DoubleAttention(C, cm, cn))
+        torch.manual_seed(4321)
+        x = torch.randn(B, C, hw, hw, device=dev)
+        sd = _sd(m)
+        if not flop:
+            n = hw * hw
+            flop = 2.0 * n * ((cm + 2 * cn) * C + cm * cn * 2 + C * cm)
+        keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight",
+                "proj.bias")
+        blocks.append(dict(name="DoubleAttention(%d,%d,%d)@%dx%d" % (C, cm, cn, hw, hw), module=m.to(dev), x=x, bound="mfma",
+                           work=flop * B, cpu=(lambda sd_: (lambda xs: O.double_attention_forward(xs, *[sd_[k] for k in keys])))(sd)))
+    return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, gather=None, dtype="f16")
+
+
+WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

@@ -50,8 +50,11 @@ typedef void* mi355_stream_t; /* hipStream_t */
 /* ---- library ------------------------------------------------------------------------------------- */
 int         mi355_version(void);            /* ABI version, bumped on any signature change */
 const char* mi355_last_error(void);         /* thread-local message of the last failing call */
-/* Tuning knobs (process-global, read at launch): "chunk_images" (images per pool->scale chunk of the
- * channel-attention family; 0 = library default).  Unknown key -> MI355_EINVAL. */
+/* Tuning knobs of the channel-attention family (process-global, read at launch; results never depend on them):
+ *   "chunk_images"  images per pool->scale chunk (0 = whole batch, default);
+ *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 2);
+ *   "reverse"       1 = the final pass walks the batch backwards (most recently touched rows first), default 0.
+ * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
 long        mi355_get_option(const char* key);
 
@@ -145,6 +148,8 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
 /* ---- measurement helpers --------------------------------------------------------------------------- */
 /* float4 streaming copy of `bytes` (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py. */
 int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t stream);
+/* read-only float4 sweep of `bytes` (sum-reduced, result discarded; `sink` is a 4-byte device scratch). */
+int mi355_stream_read(const void* src, size_t bytes, float* sink, mi355_stream_t stream);
 /* HIP-event stopwatch ON `stream` (torch.cuda.Event only sees torch's current stream): begin records an event and
  * returns an opaque handle; end records the closing event, waits for it and returns elapsed milliseconds. */
 int mi355_event_time_begin(mi355_stream_t stream, void** handle);

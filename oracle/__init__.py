@@ -18,7 +18,7 @@ the generating script, ``tests/golden/golden.json`` + ``tests/golden/small/*.npz
 outputs, and ``tests/test_oracle_golden.py`` checks every oracle function against them (``-m "not gpu"``).
 """
 from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, cbam_channel_forward, \
-    cbam_spatial_forward, double_attention_forward
+    cbam_spatial_forward, double_attention_forward, eca_gate_explicit, spatial_conv_explicit
 from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_mlp_forward,
                           vit_encoder_forward, vit_patch_embed_forward, vit_forward,
                           mixer_layer_forward, sdpa_core)

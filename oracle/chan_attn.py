@@ -6,6 +6,7 @@ reference when judging which of two fp32 answers is closer to the truth).
 """
 import math
 import torch
+import torch.nn.functional as TF
 
 
 def _prep(t, dtype):
@@ -41,12 +42,21 @@ def eca_forward(x, wconv, dtype=torch.float32):
     k = wk.numel()
     pad = (k - 1) // 2
     pooled = x.reshape(b, c, h * w).mean(dim=2)
-    padded = torch.zeros(b, c + 2 * pad, dtype=dtype)
-    padded[:, pad:pad + c] = pooled
-    z = torch.zeros(b, c, dtype=dtype)
-    for j in range(k):                                               # cross-correlation, no flip
-        z = z + wk[j] * padded[:, j:j + c]
+    z = TF.conv1d(pooled[:, None, :], wk.reshape(1, 1, k), padding=pad)[:, 0]     # the ATen op the reference's Conv1d runs
     return x * torch.sigmoid(z)[:, :, None, None]
+
+
+def eca_gate_explicit(pooled, wk):
+    """Tap-by-tap restatement of the k-tap channel conv (cross-correlation, zero pad); cross-checks conv1d in the tests."""
+    b, c = pooled.shape
+    k = wk.numel()
+    pad = (k - 1) // 2
+    padded = torch.zeros(b, c + 2 * pad, dtype=pooled.dtype)
+    padded[:, pad:pad + c] = pooled
+    z = torch.zeros(b, c, dtype=pooled.dtype)
+    for j in range(k):
+        z = z + wk[j] * padded[:, j:j + c]
+    return z
 
 
 def cbam_channel_forward(x, w1, w2, dtype=torch.float32):
@@ -80,14 +90,23 @@ def cbam_spatial_forward(x, wconv, dtype=torch.float32):
     ks = wk.shape[-1]
     pad = ks // 2
     smap = torch.stack([x.mean(dim=1), x.amax(dim=1)], dim=1)        # (B,2,H,W)
-    padded = torch.zeros(b, 2, h + 2 * pad, w + 2 * pad, dtype=dtype)
+    acc = TF.conv2d(smap, wk, padding=pad)[:, 0]                      # the ATen op the reference's Conv2d runs
+    return x * torch.sigmoid(acc)[:, None, :, :]
+
+
+def spatial_conv_explicit(smap, wk):
+    """Tap-by-tap restatement of the KxK 2->1 conv (cross-correlation, zero pad K//2); cross-checks conv2d in the tests."""
+    b, _, h, w = smap.shape
+    ks = wk.shape[-1]
+    pad = ks // 2
+    padded = torch.zeros(b, 2, h + 2 * pad, w + 2 * pad, dtype=smap.dtype)
     padded[:, :, pad:pad + h, pad:pad + w] = smap
-    acc = torch.zeros(b, h, w, dtype=dtype)
+    acc = torch.zeros(b, h, w, dtype=smap.dtype)
     for ch in range(2):
         for dy in range(ks):
             for dx in range(ks):
                 acc = acc + wk[0, ch, dy, dx] * padded[:, ch, dy:dy + h, dx:dx + w]
-    return x * torch.sigmoid(acc)[:, None, :, :]
+    return acc
 
 
 def cbam_forward(x, w1, w2, wconv, dtype=torch.float32):

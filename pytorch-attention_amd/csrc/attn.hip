@@ -1,0 +1,306 @@
+// attn.hip -- fused QK^T-softmax-PV core for short sequences / stripe windows on gfx950 (MFMA 16x16x32).
+//
+// Serves  * ViT Attention core        (ViT.py:82-86):      one "window" = the whole sequence (N = 197), d = 64
+//         * CSWin LePEAttention       (cswin.py:101-127):  stripe windows of 49..98 tokens, d = 32, + LePE
+//
+// One workgroup (4 waves) per (image, window, head).  K and V of the head are converted to the MFMA operand format
+// and parked in LDS (K as [key][d], V transposed as [d][key], both K-contiguous for their MFMA); every wave then owns
+// whole 16-query tiles:
+//     S^T = K . Q^T      (MFMA, A = K tile from LDS, B = Q fragment straight from HBM)      scores never leave registers
+//     softmax over keys  (keys of one query sit in 4 registers x KT tiles x 4 lane groups: in-lane max/sum + 2 xor-shuffles)
+//     O   = P . V        (MFMA, A = P re-packed IN-LANE -- the S^T accumulator layout is already the A-operand layout
+//                         once 32-key blocks are enumerated as (tile 2kb | tile 2kb+1) x (4 lane groups) x 4 --, B = V^T from LDS)
+//     O  /= rowsum, (+ LePE: depth-wise 3x3 over the window image of V, zero padded at the window border), staged through a
+//     per-wave LDS slab and written as whole 128/256-byte rows at their window-scattered token positions.
+// The window partition / head split / merge of the reference (img2windows, windows2img, reshape+permute chains) is pure
+// index math here: token slot t of window w is token l = ((w / nWx) * Hsp + t / Wsp) * reso + (w % nWx) * Wsp + t % Wsp.
+//
+// HBM traffic per call = read qkv once + write out once (the isolated core is HBM-bound: SURVEY.md 8d).
+#include "common.h"
+#include "mma.h"
+
+namespace {
+
+struct AttnArgs {
+    const float* qkv;      // (B, L, 3, Ctot)
+    float* out;            // (B, L, Ctot)
+    const float* lepe_w;   // (Cb, 3, 3) or null
+    const float* lepe_b;   // (Cb)
+    int L, Ctot, c0, heads;
+    int reso, Hsp, Wsp, nWx, nwin;   // window geometry on the token grid
+    int T;                 // tokens per window
+    float scale;
+    int pre_scale;         // 1: q*scale before QK^T (CSWin), 0: (QK^T)*scale (ViT)
+};
+
+template <int PREC, int D, int KT, bool LEPE>
+__global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
+    using M_ = Mma<PREC>;
+    using v8 = typename M_::v8;
+    using v4 = typename M_::v4;
+    using el = typename M_::e;
+    constexpr int NS = M_::NSPLIT;
+    constexpr int TK = KT * 16;               // padded key count
+    constexpr int KP = D + 8;                 // K row pitch (elements)
+    constexpr int VP = TK + 4;                // V^T row pitch (elements, multiple of 4 -> 8-byte aligned reads)
+    constexpr int OP = D + 4;                 // O slab pitch (floats)
+    constexpr int K_EL = TK * KP, V_EL = D * VP;
+    __shared__ __attribute__((aligned(16))) unsigned short s_k[NS * K_EL];
+    __shared__ __attribute__((aligned(16))) unsigned short s_v[NS * V_EL];
+    __shared__ __attribute__((aligned(16))) float s_o[4 * 16 * OP];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int bid = blockIdx.x;
+    const int head = bid % a.heads; bid /= a.heads;
+    const int win = bid % a.nwin;
+    const int b = bid / a.nwin;
+    const int T = a.T;
+    const int wy0 = (win / a.nWx) * a.Hsp, wx0 = (win % a.nWx) * a.Wsp;
+    const int ch0 = a.c0 + head * D;                                  // first channel of this head inside a q/k/v row
+    const long row3 = 3L * a.Ctot;
+    const float* base = a.qkv + (long)b * a.L * row3 + ch0;
+    auto tok = [&](int s) { return (wy0 + s / a.Wsp) * a.reso + wx0 + s % a.Wsp; };   // window slot -> token index
+
+    // ---- phase A: K -> LDS [key][d],  V -> LDS transposed [d][key] -------------------------------------------------
+    constexpr int D4 = D / 4;
+    for (int idx = t; idx < TK * D4; idx += 256) {
+        const int key = idx / D4, d4 = idx % D4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < T) v = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + a.Ctot + d4 * 4);
+        const v4 h = M_::cvt(v);
+        *reinterpret_cast<v4*>(s_k + key * KP + d4 * 4) = h;
+        if constexpr (NS == 2) *reinterpret_cast<v4*>(s_k + K_EL + key * KP + d4 * 4) = M_::cvt_lo(v, h);
+    }
+    for (int idx = t; idx < (TK / 4) * D4; idx += 256) {
+        const int kg = idx / D4, d4 = idx % D4;
+        f4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = kg * 4 + j;
+            r[j] = f4{0.f, 0.f, 0.f, 0.f};
+            if (key < T) r[j] = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + 2 * a.Ctot + d4 * 4);
+        }
+        const f4 c[4] = {{r[0].x, r[1].x, r[2].x, r[3].x}, {r[0].y, r[1].y, r[2].y, r[3].y},
+                         {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4 h = M_::cvt(c[q]);
+            *reinterpret_cast<v4*>(s_v + (d4 * 4 + q) * VP + kg * 4) = h;
+            if constexpr (NS == 2) *reinterpret_cast<v4*>(s_v + V_EL + (d4 * 4 + q) * VP + kg * 4) = M_::cvt_lo(c[q], h);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: each wave owns 16-query tiles ------------------------------------------------------------------------
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqt = (T + 15) >> 4;
+    float* slab = s_o + wave * 16 * OP;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        // Q fragments (B operand of S^T = K.Q^T): column q = l15, k = d = ks*32 + g*8 + [0,8)
+        const int qs = qt * 16 + l15;
+        v8 qf[D / 32][NS];
+        {
+            const float* qrow = base + (long)tok(qs < T ? qs : 0) * row3;
+#pragma unroll
+            for (int ks = 0; ks < D / 32; ++ks) {
+                f4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+                if (qs < T) {
+                    lo4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8);
+                    hi4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8 + 4);
+                }
+                if (a.pre_scale) { lo4 = lo4 * a.scale; hi4 = hi4 * a.scale; }
+                const v4 h0 = M_::cvt(lo4), h1 = M_::cvt(hi4);
+                qf[ks][0] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                if constexpr (NS == 2) {
+                    const v4 e0 = M_::cvt_lo(lo4, h0), e1 = M_::cvt_lo(hi4, h1);
+                    qf[ks][1] = v8{e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                }
+            }
+        }
+        // S^T tiles: lane holds S^T[key = kt*16 + g*4 + r][q = l15]
+        f4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
+            if (kt * 16 < T) {
+#pragma unroll
+                for (int ks = 0; ks < D / 32; ++ks) {
+                    v8 kf[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp)
+                        kf[sp] = *reinterpret_cast<const v8*>(s_k + sp * K_EL + (kt * 16 + l15) * KP + ks * 32 + g * 8);
+                    s[kt] = mma_step<PREC>(kf, qf[ks], s[kt]);
+                }
+            }
+        }
+        // softmax over keys (masked beyond T)
+        const float post = a.pre_scale ? 1.0f : a.scale;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                const float v = (key < T) ? s[kt][r] * post : -INFINITY;
+                s[kt][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, WAVE));
+        m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(s[kt][r] - m);      // exp(-inf) = 0 for masked keys
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, WAVE);
+        sum += __shfl_xor(sum, 32, WAVE);
+        // O = P.V : A = P (row q = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = V^T same enumeration
+        f4 o[D / 16];
+#pragma unroll
+        for (int nt = 0; nt < D / 16; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KT / 2; ++kb) {
+            if (kb * 32 < T) {
+                v8 pf[NS];
+                {
+                    const f4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
+                    const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
+                    pf[0] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    if constexpr (NS == 2) {
+                        const v4 e0 = M_::cvt_lo(p0, h0), e1 = M_::cvt_lo(p1, h1);
+                        pf[1] = v8{e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < D / 16; ++nt) {
+                    v8 vf[NS];
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) {
+                        const unsigned short* vr = s_v + sp * V_EL + (nt * 16 + l15) * VP + kb * 32 + g * 4;
+                        const v4 a0 = *reinterpret_cast<const v4*>(vr);
+                        const v4 a1 = *reinterpret_cast<const v4*>(vr + 16);
+                        vf[sp] = v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    }
+                    o[nt] = mma_step<PREC>(pf, vf, o[nt]);
+                }
+            }
+        }
+        // normalise: o[nt][r] belongs to query row g*4 + r, whose row sum lives in lanes with l15 == g*4 + r
+        float inv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inv[r] = 1.0f / __shfl(sum, g * 4 + r, WAVE);
+#pragma unroll
+        for (int nt = 0; nt < D / 16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float val = o[nt][r] * inv[r];
+                if constexpr (LEPE) {
+                    // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo
+                    const int qslot = qt * 16 + g * 4 + r;
+                    if (qslot < T) {
+                        const int d = nt * 16 + l15, cidx = head * D + d;        // channel inside this branch
+                        const int ty = qslot / a.Wsp, tx = qslot % a.Wsp;
+                        float acc = a.lepe_b[cidx];
+                        const float* w9 = a.lepe_w + (long)cidx * 9;
+#pragma unroll
+                        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int yy = ty + dy, xx = tx + dx;
+                                if (yy >= 0 && yy < a.Hsp && xx >= 0 && xx < a.Wsp) {
+                                    const int ss = yy * a.Wsp + xx;
+                                    float vv = (float)(*reinterpret_cast<const el*>(s_v + d * VP + ss));
+                                    if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(s_v + V_EL + d * VP + ss));
+                                    acc += w9[(dy + 1) * 3 + dx + 1] * vv;
+                                }
+                            }
+                        val += acc;
+                    }
+                }
+                slab[(g * 4 + r) * OP + nt * 16 + l15] = val;
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // row-contiguous stores: D/4 lanes per query row
+        constexpr int LPR = D / 4, RPI = 64 / LPR;
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int r = it * RPI + lane / LPR, c4 = (lane % LPR) * 4;
+            const int qslot = qt * 16 + r;
+            if (qslot < T) {
+                const f4 v = *reinterpret_cast<const f4*>(slab + r * OP + c4);
+                *reinterpret_cast<f4*>(a.out + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+template <int D, bool LEPE>
+int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st) {
+    const int grid = B * a.nwin * a.heads;
+#define GO(P, KT_) win_attn_kernel<P, D, KT_, LEPE><<<grid, 256, 0, st>>>(a)
+#define BYKT(P)                              \
+    do {                                     \
+        if (a.T <= 64) GO(P, 4);             \
+        else if (a.T <= 128) GO(P, 8);       \
+        else GO(P, 14);                      \
+    } while (0)
+    switch (precision) {
+        case MI355_PREC_STRICT: BYKT(0); break;
+        case MI355_PREC_FP16:   BYKT(1); break;
+        case MI355_PREC_BF16:   BYKT(2); break;
+        default: return mi355::fail(MI355_EINVAL, "precision must be 0, 1 or 2 (got %d)", precision);
+    }
+#undef BYKT
+#undef GO
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_sdpa_fwd(const float* qkv, float* out, int B, int N, int heads, int d, float scale, int precision,
+                   mi355_stream_t stream) {
+    MI355_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0);
+    if (!(d == 32 || d == 64)) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_fwd: head dim %d (built: 32, 64)", d);
+    if (N > 224) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_fwd: sequence length %d > 224 (single-pass softmax core)", N);
+    MI355_CHECK_ARG(aligned16(qkv) && aligned16(out));
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.L = N; a.Ctot = heads * d; a.c0 = 0; a.heads = heads;
+    a.reso = N; a.Hsp = 1; a.Wsp = N; a.nWx = 1; a.nwin = 1; a.T = N; a.scale = scale; a.pre_scale = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = (d == 64) ? launch_attn<64, false>(a, B, precision, st) : launch_attn<32, false>(a, B, precision, st);
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float* getv_b, float* out, int B, int reso, int Ctot,
+                              int c0, int Cb, int heads, int Hsp, int Wsp, float scale, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(qkv && getv_w && getv_b && out);
+    MI355_CHECK_ARG(B > 0 && reso > 0 && Ctot > 0 && c0 >= 0 && Cb > 0 && c0 + Cb <= Ctot && heads > 0 && Cb % heads == 0);
+    MI355_CHECK_ARG(Hsp > 0 && Wsp > 0 && reso % Hsp == 0 && reso % Wsp == 0);
+    const int d = Cb / heads, T = Hsp * Wsp;
+    if (d != 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn_fwd: head dim %d (built: 32)", d);
+    if (T > 224) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn_fwd: %d tokens per stripe window > 224", T);
+    MI355_CHECK_ARG((Ctot & 3) == 0 && (c0 & 3) == 0 && aligned16(qkv) && aligned16(out));
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.lepe_w = getv_w; a.lepe_b = getv_b;
+    a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
+    a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = T;
+    a.scale = scale; a.pre_scale = 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = launch_attn<32, true>(a, B, precision, st);
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -21,16 +21,17 @@ constexpr int RPB = 16;   // rows (channels) per workgroup in the scale kernels
 using v4f = float __attribute__((ext_vector_type(4)));   // 16-byte lane vector (global_load/store_dwordx4)
 
 // ---------------------------------------------------------------------------------------------------
-// K1: per-row global pooling.  One wave per row, grid-strided.  avg[row] = sum/HW (true division, like
-// ATen's mean), mx[row] = max (CBAM only).
+// K1: per-row global pooling.  Workgroup = (image, group of RPB channels) -- the SAME block <-> rows map as the
+// scale kernels, so a row is pooled and later rescaled by workgroups that sit on the same XCD (block id mod 8).
+// One wave per row.  avg[row] = sum/HW (true division, like ATen's mean), mx[row] = max (CBAM only).
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_MAX, bool VEC>
 __global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ x, float* __restrict__ avg,
-                                                       float* __restrict__ mx, long rows, int HW) {
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long nwaves = (long)gridDim.x * 4;
-    for (long row = wave0; row < rows; row += nwaves) {
+                                                       float* __restrict__ mx, int C, int HW, int groups) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * RPB;
+    for (int r = wave; r < RPB && c0 + r < C; r += 4) {
+        const long row = (long)b * C + c0 + r;
         const float* p = x + row * HW;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         float m = -INFINITY;
@@ -70,6 +71,16 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict_
     }
 }
 
+// Second-pass block order.  With `reverse` the pass walks the (image, group) list backwards in units of 8 so
+// that (a) the rows the previous pass touched LAST (still in L2 / Infinity Cache) are re-read FIRST and (b) a
+// group stays on the XCD (block id mod 8) that pooled it.
+__device__ __forceinline__ int second_pass_block(int bid, int nblocks, int reverse) {
+    if (!reverse) return bid;
+    const int full = nblocks & ~7;                       // reversible part; the (<8) tail keeps its place
+    if (bid >= full) return bid;
+    return (full - 8 - (bid & ~7)) + (bid & 7);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Excite helpers (run by one whole 256-thread workgroup; smem: p[C] | h[Cr]).
 // hidden_j = relu(sum_c w1[j,c] * p[c]) computed by 16-lane groups (16 j's per pass).
@@ -90,17 +101,29 @@ __device__ __forceinline__ float dot16(const float* __restrict__ wrow, const flo
 //   MODE 0: SE   gate_c = sigmoid(sum_j w2[c,j] relu(sum_c' w1[j,c'] p[c']))
 //   MODE 1: ECA  gate_c = sigmoid(sum_j wk[j] p[c + j - pad])
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, bool VEC>
+template <bool NT>
+__device__ __forceinline__ v4f ldx(const v4f* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void stx(v4f v, v4f* p) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int MODE, bool VEC, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
                                                         const float* __restrict__ wa, const float* __restrict__ wb,
-                                                        float* __restrict__ y, int C, int Cr, int HW, int groups) {
+                                                        float* __restrict__ y, int C, int Cr, int HW, int groups, int reverse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_p = smem;            // C
     float* s_h = smem + C;        // Cr (SE)
     float* s_g = s_h + Cr;        // RPB
     const int t = threadIdx.x;
-    const int b = blockIdx.x / groups;
-    const int c0 = (blockIdx.x % groups) * RPB;
+    const int blk = second_pass_block(blockIdx.x, gridDim.x, reverse);
+    const int b = blk / groups;
+    const int c0 = (blk % groups) * RPB;
     const float* pb = pooled + (long)b * C;
 
     if constexpr (MODE == 0) {
@@ -142,16 +165,16 @@ __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict
             const int n4 = HW >> 2;
             int i = lane;
             for (; i + 192 < n4; i += 256) {
-                v4f a = __builtin_nontemporal_load(&xr[i]), bq = __builtin_nontemporal_load(&xr[i + 64]);
-                v4f c = __builtin_nontemporal_load(&xr[i + 128]), d = __builtin_nontemporal_load(&xr[i + 192]);
-                __builtin_nontemporal_store(a * g, &yr[i]);
-                __builtin_nontemporal_store(bq * g, &yr[i + 64]);
-                __builtin_nontemporal_store(c * g, &yr[i + 128]);
-                __builtin_nontemporal_store(d * g, &yr[i + 192]);
+                v4f a = ldx<NTL>(&xr[i]), bq = ldx<NTL>(&xr[i + 64]);
+                v4f c = ldx<NTL>(&xr[i + 128]), d = ldx<NTL>(&xr[i + 192]);
+                stx<NTS>(a * g, &yr[i]);
+                stx<NTS>(bq * g, &yr[i + 64]);
+                stx<NTS>(c * g, &yr[i + 128]);
+                stx<NTS>(d * g, &yr[i + 192]);
             }
             for (; i < n4; i += 64) {
-                v4f a = __builtin_nontemporal_load(&xr[i]);
-                __builtin_nontemporal_store(a * g, &yr[i]);
+                v4f a = ldx<NTL>(&xr[i]);
+                stx<NTS>(a * g, &yr[i]);
             }
         } else {
             for (int i = lane; i < HW; i += 64) y[off + i] = x[off + i] * g;
@@ -249,14 +272,18 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __
 
 // ---------------------------------------------------------------------------------------------------
 // CBAM K4: spatial gate gs[b,p] = sigmoid(conv_ks x ks (smap[b]) ), 2->1 channels, zero pad ks/2, no bias,
-// cross-correlation.  Workgroup = (image, band of TR full-width rows); the band plus halo sits in LDS.
-// smem: w[2*ks*ks] | tile[2][(TR+ks-1)][(W+ks-1)]
+// cross-correlation.  Workgroup = (image, band of TR full-width rows); the band plus halo sits in LDS and every
+// thread produces 4 horizontally adjacent outputs (each LDS value feeds up to 4 taps from a register).
+// smem: w[2*ks*ks] | tile[2][(TR+ks-1)][TW]   with TW = 4*ceil(W/4) + ks - 1
 // ---------------------------------------------------------------------------------------------------
+template <int KS>   // KS > 0: compile-time kernel size (fully unrolled taps); KS == 0: runtime ks
 __global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __restrict__ smap, const float* __restrict__ wconv,
-                                                               float* __restrict__ gs, int H, int W, int ks, int TR, int bands) {
+                                                               float* __restrict__ gs, int H, int W, int ks_rt, int TR, int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ks = KS > 0 ? KS : ks_rt;
     const int kk = ks * ks, pad = ks / 2;
-    const int TW = W + ks - 1, TH = TR + ks - 1;
+    const int quads = (W + 3) >> 2;
+    const int TW = quads * 4 + ks - 1, TH = TR + ks - 1;
     float* s_w = smem;
     float* s_t = smem + ((2 * kk + 3) & ~3);
     const int t = threadIdx.x;
@@ -271,16 +298,40 @@ __global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __r
     }
     __syncthreads();
     const int rows_here = min(TR, H - r0);
-    for (int o = t; o < rows_here * W; o += 256) {
-        const int r = o / W, col = o % W;
-        float acc = 0.f;
-        for (int ch = 0; ch < 2; ++ch)
-            for (int dy = 0; dy < ks; ++dy) {
-                const float* trow = s_t + (ch * TH + r + dy) * TW + col;
-                const float* wrow = s_w + ch * kk + dy * ks;
-                for (int dx = 0; dx < ks; ++dx) acc += wrow[dx] * trow[dx];
+    for (int o = t; o < rows_here * quads; o += 256) {
+        const int r = o / quads, col = (o % quads) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int ch = 0; ch < 2; ++ch) {
+            if constexpr (KS > 0) {
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const float* trow = s_t + (ch * TH + r + dy) * TW + col;
+                    const float* wrow = s_w + ch * kk + dy * KS;
+                    float v[KS + 3];
+#pragma unroll
+                    for (int i = 0; i < KS + 3; ++i) v[i] = trow[i];
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        const float w = wrow[dx];
+                        a0 += w * v[dx]; a1 += w * v[dx + 1]; a2 += w * v[dx + 2]; a3 += w * v[dx + 3];
+                    }
+                }
+            } else {
+                for (int dy = 0; dy < ks; ++dy) {
+                    const float* trow = s_t + (ch * TH + r + dy) * TW + col;
+                    const float* wrow = s_w + ch * kk + dy * ks;
+                    for (int dx = 0; dx < ks; ++dx) {
+                        const float w = wrow[dx];
+                        a0 += w * trow[dx]; a1 += w * trow[dx + 1]; a2 += w * trow[dx + 2]; a3 += w * trow[dx + 3];
+                    }
+                }
             }
-        gs[(long)b * H * W + (long)(r0 + r) * W + col] = sigmoidf_(acc);
+        }
+        float* out = gs + (long)b * H * W + (long)(r0 + r) * W + col;
+        const float res[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col + q < W) out[q] = sigmoidf_(res[q]);
     }
 }
 
@@ -289,13 +340,14 @@ __global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __r
 // rounded to fp32 before the spatial multiply).  Workgroup = (image, RPB channels); waves walk pixel
 // chunks (gs stays in 4 VGPRs) and loop the RPB rows inside.  gc or gs may be NULL (= 1).
 // ---------------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gc,
                                                         const float* __restrict__ gs, float* __restrict__ y,
-                                                        int C, int HW, int groups) {
+                                                        int C, int HW, int groups, int reverse) {
     __shared__ float s_g[RPB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * RPB;
+    const int blk = second_pass_block(blockIdx.x, gridDim.x, reverse);
+    const int b = blk / groups, c0 = (blk % groups) * RPB;
     const int nrows = min(RPB, C - c0);
     if (t < RPB) s_g[t] = (gc && t < nrows) ? gc[(long)b * C + c0 + t] : 1.0f;
     __syncthreads();
@@ -313,9 +365,9 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
 #pragma unroll 4
             for (int r = 0; r < nrows; ++r) {
                 const float g = s_g[r];
-                v4f v = __builtin_nontemporal_load(&reinterpret_cast<const v4f*>(xb + (long)r * HW)[i]);
+                v4f v = ldx<NTL>(&reinterpret_cast<const v4f*>(xb + (long)r * HW)[i]);
                 v = (v * g) * s4;
-                __builtin_nontemporal_store(v, &reinterpret_cast<v4f*>(yb + (long)r * HW)[i]);
+                stx<NTS>(v, &reinterpret_cast<v4f*>(yb + (long)r * HW)[i]);
             }
         }
     } else {
@@ -336,17 +388,40 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restri
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
-inline int pool_grid(long rows) { return (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096); }
-
-inline int resolve_chunk(int B, long bytes_per_image) {
-    long ci = mi355::opt_chunk_images();
-    if (ci <= 0) {
-        // default: keep one chunk's input well inside the 256 MiB Infinity Cache (~96 MiB of x)
-        ci = (96L << 20) / (bytes_per_image > 0 ? bytes_per_image : 1);
-        if (ci < 1) ci = 1;
+// read-only sweep (sum reduction, one atomic-free store per block only if the sum is NaN-free-impossible):
+// the bandwidth yardstick for the pooling passes and for Infinity-Cache residency experiments.
+__global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ src, long n4, float* __restrict__ sink) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        s0 += a.x + b.x + c.x + d.x; s1 += a.y + b.y + c.y + d.y;
+        s2 += a.z + b.z + c.z + d.z; s3 += a.w + b.w + c.w + d.w;
     }
-    return (int)(ci > B ? B : ci);
+    for (; i < n4; i += stride) { float4 a = src[i]; s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w; }
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
+    if ((threadIdx.x & 63) == 0 && s == 123456.789f) sink[0] = s;   // keeps the loads live; practically never stores
 }
+
+struct Tune { int chunk; int ntl; int nts; int reverse; };
+
+inline Tune resolve_tune(int B) {
+    Tune t;
+    long ci = mi355::opt_chunk_images();                 // 0 = whole batch in one pass pair (default)
+    t.chunk = (ci <= 0 || ci > B) ? B : (int)ci;
+    const long nt = mi355::opt_nt();
+    t.ntl = (nt & 1) != 0;
+    t.nts = (nt & 2) != 0;
+    t.reverse = mi355::opt_reverse() != 0;
+    return t;
+}
+
+#define NT_DISPATCH(ntl, nts, CALL)                                        \
+    do {                                                                   \
+        if (ntl) { if (nts) { CALL(true, true); } else { CALL(true, false); } } \
+        else     { if (nts) { CALL(false, true); } else { CALL(false, false); } } \
+    } while (0)
 
 }  // namespace
 
@@ -366,23 +441,27 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     const int groups = cdiv(C, RPB);
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
-    const int chunk = resolve_chunk(B, (long)C * HW * 4);
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+    const Tune tu = resolve_tune(B);
+    for (int b0 = 0; b0 < B; b0 += tu.chunk) {
+        const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;
         const float* xc = x + (long)b0 * C * HW;
         float* yc = y + (long)b0 * C * HW;
         float* pc = pooled + (long)b0 * C;
-        const long rows = (long)nb * C;
-        if (vec) pool_rows_kernel<false, true><<<pool_grid(rows), 256, 0, st>>>(xc, pc, nullptr, rows, HW);
-        else     pool_rows_kernel<false, false><<<pool_grid(rows), 256, 0, st>>>(xc, pc, nullptr, rows, HW);
         const int grid = nb * groups;
-        if (mode == 0) {
-            if (vec) gate_scale_kernel<0, true><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups);
-            else     gate_scale_kernel<0, false><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups);
-        } else {
-            if (vec) gate_scale_kernel<1, true><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups);
-            else     gate_scale_kernel<1, false><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups);
-        }
+        if (vec) pool_rows_kernel<false, true><<<grid, 256, 0, st>>>(xc, pc, nullptr, C, HW, groups);
+        else     pool_rows_kernel<false, false><<<grid, 256, 0, st>>>(xc, pc, nullptr, C, HW, groups);
+#define SCALE_CALL(NTL, NTS)                                                                                          \
+        do {                                                                                                           \
+            if (mode == 0) {                                                                                           \
+                if (vec) gate_scale_kernel<0, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse);   \
+                else     gate_scale_kernel<0, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse);  \
+            } else {                                                                                                   \
+                if (vec) gate_scale_kernel<1, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse);  \
+                else     gate_scale_kernel<1, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse); \
+            }                                                                                                          \
+        } while (0)
+        NT_DISPATCH(tu.ntl, tu.nts, SCALE_CALL);
+#undef SCALE_CALL
     }
     MI355_LAUNCH_CHECK();
     (void)ws_bytes;
@@ -432,17 +511,20 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
     float* smap = reinterpret_cast<float*>(wsp + 3 * bc);
     float* gs = reinterpret_cast<float*>(wsp + 3 * bc + r16((size_t)B * 2 * HW * 4));
 
-    // spatial-gate band geometry: LDS tile (2 ch) of (TR + ks - 1) x (W + ks - 1) floats <= 48 KiB
+    // spatial-gate band geometry: 4 outputs per thread, about one output quad per thread per band,
+    // LDS tile (2 ch) of (TR + ks - 1) x (4*ceil(W/4) + ks - 1) floats <= 60 KiB
     int TR = H, bands = 1;
     size_t smem_gate = 0;
     if (do_s) {
-        const int TW = W + ks - 1;
-        const long budget = (48L * 1024 / 4 - ((2 * ks * ks + 3) & ~3)) / (2L * TW);
-        if (budget < ks) return mi355::fail(MI355_EUNSUPPORTED, "W=%d too wide for the %dx%d spatial-gate tile", W, ks, ks);
-        TR = (int)(budget - (ks - 1));
+        const int quads = (W + 3) / 4, TW = quads * 4 + ks - 1, wpad = (2 * ks * ks + 3) & ~3;
+        TR = 256 / quads;
+        if (TR < 1) TR = 1;
         if (TR > H) TR = H;
+        while (TR > 1 && (size_t)(wpad + 2 * (TR + ks - 1) * TW) * 4 > 60 * 1024) --TR;
+        smem_gate = (size_t)(wpad + 2 * (TR + ks - 1) * TW) * 4;
+        if (smem_gate > 60 * 1024)
+            return mi355::fail(MI355_EUNSUPPORTED, "W=%d too wide for the %dx%d spatial-gate tile", W, ks, ks);
         bands = cdiv(H, TR);
-        smem_gate = (size_t)(((2 * ks * ks + 3) & ~3) + 2 * (TR + ks - 1) * TW) * 4;
     }
     const size_t smem_cg = (size_t)(2 * C + Cr) * 4;
     if (do_c && smem_cg > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
@@ -450,9 +532,9 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
     const int groups = cdiv(C, RPB);
     const int VW = vec ? 4 : 1;
     const int tiles = cdiv(HW / VW, 64);
-    const int chunk = resolve_chunk(B, (long)C * HW * 4);
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+    const Tune tu = resolve_tune(B);
+    for (int b0 = 0; b0 < B; b0 += tu.chunk) {
+        const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;
         const float* xc = x + (long)b0 * C * HW;
         float* yc = y + (long)b0 * C * HW;
         float* avgc = avg + (long)b0 * C;
@@ -460,19 +542,27 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
         float* gcc = gc + (long)b0 * C;
         float* smc = smap + (long)b0 * 2 * HW;
         float* gsc = gs + (long)b0 * HW;
-        const long rows = (long)nb * C;
         if (do_c) {
-            if (vec) pool_rows_kernel<true, true><<<pool_grid(rows), 256, 0, st>>>(xc, avgc, mxc, rows, HW);
-            else     pool_rows_kernel<true, false><<<pool_grid(rows), 256, 0, st>>>(xc, avgc, mxc, rows, HW);
+            if (vec) pool_rows_kernel<true, true><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
+            else     pool_rows_kernel<true, false><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
             cbam_channel_gate_kernel<<<nb, 256, smem_cg, st>>>(avgc, mxc, w1, w2, gcc, C, Cr);
         }
         if (do_s) {
             if (vec) cbam_spatial_stats_kernel<true><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
             else     cbam_spatial_stats_kernel<false><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
-            cbam_spatial_gate_kernel<<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
+            if (ks == 7)      cbam_spatial_gate_kernel<7><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
+            else if (ks == 3) cbam_spatial_gate_kernel<3><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
+            else              cbam_spatial_gate_kernel<0><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
         }
-        if (vec) cbam_apply_kernel<true><<<nb * groups, 256, 0, st>>>(xc, do_c ? gcc : nullptr, do_s ? gsc : nullptr, yc, C, HW, groups);
-        else     cbam_apply_kernel<false><<<nb * groups, 256, 0, st>>>(xc, do_c ? gcc : nullptr, do_s ? gsc : nullptr, yc, C, HW, groups);
+        const float* gcp = do_c ? gcc : nullptr;
+        const float* gsp = do_s ? gsc : nullptr;
+#define APPLY_CALL(NTL, NTS)                                                                                             \
+        do {                                                                                                              \
+            if (vec) cbam_apply_kernel<true, NTL, NTS><<<nb * groups, 256, 0, st>>>(xc, gcp, gsp, yc, C, HW, groups, tu.reverse);  \
+            else     cbam_apply_kernel<false, NTL, NTS><<<nb * groups, 256, 0, st>>>(xc, gcp, gsp, yc, C, HW, groups, tu.reverse); \
+        } while (0)
+        NT_DISPATCH(tu.ntl, tu.nts, APPLY_CALL);
+#undef APPLY_CALL
     }
     MI355_LAUNCH_CHECK();
     return MI355_OK;
@@ -485,6 +575,16 @@ int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t s
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     stream_copy_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const float4*>(src),
                                                                             static_cast<float4*>(dst), n4);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_stream_read(const void* src, size_t bytes, float* sink, mi355_stream_t stream) {
+    MI355_CHECK_ARG(src && sink && bytes % 16 == 0 && aligned16(src));
+    const long n4 = (long)(bytes / 16);
+    if (n4 == 0) return MI355_OK;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    stream_read_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const float4*>(src), n4, sink);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

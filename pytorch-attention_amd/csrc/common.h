@@ -14,6 +14,16 @@ namespace mi355 {
 char* err_buf();                      // thread-local 512-byte buffer (defined in api.hip)
 int   fail(int code, const char* fmt, ...);
 long  opt_chunk_images();
+long  opt_nt();
+long  opt_reverse();
+// GEMM engine (gemm.hip), shared by the other translation units.  NT: B is (N,K) K-contiguous; KN: B is (K,N) N-contiguous.
+int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
+            int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st);
+int gemm_nt_batched(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc, long sA,
+                    long sB, long sC, int precision, hipStream_t st);
+int gemm_kn_batched(const float* A, const float* B, const float* bias_row, const float* resid, float* C, int batch, int M,
+                    int N, int K, int lda, int ldb, int ldc, long sA, long sB, long sC, int act, int precision,
+                    hipStream_t st);
 }  // namespace mi355
 
 #define MI355_CHECK_ARG(cond)                                                                   \

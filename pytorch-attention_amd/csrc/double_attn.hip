@@ -1,0 +1,101 @@
+// double_attn.hip -- A2-Net DoubleAttention forward (double_attention.py:32-48) on the MFMA GEMM engine.
+//
+//   [A; Bm; V] = [WA; WB; WV] X_b + bias          one batched K-major GEMM (the three 1x1 convs share the read of X)
+//   Bm = softmax over HW (rows),  V = softmax over c_n (columns)      two small fp32 kernels, in place
+//   G = A Bm^T (c_m x c_n, contraction over HW)    batched NT GEMM
+//   Z = G V    (c_m x HW)                          batched K-major GEMM
+//   y = WP Z + bP                                   batched K-major GEMM with row bias
+// x, y are NCHW, i.e. each image is a (C x HW) matrix with HW contiguous: the activation is always the K-major operand
+// of the engine, never transposed in memory.
+#include "common.h"
+
+namespace {
+
+// in-place softmax over the last axis of `rows` rows; row r of image b starts at base + b*img_stride + r*cols
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ p, int rows_per_img, int cols, long img_stride,
+                                                          long total_rows) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    for (long r = wave0; r < total_rows; r += nw) {
+        float* row = p + (r / rows_per_img) * img_stride + (r % rows_per_img) * (long)cols;
+        float m = -INFINITY;
+        for (int i = lane; i < cols; i += 64) m = fmaxf(m, row[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < cols; i += 64) s += expf(row[i] - m);
+        s = wave_sum(s);
+        for (int i = lane; i < cols; i += 64) row[i] = expf(row[i] - m) / s;
+    }
+}
+
+// in-place softmax over the channel axis: element (b, j, p) at base + b*img_stride + j*HW + p, j < cn
+__global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ p, int cn, int HW, long img_stride, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float* col = p + (i / HW) * img_stride + (i % HW);
+    float m = -INFINITY;
+    for (int j = 0; j < cn; ++j) m = fmaxf(m, col[(long)j * HW]);
+    float s = 0.f;
+    for (int j = 0; j < cn; ++j) s += expf(col[(long)j * HW] - m);
+    for (int j = 0; j < cn; ++j) col[(long)j * HW] = expf(col[(long)j * HW] - m) / s;
+}
+
+inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+}  // namespace
+
+extern "C" {
+
+// workspace: Wcat (M3 x C) | bcat (M3) | ABV (B, M3, HW) | G (B, cm, cn) | Z (B, cm, HW)
+size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, int W) {
+    const size_t M3 = (size_t)cm + 2 * (size_t)cn, HW = (size_t)H * W;
+    return r16(M3 * C * 4) + r16(M3 * 4) + r16((size_t)B * M3 * HW * 4) + r16((size_t)B * cm * cn * 4) + r16((size_t)B * cm * HW * 4);
+}
+
+int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV,
+                          const float* bV, const float* wP, const float* bP, float* y, int B, int C, int cm, int cn, int H, int W,
+                          int precision, void* ws, size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && wA && bA && wB && bB && wV && bV && wP && bP && y && ws);
+    MI355_CHECK_ARG(B > 0 && C > 0 && cm > 0 && cn > 0 && H > 0 && W > 0);
+    MI355_CHECK_ARG(ws_bytes >= mi355_double_attn_workspace_bytes(B, C, cm, cn, H, W));
+    const int HW = H * W, M3 = cm + 2 * cn;
+    if ((HW & 3) || (C & 3) || (cm & 3) || (cn & 3) || !aligned16(x) || !aligned16(y) || !aligned16(ws))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_double_attn_fwd: H*W, C, c_m, c_n must be multiples of 4 (HW=%d C=%d cm=%d cn=%d)",
+                           HW, C, cm, cn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* p = static_cast<char*>(ws);
+    float* Wcat = reinterpret_cast<float*>(p); p += r16((size_t)M3 * C * 4);
+    float* bcat = reinterpret_cast<float*>(p); p += r16((size_t)M3 * 4);
+    float* ABV = reinterpret_cast<float*>(p);  p += r16((size_t)B * M3 * HW * 4);
+    float* G = reinterpret_cast<float*>(p);    p += r16((size_t)B * cm * cn * 4);
+    float* Z = reinterpret_cast<float*>(p);
+    MI355_HIP(hipMemcpyAsync(Wcat, wA, (size_t)cm * C * 4, hipMemcpyDeviceToDevice, st));
+    MI355_HIP(hipMemcpyAsync(Wcat + (size_t)cm * C, wB, (size_t)cn * C * 4, hipMemcpyDeviceToDevice, st));
+    MI355_HIP(hipMemcpyAsync(Wcat + (size_t)(cm + cn) * C, wV, (size_t)cn * C * 4, hipMemcpyDeviceToDevice, st));
+    MI355_HIP(hipMemcpyAsync(bcat, bA, (size_t)cm * 4, hipMemcpyDeviceToDevice, st));
+    MI355_HIP(hipMemcpyAsync(bcat + cm, bB, (size_t)cn * 4, hipMemcpyDeviceToDevice, st));
+    MI355_HIP(hipMemcpyAsync(bcat + cm + cn, bV, (size_t)cn * 4, hipMemcpyDeviceToDevice, st));
+    const long sABV = (long)M3 * HW;
+    int rc = mi355::gemm_kn_batched(Wcat, x, bcat, nullptr, ABV, B, M3, HW, C, C, HW, HW, 0, (long)C * HW, sABV, MI355_ACT_NONE,
+                                    precision, st);
+    if (rc) return rc;
+    {
+        const long rows = (long)B * cn;
+        const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
+        softmax_rows_kernel<<<grid, 256, 0, st>>>(ABV + (long)cm * HW, cn, HW, sABV, rows);
+        const long total = (long)B * HW;
+        softmax_cols_kernel<<<cdiv(total, 256), 256, 0, st>>>(ABV + (long)(cm + cn) * HW, cn, HW, sABV, total);
+    }
+    rc = mi355::gemm_nt_batched(ABV, ABV + (long)cm * HW, G, B, cm, cn, HW, HW, HW, cn, sABV, sABV, (long)cm * cn, precision, st);
+    if (rc) return rc;
+    rc = mi355::gemm_kn_batched(G, ABV + (long)(cm + cn) * HW, nullptr, nullptr, Z, B, cm, HW, cn, cn, HW, HW, (long)cm * cn, sABV,
+                                (long)cm * HW, MI355_ACT_NONE, precision, st);
+    if (rc) return rc;
+    rc = mi355::gemm_kn_batched(wP, Z, bP, nullptr, y, B, C, HW, cm, cm, HW, HW, 0, (long)cm * HW, (long)C * HW, MI355_ACT_NONE,
+                                precision, st);
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// gemm.hip -- MFMA GEMM with fused epilogue for gfx950: nn.Linear, Mixer token mixing, ViT patch embedding.
+//
+//   C[b] (M x N) = epilogue( A[b] (M x K) . B[b] )       fp32 in HBM, 16-bit MFMA operands, fp32 accumulate
+//
+// Operand layouts (row-major, strides in elements):
+//   A      : (M, K), K contiguous                      AMODE 0 plain rows | AMODE 1 ViT patch gather (im2col in the load)
+//   B NT   : (N, K), K contiguous  (nn.Linear weight)  BMODE 0
+//   B KN   : (K, N), N contiguous  (activation as the K-major operand: Mixer token mix, 1x1 conv on NCHW)  BMODE 1
+// Tiling: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave = 4 x 4 MFMA 16x16x32 tiles).
+// Staging: global fp32 -> registers (float4, issued one K-step ahead) -> convert to the MFMA operand format (hi/lo
+// pair in strict mode) -> LDS rows of 32 k-elements (+8 pad), always K-contiguous; the KN operand is transposed in
+// registers (4 k-rows x 4 n-columns micro-tile per thread) on its way to LDS.  Two LDS buffers, one barrier per K-step.
+// Epilogue: accumulators -> per-wave LDS slab -> row-contiguous float4 stores with bias / GELU / LayerScale /
+// residual / position-embedding fused (the C/D fragment layout would otherwise write 64-byte pieces).
+// Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (n fastest): the A panel of a tile row
+// is fetched into one L2 instead of eight.
+#include "common.h"
+#include "mma.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PITCH = BK + 8;                 // LDS row pitch in 16-bit elements (80 B, keeps 16-B alignment)
+constexpr int EPITCH = 68;                    // epilogue slab pitch in floats
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* gamma; const float* resid; const float* pos;
+    int M, N, K;
+    int lda, ldb, ldc;
+    long sA, sB, sC;                          // batch strides (elements); 0 = shared operand
+    int act, bias_per_row;
+    // AMODE 1 (patch embedding): image geometry
+    int Cin, H, W, ps, gw, P;
+};
+
+__device__ __forceinline__ f4 ld4_guard(const float* p, bool ok) {
+    f4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? *reinterpret_cast<const f4*>(p) : z;
+}
+
+template <int PREC>
+__device__ __forceinline__ void st_lds4(unsigned short* hi, unsigned short* lo, int off, f4 v) {
+    using M_ = Mma<PREC>;
+    typename M_::v4 h = M_::cvt(v);
+    *reinterpret_cast<typename M_::v4*>(hi + off) = h;
+    if constexpr (M_::NSPLIT == 2) *reinterpret_cast<typename M_::v4*>(lo + off) = M_::cvt_lo(v, h);
+}
+
+template <int PREC, int BMODE, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    using M_ = Mma<PREC>;
+    using v8 = typename M_::v8;
+    constexpr int NS = M_::NSPLIT;
+    constexpr int TILE = (BM + BN) * PITCH;                  // 16-bit elements per (split, buffer)
+    constexpr int STAGE_BYTES = 2 * NS * TILE * 2;
+    constexpr int EPI_BYTES = 4 * 32 * EPITCH * 4;
+    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned short* lds = reinterpret_cast<unsigned short*>(lds_raw);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- tile id: XCD-contiguous remap (bijective for any grid size), n fastest -------------------------
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int bz = blockIdx.y;
+    const float* __restrict__ Ab = g.A + (long)bz * g.sA;
+    const float* __restrict__ Bb = g.B + (long)bz * g.sB;
+
+    // ---- per-thread staging coordinates --------------------------------------------------------------------
+    const int lr = t >> 3, lk = (t & 7) * 4;                 // row-within-32 and k offset for K-contiguous operands
+    const float* a_ptr[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lr + 32 * i;
+        a_ok[i] = m < g.M;
+        if constexpr (AMODE == 0) {
+            a_ptr[i] = Ab + (long)(a_ok[i] ? m : 0) * g.lda;
+        } else {                                             // row m = (image, patch); k = (c, ky, kx), kx contiguous
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / g.P, p = mm % g.P;
+            const int py = p / g.gw, px = p % g.gw;
+            a_ptr[i] = Ab + ((long)img * g.Cin * g.H + (long)py * g.ps) * g.W + (long)px * g.ps;
+        }
+    }
+    const float* b_ptr[4];
+    bool b_ok[4];
+    const int bk = (t & 7) * 4, bn4 = (t >> 3) * 4;          // BMODE 1: k-group and n-quad of this thread's 4x4 micro-tile
+    if constexpr (BMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + lr + 32 * i;
+            b_ok[i] = n < g.N;
+            b_ptr[i] = Bb + (long)(b_ok[i] ? n : 0) * g.ldb;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b_ok[i] = (n0 + bn4) < g.N;
+            b_ptr[i] = Bb + n0 + bn4;                        // + k * ldb added per step
+        }
+    }
+
+    f4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + lk;
+            if constexpr (AMODE == 0) {
+                ra[i] = ld4_guard(a_ptr[i] + k, a_ok[i] && k < g.K);
+            } else {
+                const int pp = g.ps * g.ps;
+                const int c = k / pp, rem = k % pp;
+                const int ky = rem / g.ps, kx = rem % g.ps;
+                ra[i] = ld4_guard(a_ptr[i] + ((long)c * g.H + ky) * g.W + kx, a_ok[i] && k < g.K);
+            }
+        }
+        if constexpr (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + lk;
+                rb[i] = ld4_guard(b_ptr[i] + k, b_ok[i] && k < g.K);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + bk + j;
+                rb[j] = ld4_guard(b_ptr[j] + (long)k * g.ldb, b_ok[j] && k < g.K);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned short* hiA = lds + (buf * NS + 0) * TILE;
+        unsigned short* loA = lds + (buf * NS + (NS - 1)) * TILE;
+        unsigned short* hiB = hiA + BM * PITCH;
+        unsigned short* loB = loA + BM * PITCH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st_lds4<PREC>(hiA, loA, (lr + 32 * i) * PITCH + lk, ra[i]);
+        if constexpr (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_lds4<PREC>(hiB, loB, (lr + 32 * i) * PITCH + lk, rb[i]);
+        } else {                                             // transpose the 4(k) x 4(n) micro-tile: rows n, 4 consecutive k
+            const f4 c0 = {rb[0].x, rb[1].x, rb[2].x, rb[3].x};
+            const f4 c1 = {rb[0].y, rb[1].y, rb[2].y, rb[3].y};
+            const f4 c2 = {rb[0].z, rb[1].z, rb[2].z, rb[3].z};
+            const f4 c3 = {rb[0].w, rb[1].w, rb[2].w, rb[3].w};
+            st_lds4<PREC>(hiB, loB, (bn4 + 0) * PITCH + bk, c0);
+            st_lds4<PREC>(hiB, loB, (bn4 + 1) * PITCH + bk, c1);
+            st_lds4<PREC>(hiB, loB, (bn4 + 2) * PITCH + bk, c2);
+            st_lds4<PREC>(hiB, loB, (bn4 + 3) * PITCH + bk, c3);
+        }
+    };
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);           // next tile in flight under the MFMAs
+        const unsigned short* sA = lds + (buf * NS) * TILE + (wr * 64 + frow) * PITCH + fk;
+        const unsigned short* sB = lds + (buf * NS) * TILE + BM * PITCH + (wc * 64 + frow) * PITCH + fk;
+        v8 fa[4][NS], fb[4][NS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                fa[i][s] = *reinterpret_cast<const v8*>(sA + s * TILE + i * 16 * PITCH);
+                fb[i][s] = *reinterpret_cast<const v8*>(sB + s * TILE + i * 16 * PITCH);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma_step<PREC>(fa[i], fb[j], acc[i][j]);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: 2 passes of 32 rows per wave through a private LDS slab ---------------------------------
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EPITCH;
+    float* Cb = g.C + (long)bz * g.sC;
+    const float* Rb = g.resid ? g.resid + (long)bz * g.sC : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) &&
+                        (!Rb || (reinterpret_cast<uintptr_t>(Rb) & 15) == 0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[(ii * 16 + (lane >> 4) * 4 + r) * EPITCH + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
+            const int m = m0 + wr * 64 + p * 32 + rl, n = n0 + wc * 64 + cl;
+            if (m >= g.M || n >= g.N) continue;
+            f4 v = *reinterpret_cast<const f4*>(slab + rl * EPITCH + cl);
+            long orow = m;
+            if constexpr (AMODE == 1) orow = (long)(m / g.P) * (g.P + 1) + (m % g.P);
+            const bool full = vec_ok && (n + 3 < g.N);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (n + c >= g.N) break;
+                float z = vv[c];
+                if (g.bias) z += g.bias_per_row ? g.bias[m] : g.bias[n + c];
+                if constexpr (AMODE == 1) z += g.pos[(long)(m % g.P) * g.N + n + c];
+                if (g.act == MI355_ACT_GELU) z = gelu_erf(z);
+                if (g.gamma) z *= g.gamma[n + c];
+                if (Rb) z += Rb[orow * g.ldc + n + c];
+                vv[c] = z;
+            }
+            if (full) {
+                *reinterpret_cast<f4*>(Cb + orow * g.ldc + n) = f4{vv[0], vv[1], vv[2], vv[3]};
+            } else {
+                for (int c = 0; c < 4 && n + c < g.N; ++c) Cb[orow * g.ldc + n + c] = vv[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// cls row of the ViT token matrix: tokens[b, P, :] = cls + pos[P]   (ViT.py:183-185, cls appended LAST)
+__global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tokens,
+                               int B, int P, int E) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * E) return;
+    const int b = (int)(i / E), e = (int)(i % E);
+    tokens[((long)b * (P + 1) + P) * E + e] = cls[e] + pos[(long)P * E + e];
+}
+
+template <int BMODE, int AMODE>
+int launch(const GemmArgs& g, int batch, int precision, hipStream_t st) {
+    const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+    dim3 grid(tiles, batch);
+    switch (precision) {
+        case MI355_PREC_STRICT: gemm_kernel<0, BMODE, AMODE><<<grid, 256, 0, st>>>(g); break;
+        case MI355_PREC_FP16:   gemm_kernel<1, BMODE, AMODE><<<grid, 256, 0, st>>>(g); break;
+        case MI355_PREC_BF16:   gemm_kernel<2, BMODE, AMODE><<<grid, 256, 0, st>>>(g); break;
+        default: return mi355::fail(MI355_EINVAL, "precision must be 0, 1 or 2 (got %d)", precision);
+    }
+    return MI355_OK;
+}
+
+}  // namespace
+
+namespace mi355 {
+// Shared with the other translation units (double attention, attention blocks): plain / batched GEMM launches.
+int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
+            int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.gamma = gamma; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.act = act;
+    return launch<0, 0>(g, 1, precision, st);
+}
+int gemm_nt_batched(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc, long sA,
+                    long sB, long sC, int precision, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+    return launch<0, 0>(g, batch, precision, st);
+}
+int gemm_kn_batched(const float* A, const float* B, const float* bias_row, const float* resid, float* C, int batch, int M,
+                    int N, int K, int lda, int ldb, int ldc, long sA, long sB, long sC, int act, int precision,
+                    hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias_row; g.resid = resid; g.bias_per_row = 1;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC; g.act = act;
+    return launch<1, 0>(g, batch, precision, st);
+}
+}  // namespace mi355
+
+extern "C" {
+
+int mi355_linear_fwd(const float* X, const float* W, const float* bias, const float* gamma, const float* resid, float* Y,
+                     int M, int N, int K, int ldx, int ldy, int act, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X && W && Y);
+    MI355_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    if ((K & 3) || (ldx & 3) || !aligned16(X) || !aligned16(W))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear_fwd: K and ldx must be multiples of 4 and X, W 16-byte aligned "
+                                               "(K=%d ldx=%d)", K, ldx);
+    int rc = mi355::gemm_nt(X, W, bias, gamma, resid, Y, M, N, K, ldx, K, ldy, act, precision, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_token_mix_fwd(const float* W, const float* X, const float* bias, const float* resid, float* Y, int B, int T, int N,
+                        int C, int act, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(W && X && Y);
+    MI355_CHECK_ARG(B > 0 && T > 0 && N > 0 && C > 0);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    if ((N & 3) || (C & 3) || !aligned16(X) || !aligned16(W))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_token_mix_fwd: N and C must be multiples of 4 (N=%d C=%d)", N, C);
+    int rc = mi355::gemm_kn_batched(W, X, bias, resid, Y, B, T, C, N, N, C, C, 0, (long)N * C, (long)T * C, act, precision,
+                                    static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos, float* tokens,
+                          int B, int Cin, int H, int W, int ps, int E, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(img && Wp && bp && cls && pos && tokens);
+    MI355_CHECK_ARG(B > 0 && Cin > 0 && ps > 0 && E > 0 && H >= ps && W >= ps && H % ps == 0 && W % ps == 0);
+    if ((ps & 3) || (W & 3) || !aligned16(img) || !aligned16(Wp))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_patch_embed_fwd: patch size and image width must be multiples of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GemmArgs g{};
+    g.gw = W / ps;
+    g.P = (H / ps) * g.gw;
+    g.A = img; g.B = Wp; g.C = tokens; g.bias = bp; g.pos = pos;
+    g.M = B * g.P; g.N = E; g.K = Cin * ps * ps; g.lda = 0; g.ldb = g.K; g.ldc = E;
+    g.Cin = Cin; g.H = H; g.W = W; g.ps = ps;
+    int rc = launch<0, 1>(g, 1, precision, st);
+    if (rc) return rc;
+    const long n = (long)B * E;
+    cls_row_kernel<<<cdiv(n, 256), 256, 0, st>>>(cls, pos, tokens, B, g.P, E);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mi355_lpi_fwd": (c_int, [c_vp] * 7 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp, c_size, c_vp]),
     "mi355_patch_embed_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
     "mi355_stream_copy": (c_int, [c_vp, c_vp, c_size, c_vp]),
+    "mi355_stream_read": (c_int, [c_vp, c_size, c_vp, c_vp]),
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
 }

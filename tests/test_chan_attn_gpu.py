@@ -1,0 +1,117 @@
+"""GPU tests (-m gpu): edge cases and full-size properties of the SE / ECA / CBAM kernels."""
+import pytest
+import torch
+
+import oracle as O
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods(C, red=16, ks=7):
+    from mi355attn.modules import CBAM, ECALayer, SELayer
+    torch.manual_seed(11)
+    return SELayer(C, red).eval(), ECALayer(C).eval(), CBAM(C, red, ks).eval()
+
+
+# ragged spatial sizes (HW % 4 != 0 -> scalar lanes), channel counts that are not multiples of the
+# 16-row workgroup slab, single image, 1x1 maps, wide maps that need several spatial-gate bands
+SHAPES = [(1, 16, 1, 1), (2, 48, 7, 9), (3, 32, 5, 5), (2, 80, 13, 1), (1, 64, 3, 3), (2, 100, 10, 10),
+          (1, 32, 64, 200), (5, 256, 14, 14), (2, 64, 32, 32), (2, 24, 112, 112)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_edge_shapes(shape):
+    B, C, H, W = shape
+    red = 16 if C >= 32 else 4
+    se, eca, cbam = _mods(C, red, 7 if min(H, W) >= 3 else 3)
+    torch.manual_seed(5)
+    x = torch.randn(*shape)
+    xd = x.cuda()
+    with torch.no_grad():
+        y_se = se.cuda()(xd).cpu()
+        y_eca = eca.cuda()(xd).cpu()
+        y_cbam = cbam.cuda()(xd).cpu()
+        y_ca = cbam.ca(xd).cpu()
+        y_sa = cbam.sa(xd).cpu()
+    sd = {k: v.cpu() for k, v in cbam.state_dict().items()}
+    assert_parity(y_se, O.se_forward(x, se.fc[0].weight, se.fc[2].weight), 1e-5, f"se{shape}")
+    assert_parity(y_eca, O.eca_forward(x, eca.conv.weight), 1e-5, f"eca{shape}")
+    assert_parity(y_cbam, O.cbam_forward(x, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"], sd["sa.conv.weight"]), 1e-5,
+                  f"cbam{shape}")
+    assert_parity(y_ca, O.cbam_channel_forward(x, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"]), 1e-5, f"ca{shape}")
+    assert_parity(y_sa, O.cbam_spatial_forward(x, sd["sa.conv.weight"]), 1e-5, f"sa{shape}")
+
+
+def test_non_contiguous_and_offset_inputs():
+    se, _, _ = _mods(64)
+    torch.manual_seed(2)
+    big = torch.randn(2, 64, 20, 24)
+    view = big[:, :, 2:18, 4:20]                      # non-contiguous view -> wrapper makes it dense
+    with torch.no_grad():
+        y = se.cuda()(view.cuda()).cpu()
+    assert_parity(y, O.se_forward(view.contiguous(), se.fc[0].weight, se.fc[2].weight), 1e-5, "se[view]")
+
+
+def test_chunk_option_does_not_change_results():
+    """The Infinity-Cache chunking knob reorders launches only: outputs must be bit-identical."""
+    import mi355attn
+    se, eca, cbam = _mods(64)
+    torch.manual_seed(9)
+    x = torch.randn(13, 64, 28, 28).cuda()
+    outs = []
+    for chunk in (0, 1, 5, 13):
+        mi355attn.set_option("chunk_images", chunk)
+        with torch.no_grad():
+            outs.append((se.cuda()(x).clone(), eca.cuda()(x).clone(), cbam.cuda()(x).clone()))
+    mi355attn.set_option("chunk_images", 0)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["se", "eca", "cbam"])
+def test_full_size_properties(which):
+    """BASELINE config C2, x = (256,256,56,56): size-independent properties + sampled-image oracle checks.
+
+    * per-row gate constancy (SE/ECA): y[b,c,:] / x[b,c,:] is one scalar in (0,1);
+    * batch independence: the output of image b does not depend on the other images (run a 3-image
+      sub-batch of images 0,127,255 and compare bit-for-bit with the same rows of the full run);
+    * images 0, 127, 255 against the oracle;
+    * run-to-run bit identity.
+    """
+    se, eca, cbam = _mods(256)
+    m = {"se": se, "eca": eca, "cbam": cbam}[which].cuda()
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    pick = [0, 127, 255]
+    x = torch.empty(256, 256, 56, 56, device="cuda")
+    host = {}
+    for b0 in range(0, 256, 32):                       # fill in slabs to bound host memory
+        blk = torch.randn(32, 256, 56, 56, generator=g)
+        x[b0:b0 + 32] = blk.cuda()
+        for b in pick:
+            if b0 <= b < b0 + 32:
+                host[b] = blk[b - b0].clone()
+    with torch.no_grad():
+        y = m(x)
+        y2 = m(x)
+        sub = m(x[pick].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), "run-to-run results differ"
+    assert torch.equal(y[pick], sub), "output of an image depends on its batch neighbours"
+    assert torch.isfinite(y).all()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    xs = torch.stack([host[b] for b in pick])
+    if which == "se":
+        ref = O.se_forward(xs, sd["fc.0.weight"], sd["fc.2.weight"])
+    elif which == "eca":
+        ref = O.eca_forward(xs, sd["conv.weight"])
+    else:
+        ref = O.cbam_forward(xs, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"], sd["sa.conv.weight"])
+    assert_parity(y[pick].cpu(), ref, 1e-5, which + "[full-size sample]")
+    if which in ("se", "eca"):
+        ratio = (y[pick] / x[pick]).reshape(3 * 256, -1)
+        ok = x[pick].reshape(3 * 256, -1).abs() > 1e-3
+        lo = torch.where(ok, ratio, torch.full_like(ratio, 2.0)).amin(dim=1)
+        hi = torch.where(ok, ratio, torch.full_like(ratio, -1.0)).amax(dim=1)
+        assert float((hi - lo).max()) < 1e-4 and float(lo.min()) > 0.0 and float(hi.max()) < 1.0

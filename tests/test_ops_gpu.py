@@ -1,0 +1,286 @@
+"""GPU tests (-m gpu): every C-ABI op against an fp64 torch-CPU restatement, across shapes and the three precisions.
+
+Tolerances are relative Frobenius + max-abs (conftest.assert_parity):
+    strict (bf16x3 split)  5e-5      fp16 operands  1e-3      bf16 operands  1.2e-2 (reported, out of the parity tolerance)
+Shape/index paths are checked BIT-EXACTLY with a one-hot attention construction (see test_window_index_bit_exact).
+"""
+import math
+
+import pytest
+import torch
+
+import oracle as O
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 5e-5, 1: 1e-3, 2: 1.2e-2}
+
+
+def F():
+    from mi355attn import functional
+    return functional
+
+
+def gelu64(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+# ---------------------------------------------------------------------------------------------- linear / GEMM engine
+LINEAR_SHAPES = [(1, 1, 4), (5, 7, 12), (130, 70, 36), (257, 129, 100), (64, 1000, 768), (1000, 768, 768), (300, 2304, 768),
+                 (50, 196, 256), (129, 130, 4)]
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", LINEAR_SHAPES)
+def test_linear_plain(M, N, K, prec):
+    torch.manual_seed(M * 31 + N * 7 + K)
+    x, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    y = F().linear(x.cuda(), w.cuda(), b.cuda(), precision=prec).cpu()
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    assert_parity(y, ref, TOL[prec], f"linear{(M, N, K)} p{prec}")
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_linear_epilogues(prec):
+    torch.manual_seed(3)
+    M, N, K = 200, 136, 72
+    x, w, b = torch.randn(2, 100, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    gamma, resid = torch.rand(N) + 0.5, torch.randn(2, 100, N)
+    f = F()
+    z = x.double() @ w.double().t() + b.double()
+    got = f.linear(x.cuda(), w.cuda(), b.cuda(), act=f.ACT_GELU, precision=prec).cpu()
+    assert_parity(got, gelu64(z).float(), TOL[prec], "gelu")
+    got = f.linear(x.cuda(), w.cuda(), None, resid=resid.cuda(), precision=prec).cpu()
+    assert_parity(got, (x.double() @ w.double().t() + resid.double()).float(), TOL[prec], "resid, no bias")
+    got = f.linear(x.cuda(), w.cuda(), b.cuda(), act=f.ACT_GELU, gamma=gamma.cuda(), resid=resid.cuda(), precision=prec).cpu()
+    assert_parity(got, (resid.double() + gamma.double() * gelu64(z)).float(), TOL[prec], "gelu+gamma+resid")
+
+
+def test_linear_row_strided_input():
+    torch.manual_seed(4)
+    tok = torch.randn(6, 5, 64).cuda()
+    w, b = torch.randn(10, 64).cuda() / 8, torch.randn(10).cuda()
+    view = tok[:, 0]                                   # stride (320, 1): consumed in place
+    assert not view.is_contiguous()
+    y = F().linear(view, w, b, precision=0).cpu()
+    ref = (tok[:, 0].double().cpu() @ w.double().cpu().t() + b.double().cpu()).float()
+    assert_parity(y, ref, TOL[0], "strided rows")
+
+
+def test_linear_rejects_bad_shapes():
+    from mi355attn import Mi355Error
+    x, w = torch.randn(4, 6).cuda(), torch.randn(3, 6).cuda()          # K = 6 is not a multiple of 4
+    with pytest.raises(Mi355Error):
+        F().linear(x, w)
+    with pytest.raises(ValueError):
+        F().linear(torch.randn(4, 8).cuda(), w)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,T,N,C", [(2, 8, 12, 16), (3, 256, 196, 512), (2, 196, 256, 512), (1, 130, 36, 132)])
+def test_token_mix(B, T, N, C, prec):
+    torch.manual_seed(B + T + N)
+    w, x, b, r = torch.randn(T, N) / math.sqrt(N), torch.randn(B, N, C), torch.randn(T), torch.randn(B, T, C)
+    f = F()
+    got = f.token_mix(w.cuda(), x.cuda(), b.cuda(), act=f.ACT_GELU, precision=prec).cpu()
+    z = torch.einsum("tn,bnc->btc", w.double(), x.double()) + b.double()[None, :, None]
+    assert_parity(got, gelu64(z).float(), TOL[prec], "token_mix gelu")
+    got = f.token_mix(w.cuda(), x.cuda(), b.cuda(), resid=r.cuda(), precision=prec).cpu()
+    assert_parity(got, (z + r.double()).float(), TOL[prec], "token_mix resid")
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 4), (7, 64), (300, 384), (1000, 768), (33, 1000), (17, 1536), (5, 2052), (9, 50)])
+def test_layernorm(rows, cols):
+    torch.manual_seed(rows + cols)
+    x, w, b = torch.randn(rows, cols) * 3 + 1, torch.randn(cols), torch.randn(cols)
+    y = F().layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5).cpu()
+    ref = torch.nn.functional.layer_norm(x.double(), (cols,), w.double(), b.double(), 1e-5).float()
+    assert_parity(y, ref, 2e-6, f"layernorm{(rows, cols)}")
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,Cin,HW,ps,E", [(2, 3, 32, 16, 64), (1, 3, 224, 16, 768), (3, 4, 24, 8, 132)])
+def test_patch_embed(B, Cin, HW, ps, E, prec):
+    torch.manual_seed(E)
+    img = torch.randn(B, Cin, HW, HW)
+    w, b = torch.randn(E, Cin, ps, ps) / math.sqrt(Cin * ps * ps), torch.randn(E)
+    P = (HW // ps) ** 2
+    cls, pos = torch.randn(E), torch.randn(P + 1, E)
+    tok = F().patch_embed(img.cuda(), w.cuda(), b.cuda(), cls.cuda(), pos.cuda(), ps, precision=prec).cpu()
+    ref = O.vit_patch_embed_forward(img, w, b, torch.float64)
+    ref = torch.cat([ref, cls.double().expand(B, 1, E)], dim=1) + pos.double()
+    assert_parity(tok, ref.float(), TOL[prec], "patch_embed")
+
+
+# ---------------------------------------------------------------------------------------------- attention cores
+def _sdpa_ref(qkv, h, scale):
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    d = C // h
+    q, k, v = (qkv.double().reshape(B, N, 3, h, d).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    return O.sdpa_core(q, k, v, scale).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("B,N,h,d", [(2, 197, 12, 64), (1, 5, 2, 32), (3, 64, 4, 32), (2, 100, 3, 64), (1, 224, 2, 64),
+                                    (2, 17, 1, 64), (2, 1, 2, 32), (1, 129, 2, 32)])
+def test_sdpa(B, N, h, d, prec):
+    torch.manual_seed(N * 3 + h)
+    qkv = torch.randn(B, N, 3 * h * d)
+    out = F().sdpa(qkv.cuda(), h, d ** -0.5, precision=prec).cpu()
+    assert_parity(out, _sdpa_ref(qkv, h, d ** -0.5).float(), TOL[prec], f"sdpa{(B, N, h, d)} p{prec}")
+
+
+def test_sdpa_sharp_softmax_and_large_logits():
+    """Rows whose max dwarfs the rest (one spiked key) and logits ~ +-60: the masked/shifted softmax must stay finite."""
+    torch.manual_seed(1)
+    B, N, h, d = 1, 197, 2, 64
+    qkv = torch.randn(B, N, 3 * h * d)
+    qkv[0, 7, 0:d] *= 25.0
+    qkv[0, 100, h * d:h * d + d] *= 25.0
+    out = F().sdpa(qkv.cuda(), h, d ** -0.5, precision=0).cpu()
+    assert_parity(out, _sdpa_ref(qkv, h, d ** -0.5).float(), 2e-4, "sdpa spiked")
+
+
+def _onehot_codes(T, d, scale=48.0):
+    """q_t = scale * code(t), k_s = code(s) with +-1 bit codes: q_t.k_s is maximal only at s == t, by >= 2*scale."""
+    bits = max(1, (T - 1).bit_length())
+    assert bits <= d
+    idx = torch.arange(T)
+    code = torch.zeros(T, d)
+    for b in range(bits):
+        code[:, b] = ((idx >> b) & 1).float() * 2 - 1
+    return code * scale, code
+
+
+WINDOWS = [(56, 0, 1, 32, 1), (56, 1, 1, 32, 1), (28, 0, 2, 64, 2), (28, 1, 2, 64, 2), (14, 0, 7, 128, 4), (14, 1, 7, 128, 4),
+           (7, -1, 7, 512, 16), (8, 0, 2, 64, 2), (8, 1, 4, 32, 1), (6, -1, 6, 64, 2)]
+
+
+@pytest.mark.parametrize("reso,idx,split,dim,heads", WINDOWS)
+def test_window_index_bit_exact(reso, idx, split, dim, heads):
+    """Stripe-window gather / head split / scatter are pure index math: with a one-hot attention (q_t.k_s peaks only at
+    s == t inside every window) and LePE switched off, out must equal v BIT FOR BIT (values are integers < 2^16, exact
+    in the strict operand format)."""
+    from mi355attn.modules import LePEAttention
+    torch.manual_seed(0)
+    m = LePEAttention(dim, reso, idx, split_size=split, num_heads=heads, precision=0).eval()
+    torch.nn.init.zeros_(m.get_v.weight)
+    torch.nn.init.zeros_(m.get_v.bias)
+    B, L, d = 2, reso * reso, dim // heads
+    T = m.H_sp * m.W_sp
+    tab = O.window_token_index(reso, m.H_sp, m.W_sp)                      # (nWin, T) token ids
+    qc, kc = _onehot_codes(T, d)
+    q = torch.zeros(B, L, dim)
+    k = torch.zeros(B, L, dim)
+    for w in range(tab.shape[0]):
+        for hh in range(heads):
+            q[:, tab[w], hh * d:(hh + 1) * d] = qc / m.scale               # kernel pre-scales q by m.scale
+            k[:, tab[w], hh * d:(hh + 1) * d] = kc
+    lidx, cidx, bidx = torch.arange(L).float()[None, :, None], torch.arange(dim).float()[None, None, :], \
+        torch.arange(B).float()[:, None, None]
+    patterns = [lidx * 16 + cidx % 16 + bidx * 7,                 # distinguishes every token
+                cidx + (lidx % 64) * 512 + bidx * 0]              # distinguishes every channel (head split / merge)
+    m = m.cuda()
+    for v in patterns:
+        v = v.expand(B, L, dim).contiguous()
+        assert float(v.max()) < 65536
+        qkv = torch.stack([q, k, v], dim=0)
+        with torch.no_grad():
+            out = m(qkv.cuda()).cpu()
+        assert torch.equal(out, v), "window / head index math is not bit-exact"
+
+
+def test_vit_head_index_bit_exact():
+    B, N, h, d = 2, 197, 12, 64
+    qc, kc = _onehot_codes(N, d)
+    scale = d ** -0.5
+    q = (qc / scale).repeat(1, h)
+    k = kc.repeat(1, h)
+    v = torch.arange(N).float()[:, None] * 64 + (torch.arange(h * d).float()[None, :] % 64)
+    qkv = torch.cat([q, k, v], dim=1)[None].repeat(B, 1, 1).contiguous()
+    qkv[1, :, 2 * h * d:] += 3
+    out = F().sdpa(qkv.cuda(), h, scale, precision=0).cpu()
+    assert torch.equal(out, qkv[:, :, 2 * h * d:]), "ViT head split / merge is not bit-exact"
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("reso,idx,split,dim,heads", WINDOWS)
+def test_lepe_attention_vs_oracle(reso, idx, split, dim, heads, prec):
+    from mi355attn.modules import LePEAttention
+    torch.manual_seed(reso + dim)
+    m = LePEAttention(dim, reso, idx, split_size=split, num_heads=heads, precision=prec).eval()
+    qkv = torch.randn(3, 2, reso * reso, dim)
+    ref = O.lepe_attention_forward(qkv, m.get_v.weight, m.get_v.bias, reso, idx, split, heads, torch.float64)
+    with torch.no_grad():
+        out = m.cuda()(qkv.cuda()).cpu()
+    assert_parity(out, ref.float(), TOL[prec], f"lepe{(reso, idx, split, dim, heads)} p{prec}")
+
+
+def test_lepe_accepts_permuted_view_without_copy():
+    from mi355attn.modules import LePEAttention
+    torch.manual_seed(5)
+    m = LePEAttention(32, 8, 0, split_size=2, num_heads=1, precision=0).eval().cuda()
+    buf = torch.randn(2, 64, 3, 32).cuda()
+    view = buf.permute(2, 0, 1, 3)                                        # the reference's (3,B,L,C) view of (B,L,3,C)
+    with torch.no_grad():
+        a = m(view)
+        b = m(view.contiguous())
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,h,d", [(2, 196, 8, 48), (1, 49, 4, 32), (2, 10, 2, 64), (1, 224, 2, 48), (3, 196, 4, 32)])
+def test_xca_core(B, N, h, d):
+    torch.manual_seed(N + d)
+    C = h * d
+    qkv = torch.randn(B, N, 3 * C)
+    temp = torch.rand(h) + 0.5
+    out = F().xca_core(qkv.cuda(), temp.cuda(), h).cpu()
+    ref = _xca_core_ref(qkv.double(), temp.double(), h)
+    assert_parity(out, ref.float(), 2e-5, f"xca{(B, N, h, d)}")
+
+
+def _xca_core_ref(qkv, temp, h):
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    d = C // h
+    q, k, v = (qkv.reshape(B, N, 3, h, d).permute(2, 0, 3, 4, 1)[i] for i in range(3))    # (B,h,d,N)
+    qn = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    kn = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    a = torch.softmax((qn @ kn.transpose(-1, -2)) * temp.reshape(1, h, 1, 1), dim=-1)
+    return (a @ v).permute(0, 3, 1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 14, 14, 384), (1, 7, 7, 40), (3, 4, 9, 100), (1, 1, 1, 32)])
+def test_lpi(B, H, W, C):
+    torch.manual_seed(H * W + C)
+    x = torch.randn(B, H * W, C)
+    p = {"conv1.weight": torch.randn(C, 1, 3, 3) / 3, "conv1.bias": torch.randn(C), "bn.weight": torch.rand(C) + 0.5,
+         "bn.bias": torch.randn(C), "bn.running_mean": torch.randn(C) * 0.1, "bn.running_var": torch.rand(C) + 0.5,
+         "conv2.weight": torch.randn(C, 1, 3, 3) / 3, "conv2.bias": torch.randn(C)}
+    gamma, resid = torch.rand(C), torch.randn(B, H * W, C)
+    ref = O.lpi_forward(x, p, H, W, torch.float64)
+    d = {k: v.cuda() for k, v in p.items()}
+    got = F().lpi(x.cuda(), d["conv1.weight"], d["conv1.bias"], d["bn.weight"], d["bn.bias"], d["bn.running_mean"],
+                  d["bn.running_var"], 1e-5, d["conv2.weight"], d["conv2.bias"], H, W).cpu()
+    assert_parity(got, ref.float(), 5e-6, "lpi")
+    got = F().lpi(x.cuda(), d["conv1.weight"], d["conv1.bias"], d["bn.weight"], d["bn.bias"], d["bn.running_mean"],
+                  d["bn.running_var"], 1e-5, d["conv2.weight"], d["conv2.bias"], H, W, gamma=gamma.cuda(),
+                  resid=resid.cuda()).cpu()
+    assert_parity(got, (resid.double() + gamma.double() * ref).float(), 5e-6, "lpi gamma+resid")
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,C,cm,cn,H,W", [(2, 64, 32, 32, 32, 32), (2, 32, 16, 8, 8, 8), (1, 256, 128, 128, 14, 14), (3, 16, 4, 12, 6, 6)])
+def test_double_attention(B, C, cm, cn, H, W, prec):
+    from mi355attn.modules import DoubleAttention
+    torch.manual_seed(C + cm)
+    m = DoubleAttention(C, cm, cn, precision=prec).eval()
+    x = torch.randn(B, C, H, W)
+    sd = m.state_dict()
+    ref = O.double_attention_forward(x, sd["convA.weight"], sd["convA.bias"], sd["convB.weight"], sd["convB.bias"],
+                                     sd["convV.weight"], sd["convV.bias"], sd["proj.weight"], sd["proj.bias"], torch.float64)
+    with torch.no_grad():
+        y = m.cuda()(x.cuda()).cpu()
+    assert_parity(y, ref.float(), TOL[prec], f"double_attention p{prec}")

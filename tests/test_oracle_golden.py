@@ -83,6 +83,18 @@ def test_eca_kernel_size_rule():
         assert ECALayer(c).conv.weight.shape[-1] == O.eca_kernel_size(c)
 
 
+def test_explicit_stencils_match_aten_convs():
+    """The oracle calls ATen conv1d/conv2d (what the reference's modules run); tap-by-tap loops agree with them."""
+    import oracle as O
+    import torch.nn.functional as TF
+    torch.manual_seed(0)
+    pooled, wk = torch.randn(3, 37, dtype=torch.float64), torch.randn(5, dtype=torch.float64)
+    assert torch.allclose(O.eca_gate_explicit(pooled, wk), TF.conv1d(pooled[:, None], wk.reshape(1, 1, 5), padding=2)[:, 0],
+                          atol=1e-12)
+    smap, w7 = torch.randn(2, 2, 9, 11, dtype=torch.float64), torch.randn(1, 2, 7, 7, dtype=torch.float64)
+    assert torch.allclose(O.spatial_conv_explicit(smap, w7), TF.conv2d(smap, w7, padding=3)[:, 0], atol=1e-12)
+
+
 def test_window_index_is_a_permutation_and_bit_exact():
     import oracle as O
     for reso, hs, ws in ((56, 56, 1), (56, 1, 56), (28, 28, 2), (28, 2, 28), (14, 14, 7), (14, 7, 14), (7, 7, 7)):
