@@ -218,8 +218,20 @@ def main():
 
     if world == 1 and not args.no_cpu:
         ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         ns = min(args.cpu_sample, args.batch)
+        # pick the torch thread count that is fastest on this host (all SMT threads is often NOT it on big dual-socket boxes)
+        probe = blocks[0]
+        xs0 = probe["x"][:ns].cpu()
+        best_t, best_n = None, None
+        for nthr in sorted({min(ncores, n) for n in (8, 16, 32, 64, 128, ncores)}):
+            torch.set_num_threads(nthr)
+            probe["cpu"](xs0)
+            t1 = time.perf_counter()
+            probe["cpu"](xs0)
+            dt = time.perf_counter() - t1
+            if best_t is None or dt < best_t:
+                best_t, best_n = dt, nthr
+        torch.set_num_threads(best_n)
         t_cpu = 0.0
         reps = 3
         for b in blocks:

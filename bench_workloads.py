@@ -66,9 +66,8 @@ def workload_c5(B, dev):
     sd = _sd(m)
 
     def gather(logits, dist):
-        out = torch.empty(dist.get_world_size() * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
-        dist.all_gather_into_tensor(out, logits.contiguous())          # RCCL all-gather over xGMI, 1 MB per rank
-        return out
+        from mi355attn.dist import gather_batch
+        return gather_batch(logits)                                    # one RCCL all-gather over xGMI, 1 MB per rank
 
     blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
                    cpu=lambda xs: O.vit_forward(xs, sd, 12, 12))]

@@ -51,8 +51,9 @@ typedef void* mi355_stream_t; /* hipStream_t */
 int         mi355_version(void);            /* ABI version, bumped on any signature change */
 const char* mi355_last_error(void);         /* thread-local message of the last failing call */
 /* Tuning knobs of the channel-attention family (process-global, read at launch; results never depend on them):
- *   "chunk_images"  images per pool->scale chunk (0 = whole batch, default);
- *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 2);
+ *   "chunk_images"  images per pool->scale chunk (0 = auto: ~200 MB of x per chunk so that a chunk's re-read is served
+ *                   by the 256 MiB Infinity Cache -- default; a value >= B disables chunking);
+ *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 3);
  *   "reverse"       1 = the final pass walks the batch backwards (most recently touched rows first), default 0.
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
@@ -106,6 +107,25 @@ int mi355_token_mix_fwd(const float* W, const float* X, const float* bias, const
 /* nn.LayerNorm over the last axis, eps inside the sqrt (ViT.py:111-114, cswin.py:139, xcit.py:271). */
 int mi355_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
                         int rows, int cols, float eps, mi355_stream_t stream);
+
+/* ---- 16-bit activation dataflow (precision 1 = IEEE half, 2 = bfloat16) ----------------------------------------
+ * The composite blocks keep activations that only ever feed an MFMA in the MFMA operand format IN HBM: the rounding
+ * point is the same as in the fp32-in entry points (operands are rounded to 16 bit exactly once, accumulation and
+ * epilogues stay fp32), so results are bit-identical, but GEMM operand traffic halves and tiles go HBM -> LDS by DMA.
+ * `void*` 16-bit buffers hold _Float16 (precision 1) or bfloat16 (precision 2) elements. */
+int mi355_cast16_fwd(const float* src, void* dst16, size_t n, int precision, mi355_stream_t stream);
+int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias, void* y16, int rows, int cols, float eps,
+                          int precision, mi355_stream_t stream);
+/* Y = resid + gamma * act(X16 W16^T + bias); Y is fp32 (out16 = 0) or 16-bit (out16 = 1); bias/gamma/resid fp32 or NULL.
+ * Needs K % 64 == 0, N % 4 == 0, ldx % 8 == 0 (other shapes: cast back and use mi355_linear_fwd). */
+int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
+                       int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, mi355_stream_t stream);
+/* mi355_sdpa_fwd / mi355_cswin_lepe_attn_fwd with 16-bit qkv and out buffers (same layouts). */
+int mi355_sdpa16_fwd(const void* qkv16, void* out16, int B, int N, int heads, int d, float scale, int precision,
+                     mi355_stream_t stream);
+int mi355_cswin_lepe_attn16_fwd(const void* qkv16, const float* getv_w, const float* getv_b, void* out16,
+                                int B, int reso, int Ctot, int c0, int Cb, int heads, int Hsp, int Wsp,
+                                float scale, int precision, mi355_stream_t stream);
 
 /* ---- attention cores ------------------------------------------------------------------------------ */
 

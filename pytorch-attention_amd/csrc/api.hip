@@ -5,8 +5,8 @@
 
 namespace mi355 {
 static thread_local char g_err[512] = "";
-static std::atomic<long> g_chunk_images{0};
-static std::atomic<long> g_nt{2};        // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
+static std::atomic<long> g_chunk_images{0};   // 0 = auto (about 200 MB of x per chunk)
+static std::atomic<long> g_nt{3};        // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
 static std::atomic<long> g_reverse{0};
 
 char* err_buf() { return g_err; }

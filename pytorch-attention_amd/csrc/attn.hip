@@ -18,12 +18,13 @@
 // HBM traffic per call = read qkv once + write out once (the isolated core is HBM-bound: SURVEY.md 8d).
 #include "common.h"
 #include "mma.h"
+#include <type_traits>
 
 namespace {
 
 struct AttnArgs {
-    const float* qkv;      // (B, L, 3, Ctot)
-    float* out;            // (B, L, Ctot)
+    const void* qkv;       // (B, L, 3, Ctot)   fp32, or the 16-bit operand type when IO16
+    void* out;             // (B, L, Ctot)      same element type as qkv
     const float* lepe_w;   // (Cb, 3, 3) or null
     const float* lepe_b;   // (Cb)
     int L, Ctot, c0, heads;
@@ -33,8 +34,10 @@ struct AttnArgs {
     int pre_scale;         // 1: q*scale before QK^T (CSWin), 0: (QK^T)*scale (ViT)
 };
 
-template <int PREC, int D, int KT, bool LEPE>
-__global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
+template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW>
+__global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
+    constexpr int NTHR = NW * 64;             // NW waves share one head's K / V (8 for the 197-token ViT case: 4 waves per SIMD)
+    static_assert(!IO16 || PREC != 0, "16-bit I/O exists for the fp16 / bf16 operand modes only");
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
     using v4 = typename M_::v4;
@@ -43,11 +46,12 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
     constexpr int TK = KT * 16;               // padded key count
     constexpr int KP = D + 8;                 // K row pitch (elements)
     constexpr int VP = TK + 4;                // V^T row pitch (elements, multiple of 4 -> 8-byte aligned reads)
-    constexpr int OP = D + 4;                 // O slab pitch (floats)
+    constexpr int OP = IO16 ? D + 8 : D + 4;  // O slab pitch (elements: 16-bit when the output is 16-bit, else floats)
     constexpr int K_EL = TK * KP, V_EL = D * VP;
+    using slab_t = typename std::conditional<IO16, unsigned short, float>::type;
     __shared__ __attribute__((aligned(16))) unsigned short s_k[NS * K_EL];
     __shared__ __attribute__((aligned(16))) unsigned short s_v[NS * V_EL];
-    __shared__ __attribute__((aligned(16))) float s_o[4 * 16 * OP];
+    __shared__ __attribute__((aligned(16))) slab_t s_o[NW * 16 * OP];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int bid = blockIdx.x;
@@ -58,12 +62,54 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
     const int wy0 = (win / a.nWx) * a.Hsp, wx0 = (win % a.nWx) * a.Wsp;
     const int ch0 = a.c0 + head * D;                                  // first channel of this head inside a q/k/v row
     const long row3 = 3L * a.Ctot;
-    const float* base = a.qkv + (long)b * a.L * row3 + ch0;
+    using gel = typename std::conditional<IO16, el, float>::type;        // element type in HBM
+    const gel* base = static_cast<const gel*>(a.qkv) + (long)b * a.L * row3 + ch0;
     auto tok = [&](int s) { return (wy0 + s / a.Wsp) * a.reso + wx0 + s % a.Wsp; };   // window slot -> token index
 
     // ---- phase A: K -> LDS [key][d],  V -> LDS transposed [d][key] -------------------------------------------------
     constexpr int D4 = D / 4;
-    for (int idx = t; idx < TK * D4; idx += 256) {
+    if constexpr (IO16) {
+        // all global loads of the head are issued back to back into registers (one memory latency for K and V together),
+        // then written to LDS: K as is, V through a 4(key) x 8(d) register transpose
+        constexpr int D8 = D / 8;
+        constexpr int NKI = (TK * D8 + NTHR - 1) / NTHR, NVI = ((TK / 4) * D8 + NTHR - 1) / NTHR;
+        const v8 zero8 = {};
+        v8 kreg[NKI];
+        v8 vreg[NVI][4];
+#pragma unroll
+        for (int it = 0; it < NKI; ++it) {
+            const int idx = t + it * NTHR, key = idx / D8, d8 = idx % D8;
+            kreg[it] = zero8;
+            if (idx < TK * D8 && key < T) kreg[it] = *reinterpret_cast<const v8*>(base + (long)tok(key) * row3 + a.Ctot + d8 * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NVI; ++it) {
+            const int idx = t + it * NTHR, kg = idx / D8, d8 = idx % D8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kg * 4 + j;
+                vreg[it][j] = zero8;
+                if (idx < (TK / 4) * D8 && key < T)
+                    vreg[it][j] = *reinterpret_cast<const v8*>(base + (long)tok(key) * row3 + 2 * a.Ctot + d8 * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NKI; ++it) {
+            const int idx = t + it * NTHR, key = idx / D8, d8 = idx % D8;
+            if (idx < TK * D8) *reinterpret_cast<v8*>(s_k + key * KP + d8 * 8) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NVI; ++it) {
+            const int idx = t + it * NTHR, kg = idx / D8, d8 = idx % D8;
+            if (idx < (TK / 4) * D8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<v4*>(s_v + (d8 * 8 + q) * VP + kg * 4) =
+                        v4{vreg[it][0][q], vreg[it][1][q], vreg[it][2][q], vreg[it][3][q]};
+            }
+        }
+    } else {
+    for (int idx = t; idx < TK * D4; idx += NTHR) {
         const int key = idx / D4, d4 = idx % D4;
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (key < T) v = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + a.Ctot + d4 * 4);
@@ -71,7 +117,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
         *reinterpret_cast<v4*>(s_k + key * KP + d4 * 4) = h;
         if constexpr (NS == 2) *reinterpret_cast<v4*>(s_k + K_EL + key * KP + d4 * 4) = M_::cvt_lo(v, h);
     }
-    for (int idx = t; idx < (TK / 4) * D4; idx += 256) {
+    for (int idx = t; idx < (TK / 4) * D4; idx += NTHR) {
         const int kg = idx / D4, d4 = idx % D4;
         f4 r[4];
 #pragma unroll
@@ -89,22 +135,30 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
             if constexpr (NS == 2) *reinterpret_cast<v4*>(s_v + V_EL + (d4 * 4 + q) * VP + kg * 4) = M_::cvt_lo(c[q], h);
         }
     }
+    }
     __syncthreads();
 
     // ---- phase B: each wave owns 16-query tiles ------------------------------------------------------------------------
     const int l15 = lane & 15, g = lane >> 4;
     const int nqt = (T + 15) >> 4;
-    float* slab = s_o + wave * 16 * OP;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    slab_t* slab = s_o + wave * 16 * OP;
+    for (int qt = wave; qt < nqt; qt += NW) {
         // Q fragments (B operand of S^T = K.Q^T): column q = l15, k = d = ks*32 + g*8 + [0,8)
         const int qs = qt * 16 + l15;
         v8 qf[D / 32][NS];
         {
-            const float* qrow = base + (long)tok(qs < T ? qs : 0) * row3;
+            const gel* qrow = base + (long)tok(qs < T ? qs : 0) * row3;
 #pragma unroll
             for (int ks = 0; ks < D / 32; ++ks) {
                 f4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-                if (qs < T) {
+                if constexpr (IO16) {
+                    if (qs < T) {
+                        const v8 raw = *reinterpret_cast<const v8*>(qrow + ks * 32 + g * 8);
+                        if (!a.pre_scale) { qf[ks][0] = raw; continue; }
+                        lo4 = f4{(float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]};
+                        hi4 = f4{(float)raw[4], (float)raw[5], (float)raw[6], (float)raw[7]};
+                    }
+                } else if (qs < T) {
                     lo4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8);
                     hi4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8 + 4);
                 }
@@ -134,7 +188,8 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
             }
         }
         // softmax over keys (masked beyond T)
-        const float post = a.pre_scale ? 1.0f : a.scale;
+        // logits are kept in log2 units: p = 2^(s*scale*log2(e) - max) == exp(s*scale - max) on the v_exp_f32 unit
+        const float post = (a.pre_scale ? 1.0f : a.scale) * 1.44269504088896340736f;
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -152,7 +207,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = expf(s[kt][r] - m);      // exp(-inf) = 0 for masked keys
+                const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);      // 2^(-inf) = 0 for masked keys
                 s[kt][r] = p;
                 sum += p;
             }
@@ -221,19 +276,31 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
                         val += acc;
                     }
                 }
-                slab[(g * 4 + r) * OP + nt * 16 + l15] = val;
+                if constexpr (IO16) *reinterpret_cast<el*>(slab + (g * 4 + r) * OP + nt * 16 + l15) = M_::cvt1(val);
+                else slab[(g * 4 + r) * OP + nt * 16 + l15] = val;
             }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // row-contiguous stores: D/4 lanes per query row
-        constexpr int LPR = D / 4, RPI = 64 / LPR;
+        // row-contiguous stores: 16 bytes per lane
+        if constexpr (IO16) {
+            constexpr int LPR = D / 8, RPI = 64 / LPR;
 #pragma unroll
-        for (int it = 0; it < 16 / RPI; ++it) {
-            const int r = it * RPI + lane / LPR, c4 = (lane % LPR) * 4;
-            const int qslot = qt * 16 + r;
-            if (qslot < T) {
-                const f4 v = *reinterpret_cast<const f4*>(slab + r * OP + c4);
-                *reinterpret_cast<f4*>(a.out + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c4) = v;
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int r = it * RPI + lane / LPR, c8 = (lane % LPR) * 8;
+                const int qslot = qt * 16 + r;
+                if (qslot < T)
+                    *reinterpret_cast<v8*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c8) =
+                        *reinterpret_cast<const v8*>(slab + r * OP + c8);
+            }
+        } else {
+            constexpr int LPR = D / 4, RPI = 64 / LPR;
+#pragma unroll
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int r = it * RPI + lane / LPR, c4 = (lane % LPR) * 4;
+                const int qslot = qt * 16 + r;
+                if (qslot < T)
+                    *reinterpret_cast<f4*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c4) =
+                        *reinterpret_cast<const f4*>(slab + r * OP + c4);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -241,15 +308,18 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const AttnArgs a) {
     }
 }
 
-template <int D, bool LEPE>
+template <int D, bool LEPE, bool IO16>
 int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st) {
     const int grid = B * a.nwin * a.heads;
-#define GO(P, KT_) win_attn_kernel<P, D, KT_, LEPE><<<grid, 256, 0, st>>>(a)
-#define BYKT(P)                              \
-    do {                                     \
-        if (a.T <= 64) GO(P, 4);             \
-        else if (a.T <= 128) GO(P, 8);       \
-        else GO(P, 14);                      \
+    if (IO16 && precision == MI355_PREC_STRICT)
+        return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
+#define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(a)
+#define BYKT(P)                                          \
+    do {                                                 \
+        if (a.T <= 64) GO(P, 4, 4);                      \
+        else if (a.T <= 128) GO(P, 8, 4);                \
+        else if (IO16 && P != 0) GO(P, 14, 8);           \
+        else GO(P, 14, 4);                               \
     } while (0)
     switch (precision) {
         case MI355_PREC_STRICT: BYKT(0); break;
@@ -264,19 +334,54 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st) {
 
 }  // namespace
 
+static int sdpa_common(const void* qkv, void* out, int B, int N, int heads, int d, float scale, int precision, bool io16,
+                       hipStream_t st) {
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.L = N; a.Ctot = heads * d; a.c0 = 0; a.heads = heads;
+    a.reso = N; a.Hsp = 1; a.Wsp = N; a.nWx = 1; a.nwin = 1; a.T = N; a.scale = scale; a.pre_scale = 0;
+    if (d == 64) return io16 ? launch_attn<64, false, true>(a, B, precision, st) : launch_attn<64, false, false>(a, B, precision, st);
+    return io16 ? launch_attn<32, false, true>(a, B, precision, st) : launch_attn<32, false, false>(a, B, precision, st);
+}
+
+static int lepe_common(const void* qkv, const float* getv_w, const float* getv_b, void* out, int B, int reso, int Ctot, int c0, int Cb,
+                       int heads, int Hsp, int Wsp, float scale, int precision, bool io16, hipStream_t st) {
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.lepe_w = getv_w; a.lepe_b = getv_b;
+    a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
+    a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = Hsp * Wsp;
+    a.scale = scale; a.pre_scale = 1;
+    return io16 ? launch_attn<32, true, true>(a, B, precision, st) : launch_attn<32, true, false>(a, B, precision, st);
+}
+
+#define SDPA_CHECKS(fn)                                                                                                   \
+    MI355_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0);                                                           \
+    if (!(d == 32 || d == 64)) return mi355::fail(MI355_EUNSUPPORTED, fn ": head dim %d (built: 32, 64)", d);            \
+    if (N > 224) return mi355::fail(MI355_EUNSUPPORTED, fn ": sequence length %d > 224 (single-pass softmax core)", N);   \
+    MI355_CHECK_ARG(aligned16(qkv) && aligned16(out))
+
+#define LEPE_CHECKS(fn)                                                                                                    \
+    MI355_CHECK_ARG(qkv && getv_w && getv_b && out);                                                                       \
+    MI355_CHECK_ARG(B > 0 && reso > 0 && Ctot > 0 && c0 >= 0 && Cb > 0 && c0 + Cb <= Ctot && heads > 0 && Cb % heads == 0); \
+    MI355_CHECK_ARG(Hsp > 0 && Wsp > 0 && reso % Hsp == 0 && reso % Wsp == 0);                                             \
+    if (Cb / heads != 32) return mi355::fail(MI355_EUNSUPPORTED, fn ": head dim %d (built: 32)", Cb / heads);             \
+    if (Hsp * Wsp > 224) return mi355::fail(MI355_EUNSUPPORTED, fn ": %d tokens per stripe window > 224", Hsp * Wsp);     \
+    MI355_CHECK_ARG((Ctot & 7) == 0 && (c0 & 7) == 0 && aligned16(qkv) && aligned16(out))
+
 extern "C" {
 
 int mi355_sdpa_fwd(const float* qkv, float* out, int B, int N, int heads, int d, float scale, int precision,
                    mi355_stream_t stream) {
-    MI355_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0);
-    if (!(d == 32 || d == 64)) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_fwd: head dim %d (built: 32, 64)", d);
-    if (N > 224) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_fwd: sequence length %d > 224 (single-pass softmax core)", N);
-    MI355_CHECK_ARG(aligned16(qkv) && aligned16(out));
-    AttnArgs a{};
-    a.qkv = qkv; a.out = out; a.L = N; a.Ctot = heads * d; a.c0 = 0; a.heads = heads;
-    a.reso = N; a.Hsp = 1; a.Wsp = N; a.nWx = 1; a.nwin = 1; a.T = N; a.scale = scale; a.pre_scale = 0;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = (d == 64) ? launch_attn<64, false>(a, B, precision, st) : launch_attn<32, false>(a, B, precision, st);
+    SDPA_CHECKS("mi355_sdpa_fwd");
+    int rc = sdpa_common(qkv, out, B, N, heads, d, scale, precision, false, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_sdpa16_fwd(const void* qkv, void* out, int B, int N, int heads, int d, float scale, int precision,
+                     mi355_stream_t stream) {
+    SDPA_CHECKS("mi355_sdpa16_fwd");
+    int rc = sdpa_common(qkv, out, B, N, heads, d, scale, precision, true, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;
@@ -284,20 +389,19 @@ int mi355_sdpa_fwd(const float* qkv, float* out, int B, int N, int heads, int d,
 
 int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float* getv_b, float* out, int B, int reso, int Ctot,
                               int c0, int Cb, int heads, int Hsp, int Wsp, float scale, int precision, mi355_stream_t stream) {
-    MI355_CHECK_ARG(qkv && getv_w && getv_b && out);
-    MI355_CHECK_ARG(B > 0 && reso > 0 && Ctot > 0 && c0 >= 0 && Cb > 0 && c0 + Cb <= Ctot && heads > 0 && Cb % heads == 0);
-    MI355_CHECK_ARG(Hsp > 0 && Wsp > 0 && reso % Hsp == 0 && reso % Wsp == 0);
-    const int d = Cb / heads, T = Hsp * Wsp;
-    if (d != 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn_fwd: head dim %d (built: 32)", d);
-    if (T > 224) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn_fwd: %d tokens per stripe window > 224", T);
-    MI355_CHECK_ARG((Ctot & 3) == 0 && (c0 & 3) == 0 && aligned16(qkv) && aligned16(out));
-    AttnArgs a{};
-    a.qkv = qkv; a.out = out; a.lepe_w = getv_w; a.lepe_b = getv_b;
-    a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
-    a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = T;
-    a.scale = scale; a.pre_scale = 1;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_attn<32, true>(a, B, precision, st);
+    LEPE_CHECKS("mi355_cswin_lepe_attn_fwd");
+    int rc = lepe_common(qkv, getv_w, getv_b, out, B, reso, Ctot, c0, Cb, heads, Hsp, Wsp, scale, precision, false,
+                         static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_cswin_lepe_attn16_fwd(const void* qkv, const float* getv_w, const float* getv_b, void* out, int B, int reso, int Ctot,
+                                int c0, int Cb, int heads, int Hsp, int Wsp, float scale, int precision, mi355_stream_t stream) {
+    LEPE_CHECKS("mi355_cswin_lepe_attn16_fwd");
+    int rc = lepe_common(qkv, getv_w, getv_b, out, B, reso, Ctot, c0, Cb, heads, Hsp, Wsp, scale, precision, true,
+                         static_cast<hipStream_t>(stream));
     if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -183,20 +183,21 @@ __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// CBAM K2: channel gate gc[b,c] = sigmoid(W2 (relu(W1 avg) + relu(W1 max)))  (cbam.py:31-35; fc has no
-// bias so fc(avg)+fc(max) collapses to one W2 product).  grid = B, 256 threads.  smem: a[C] | m[C] | h[Cr].
+// CBAM channel gates of one image, computed cooperatively by a 256-thread workgroup into LDS:
+//   gc[c] = sigmoid(W2 (relu(W1 avg) + relu(W1 max)))  (cbam.py:31-35; fc has no bias, so fc(avg)+fc(max)
+//   collapses to one W2 product).  12K MACs -- cheaper to recompute in every consumer workgroup than to
+//   launch a kernel for it.  scratch: a[C] | m[C] | h[Cr];  result: s_gc[C].  Ends with a barrier.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cbam_channel_gate_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
-                                                               const float* __restrict__ w1, const float* __restrict__ w2,
-                                                               float* __restrict__ gc, int C, int Cr) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_a = smem;
-    float* s_m = smem + C;
+__device__ __forceinline__ void cbam_channel_gates(const float* __restrict__ avg_b, const float* __restrict__ mx_b,
+                                                   const float* __restrict__ w1, const float* __restrict__ w2, int C, int Cr,
+                                                   float* scratch, float* s_gc) {
+    float* s_a = scratch;
+    float* s_m = scratch + C;
     float* s_h = s_m + C;
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
-        s_a[c] = avg[(long)b * C + c];
-        s_m[c] = mx[(long)b * C + c];
+        s_a[c] = avg_b[c];
+        s_m[c] = mx_b[c];
     }
     __syncthreads();
     const int part = t & 15, jl = t >> 4;
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(256) void cbam_channel_gate_kernel(const float* __r
         const float* w2r = w2 + (long)c * Cr;
         float z = 0.f;
         for (int j = 0; j < Cr; ++j) z += w2r[j] * s_h[j];
-        gc[(long)b * C + c] = sigmoidf_(z);
+        s_gc[c] = sigmoidf_(z);
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -224,11 +226,19 @@ __global__ __launch_bounds__(256) void cbam_channel_gate_kernel(const float* __r
 // channel range and combine through LDS.  gc may be NULL (stage 2: SpatialAttention alone).
 // ---------------------------------------------------------------------------------------------------
 template <bool VEC>
-__global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __restrict__ x, const float* __restrict__ gc,
-                                                                float* __restrict__ smap, int C, int HW, int tiles) {
+__global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __restrict__ x, const float* __restrict__ avg,
+                                                                const float* __restrict__ mx, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, float* __restrict__ smap, int C,
+                                                                int Cr, int HW, int tiles) {
     constexpr int VW = VEC ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // gc[C] | scratch a[C] m[C] h[Cr]   (only when avg != null)
     __shared__ __attribute__((aligned(16))) float s_sum[4][64 * VW];
     __shared__ __attribute__((aligned(16))) float s_max[4][64 * VW];
+    const bool has_c = avg != nullptr;
+    if (has_c) {
+        const int bb = blockIdx.x / tiles;
+        cbam_channel_gates(avg + (long)bb * C, mx + (long)bb * C, w1, w2, C, Cr, smem + C, smem);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int nv = HW / VW;                       // vector elements per row
@@ -238,11 +248,10 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < VW; ++q) { s[q] = 0.f; m[q] = -INFINITY; }
     const float* xb = x + (long)b * C * HW;
-    const float* gb = gc ? gc + (long)b * C : nullptr;
     if (ok) {
 #pragma unroll 8
         for (int c = wave; c < C; c += 4) {
-            const float g = gb ? gb[c] : 1.0f;
+            const float g = has_c ? smem[c] : 1.0f;
             if constexpr (VEC) {
                 const float4 v = reinterpret_cast<const float4*>(xb + (long)c * HW)[iv];
                 const float a0 = v.x * g, a1 = v.y * g, a2 = v.z * g, a3 = v.w * g;
@@ -271,109 +280,111 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// CBAM K4: spatial gate gs[b,p] = sigmoid(conv_ks x ks (smap[b]) ), 2->1 channels, zero pad ks/2, no bias,
-// cross-correlation.  Workgroup = (image, band of TR full-width rows); the band plus halo sits in LDS and every
-// thread produces 4 horizontally adjacent outputs (each LDS value feeds up to 4 taps from a register).
-// smem: w[2*ks*ks] | tile[2][(TR+ks-1)][TW]   with TW = 4*ceil(W/4) + ks - 1
+// CBAM K4: y = (x * gc[b,c]) * gs[b,p] for one (image, band of TR rows) -- all channels.  The workgroup first rebuilds
+// what it needs on chip: the channel gates (see above), then the spatial gate of ITS band,
+//   gs = sigmoid(conv_ks x ks(smap[b]))  (2->1 channels, zero pad ks/2, no bias, cross-correlation; cbam.py:43-48),
+// from an LDS tile of the 2-channel map (band + halo, 4 outputs per thread), so neither gate ever goes through HBM
+// and no gate kernel sits between the streaming passes.  Then it streams the band of every channel (rounding order
+// of the reference: the channel-stage product is rounded to fp32 before the spatial multiply).
+// smem: gc[C] | scratch[2C+Cr] | w[2*ks*ks (pad 4)] | tile[2][TH][TW] | gs[TR*W (pad 4)]
 // ---------------------------------------------------------------------------------------------------
-template <int KS>   // KS > 0: compile-time kernel size (fully unrolled taps); KS == 0: runtime ks
-__global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __restrict__ smap, const float* __restrict__ wconv,
-                                                               float* __restrict__ gs, int H, int W, int ks_rt, int TR, int bands) {
+template <int KS, bool VEC, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void cbam_apply_band_kernel(const float* __restrict__ x, const float* __restrict__ avg,
+                                                             const float* __restrict__ mx, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, const float* __restrict__ smap,
+                                                             const float* __restrict__ wconv, float* __restrict__ y, int C, int Cr,
+                                                             int H, int W, int ks_rt, int TR, int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool has_c = avg != nullptr, has_s = smap != nullptr;
     const int ks = KS > 0 ? KS : ks_rt;
     const int kk = ks * ks, pad = ks / 2;
     const int quads = (W + 3) >> 2;
     const int TW = quads * 4 + ks - 1, TH = TR + ks - 1;
-    float* s_w = smem;
-    float* s_t = smem + ((2 * kk + 3) & ~3);
-    const int t = threadIdx.x;
-    const int b = blockIdx.x / bands, r0 = (blockIdx.x % bands) * TR;
-    for (int i = t; i < 2 * kk; i += 256) s_w[i] = wconv[i];
-    const float* sb = smap + (long)b * 2 * H * W;
-    for (int i = t; i < 2 * TH * TW; i += 256) {
-        const int ch = i / (TH * TW), rem = i % (TH * TW);
-        const int ty = rem / TW, tx = rem % TW;
-        const int gy = r0 + ty - pad, gx = tx - pad;
-        s_t[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? sb[((long)ch * H + gy) * W + gx] : 0.f;
-    }
-    __syncthreads();
-    const int rows_here = min(TR, H - r0);
-    for (int o = t; o < rows_here * quads; o += 256) {
-        const int r = o / quads, col = (o % quads) * 4;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int ch = 0; ch < 2; ++ch) {
-            if constexpr (KS > 0) {
-#pragma unroll
-                for (int dy = 0; dy < KS; ++dy) {
-                    const float* trow = s_t + (ch * TH + r + dy) * TW + col;
-                    const float* wrow = s_w + ch * kk + dy * KS;
-                    float v[KS + 3];
-#pragma unroll
-                    for (int i = 0; i < KS + 3; ++i) v[i] = trow[i];
-#pragma unroll
-                    for (int dx = 0; dx < KS; ++dx) {
-                        const float w = wrow[dx];
-                        a0 += w * v[dx]; a1 += w * v[dx + 1]; a2 += w * v[dx + 2]; a3 += w * v[dx + 3];
-                    }
-                }
-            } else {
-                for (int dy = 0; dy < ks; ++dy) {
-                    const float* trow = s_t + (ch * TH + r + dy) * TW + col;
-                    const float* wrow = s_w + ch * kk + dy * ks;
-                    for (int dx = 0; dx < ks; ++dx) {
-                        const float w = wrow[dx];
-                        a0 += w * trow[dx]; a1 += w * trow[dx + 1]; a2 += w * trow[dx + 2]; a3 += w * trow[dx + 3];
-                    }
-                }
-            }
-        }
-        float* out = gs + (long)b * H * W + (long)(r0 + r) * W + col;
-        const float res[4] = {a0, a1, a2, a3};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (col + q < W) out[q] = sigmoidf_(res[q]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// CBAM K5: y = (x * gc[b,c]) * gs[b,p]   (same rounding order as the reference: channel stage output is
-// rounded to fp32 before the spatial multiply).  Workgroup = (image, RPB channels); waves walk pixel
-// chunks (gs stays in 4 VGPRs) and loop the RPB rows inside.  gc or gs may be NULL (= 1).
-// ---------------------------------------------------------------------------------------------------
-template <bool VEC, bool NTL, bool NTS>
-__global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, const float* __restrict__ gc,
-                                                        const float* __restrict__ gs, float* __restrict__ y,
-                                                        int C, int HW, int groups, int reverse) {
-    __shared__ float s_g[RPB];
+    float* s_gc = smem;
+    float* s_scr = smem + C;
+    float* s_w = smem + ((3 * C + Cr + 3) & ~3);             // keep the float4-read regions 16-byte aligned
+    float* s_t = s_w + ((2 * kk + 3) & ~3);
+    float* s_gs = s_t + ((2 * TH * TW + 3) & ~3);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int blk = second_pass_block(blockIdx.x, gridDim.x, reverse);
-    const int b = blk / groups, c0 = (blk % groups) * RPB;
-    const int nrows = min(RPB, C - c0);
-    if (t < RPB) s_g[t] = (gc && t < nrows) ? gc[(long)b * C + c0 + t] : 1.0f;
-    __syncthreads();
-    const float* xb = x + ((long)b * C + c0) * HW;
-    float* yb = y + ((long)b * C + c0) * HW;
-    const float* gsb = gs ? gs + (long)b * HW : nullptr;
-    if constexpr (VEC) {
-        const int n4 = HW >> 2;
-        const int chunks = (n4 + 63) >> 6;
-        for (int ch = wave; ch < chunks; ch += 4) {
-            const int i = ch * 64 + lane;
-            if (i >= n4) continue;
-            v4f s4 = {1.f, 1.f, 1.f, 1.f};
-            if (gsb) s4 = reinterpret_cast<const v4f*>(gsb)[i];
-#pragma unroll 4
-            for (int r = 0; r < nrows; ++r) {
-                const float g = s_g[r];
-                v4f v = ldx<NTL>(&reinterpret_cast<const v4f*>(xb + (long)r * HW)[i]);
-                v = (v * g) * s4;
-                stx<NTS>(v, &reinterpret_cast<v4f*>(yb + (long)r * HW)[i]);
+    const int b = blockIdx.x / bands, r0 = (blockIdx.x % bands) * TR;
+    const int rows_here = min(TR, H - r0);
+    const int HW = H * W;
+
+    if (has_c) cbam_channel_gates(avg + (long)b * C, mx + (long)b * C, w1, w2, C, Cr, s_scr, s_gc);
+    if (has_s) {
+        for (int i = t; i < 2 * kk; i += 256) s_w[i] = wconv[i];
+        const float* sb = smap + (long)b * 2 * HW;
+        for (int i = t; i < 2 * TH * TW; i += 256) {
+            const int ch = i / (TH * TW), rem = i % (TH * TW);
+            const int ty = rem / TW, tx = rem % TW;
+            const int gy = r0 + ty - pad, gx = tx - pad;
+            s_t[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? sb[((long)ch * H + gy) * W + gx] : 0.f;
+        }
+        __syncthreads();
+        for (int o = t; o < rows_here * quads; o += 256) {
+            const int r = o / quads, col = (o % quads) * 4;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int ch = 0; ch < 2; ++ch) {
+                if constexpr (KS > 0) {
+#pragma unroll
+                    for (int dy = 0; dy < KS; ++dy) {
+                        const float* trow = s_t + (ch * TH + r + dy) * TW + col;
+                        const float* wrow = s_w + ch * kk + dy * KS;
+                        float v[KS + 3];
+#pragma unroll
+                        for (int i = 0; i < KS + 3; ++i) v[i] = trow[i];
+#pragma unroll
+                        for (int dx = 0; dx < KS; ++dx) {
+                            const float w = wrow[dx];
+                            a0 += w * v[dx]; a1 += w * v[dx + 1]; a2 += w * v[dx + 2]; a3 += w * v[dx + 3];
+                        }
+                    }
+                } else {
+                    for (int dy = 0; dy < ks; ++dy) {
+                        const float* trow = s_t + (ch * TH + r + dy) * TW + col;
+                        const float* wrow = s_w + ch * kk + dy * ks;
+                        for (int dx = 0; dx < ks; ++dx) {
+                            const float w = wrow[dx];
+                            a0 += w * trow[dx]; a1 += w * trow[dx + 1]; a2 += w * trow[dx + 2]; a3 += w * trow[dx + 3];
+                        }
+                    }
+                }
             }
+            const float res[4] = {a0, a1, a2, a3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col + q < W) s_gs[r * W + col + q] = sigmoidf_(res[q]);
+        }
+    }
+    __syncthreads();
+
+    // ---- stream the band of every channel: waves take channels round-robin, (channel, vector) pairs are walked flat so
+    //      that all 64 lanes stay busy whatever the band length --------------------------------------------------------------
+    const long band0 = (long)r0 * W;
+    const int npx = rows_here * W;
+    const float* xb = x + (long)b * C * HW + band0;
+    float* yb = y + (long)b * C * HW + band0;
+    if constexpr (VEC) {
+        const int n4 = npx >> 2;                                    // W % 4 == 0 on this path
+        int c = wave, i = lane;
+        while (i >= n4) { i -= n4; c += 4; }
+        while (c < C) {
+            const float g = has_c ? s_gc[c] : 1.0f;
+            v4f s4 = {1.f, 1.f, 1.f, 1.f};
+            if (has_s) s4 = reinterpret_cast<const v4f*>(s_gs)[i];
+            v4f v = ldx<NTL>(&reinterpret_cast<const v4f*>(xb + (long)c * HW)[i]);
+            v = (v * g) * s4;
+            stx<NTS>(v, &reinterpret_cast<v4f*>(yb + (long)c * HW)[i]);
+            i += 64;
+            while (i >= n4) { i -= n4; c += 4; }
         }
     } else {
-        for (int i = t; i < HW; i += 256) {
-            const float sp = gsb ? gsb[i] : 1.0f;
-            for (int r = 0; r < nrows; ++r) yb[(long)r * HW + i] = (xb[(long)r * HW + i] * s_g[r]) * sp;
+        for (int c = wave; c < C; c += 4) {
+            const float g = has_c ? s_gc[c] : 1.0f;
+            for (int i = lane; i < npx; i += 64) {
+                const float sp = has_s ? s_gs[i] : 1.0f;
+                yb[(long)c * HW + i] = (xb[(long)c * HW + i] * g) * sp;
+            }
         }
     }
 }
@@ -406,10 +417,14 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restri
 
 struct Tune { int chunk; int ntl; int nts; int reverse; };
 
-inline Tune resolve_tune(int B) {
+inline Tune resolve_tune(int B, long bytes_per_image) {
     Tune t;
-    long ci = mi355::opt_chunk_images();                 // 0 = whole batch in one pass pair (default)
-    t.chunk = (ci <= 0 || ci > B) ? B : (int)ci;
+    long ci = mi355::opt_chunk_images();
+    if (ci <= 0) {   // auto: ~200 MB of x per chunk, so the chunk's re-read(s) are served by the 256 MiB Infinity Cache
+        ci = (200L << 20) / (bytes_per_image > 0 ? bytes_per_image : 1);
+        if (ci < 1) ci = 1;
+    }
+    t.chunk = ci > B ? B : (int)ci;
     const long nt = mi355::opt_nt();
     t.ntl = (nt & 1) != 0;
     t.nts = (nt & 2) != 0;
@@ -441,7 +456,7 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     const int groups = cdiv(C, RPB);
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
-    const Tune tu = resolve_tune(B);
+    const Tune tu = resolve_tune(B, (long)C * HW * 4);
     for (int b0 = 0; b0 < B; b0 += tu.chunk) {
         const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;
         const float* xc = x + (long)b0 * C * HW;
@@ -484,11 +499,10 @@ int mi355_eca_fwd(const float* x, const float* wconv, float* y, int B, int C, in
     return se_eca_common(1, x, wconv, nullptr, y, B, C, k, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
-// workspace: avg[B*C] | max[B*C] | gc[B*C] | smap[B*2*HW] | gs[B*HW]   (each region rounded to 16 B)
+// workspace: avg[B*C] | max[B*C] | smap[B*2*HW]   (each region rounded to 16 B)
 static inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
 size_t mi355_cbam_workspace_bytes(int B, int C, int H, int W) {
-    const size_t bc = r16((size_t)B * C * 4), hw = (size_t)H * W;
-    return 3 * bc + r16((size_t)B * 2 * hw * 4) + r16((size_t)B * hw * 4);
+    return 2 * r16((size_t)B * C * 4) + r16((size_t)B * 2 * H * W * 4);
 }
 
 int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr,
@@ -501,68 +515,67 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
     if (do_s) MI355_CHECK_ARG(wconv && ks > 0 && (ks & 1));
     MI355_CHECK_ARG(ws_bytes >= mi355_cbam_workspace_bytes(B, C, H, W));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!do_c) Cr = 0;
+    if (!do_s) ks = 1;
     const int HW = H * W;
-    const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+    const bool vec_pix = (HW % 4 == 0) && aligned16(x) && aligned16(y);          // whole-image rows
+    const bool vec_band = vec_pix && (W % 4 == 0);                               // row bands start 16-byte aligned
     char* wsp = static_cast<char*>(ws);
     const size_t bc = r16((size_t)B * C * 4);
     float* avg = reinterpret_cast<float*>(wsp);
     float* mx = reinterpret_cast<float*>(wsp + bc);
-    float* gc = reinterpret_cast<float*>(wsp + 2 * bc);
-    float* smap = reinterpret_cast<float*>(wsp + 3 * bc);
-    float* gs = reinterpret_cast<float*>(wsp + 3 * bc + r16((size_t)B * 2 * HW * 4));
+    float* smap = reinterpret_cast<float*>(wsp + 2 * bc);
 
-    // spatial-gate band geometry: 4 outputs per thread, about one output quad per thread per band,
-    // LDS tile (2 ch) of (TR + ks - 1) x (4*ceil(W/4) + ks - 1) floats <= 60 KiB
-    int TR = H, bands = 1;
-    size_t smem_gate = 0;
-    if (do_s) {
-        const int quads = (W + 3) / 4, TW = quads * 4 + ks - 1, wpad = (2 * ks * ks + 3) & ~3;
-        TR = 256 / quads;
-        if (TR < 1) TR = 1;
-        if (TR > H) TR = H;
-        while (TR > 1 && (size_t)(wpad + 2 * (TR + ks - 1) * TW) * 4 > 60 * 1024) --TR;
-        smem_gate = (size_t)(wpad + 2 * (TR + ks - 1) * TW) * 4;
-        if (smem_gate > 60 * 1024)
-            return mi355::fail(MI355_EUNSUPPORTED, "W=%d too wide for the %dx%d spatial-gate tile", W, ks, ks);
-        bands = cdiv(H, TR);
-    }
-    const size_t smem_cg = (size_t)(2 * C + Cr) * 4;
-    if (do_c && smem_cg > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
+    // band geometry of the final pass: ~8 rows per workgroup (>= 1 output quad per thread for the gate conv), LDS <= 60 KiB
+    const int quads = (W + 3) / 4, TW = quads * 4 + ks - 1, wpad = (2 * ks * ks + 3) & ~3;
+    const size_t gate_floats = (size_t)((3 * C + Cr + 3) & ~3);
+    int TR = 256 / quads;
+    if (TR > 8) TR = 8;
+    if (TR < 1) TR = 1;
+    if (TR > H) TR = H;
+    auto apply_smem = [&](int tr) {
+        return (gate_floats + wpad + (size_t)((2 * (tr + ks - 1) * TW + 3) & ~3) + (size_t)((tr * W + 3) & ~3)) * 4;
+    };
+    while (TR > 1 && apply_smem(TR) > 60 * 1024) --TR;
+    if (apply_smem(TR) > 60 * 1024)
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_cbam_fwd: C=%d / W=%d exceed the LDS budget of the fused final pass", C, W);
+    const int bands = cdiv(H, TR);
+    const size_t smem_apply = apply_smem(TR);
+    const size_t smem_stats = do_c ? gate_floats * 4 : 0;
 
     const int groups = cdiv(C, RPB);
-    const int VW = vec ? 4 : 1;
+    const int VW = vec_pix ? 4 : 1;
     const int tiles = cdiv(HW / VW, 64);
-    const Tune tu = resolve_tune(B);
+    const Tune tu = resolve_tune(B, (long)C * HW * 4);
     for (int b0 = 0; b0 < B; b0 += tu.chunk) {
         const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;
         const float* xc = x + (long)b0 * C * HW;
         float* yc = y + (long)b0 * C * HW;
-        float* avgc = avg + (long)b0 * C;
-        float* mxc = mx + (long)b0 * C;
-        float* gcc = gc + (long)b0 * C;
-        float* smc = smap + (long)b0 * 2 * HW;
-        float* gsc = gs + (long)b0 * HW;
+        float* avgc = do_c ? avg + (long)b0 * C : nullptr;
+        float* mxc = do_c ? mx + (long)b0 * C : nullptr;
+        float* smc = do_s ? smap + (long)b0 * 2 * HW : nullptr;
         if (do_c) {
-            if (vec) pool_rows_kernel<true, true><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
-            else     pool_rows_kernel<true, false><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
-            cbam_channel_gate_kernel<<<nb, 256, smem_cg, st>>>(avgc, mxc, w1, w2, gcc, C, Cr);
+            if (vec_pix) pool_rows_kernel<true, true><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
+            else         pool_rows_kernel<true, false><<<nb * groups, 256, 0, st>>>(xc, avgc, mxc, C, HW, groups);
         }
         if (do_s) {
-            if (vec) cbam_spatial_stats_kernel<true><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
-            else     cbam_spatial_stats_kernel<false><<<nb * tiles, 256, 0, st>>>(xc, do_c ? gcc : nullptr, smc, C, HW, tiles);
-            if (ks == 7)      cbam_spatial_gate_kernel<7><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
-            else if (ks == 3) cbam_spatial_gate_kernel<3><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
-            else              cbam_spatial_gate_kernel<0><<<nb * bands, 256, smem_gate, st>>>(smc, wconv, gsc, H, W, ks, TR, bands);
+            if (vec_pix) cbam_spatial_stats_kernel<true><<<nb * tiles, 256, smem_stats, st>>>(xc, avgc, mxc, w1, w2, smc, C, Cr, HW, tiles);
+            else         cbam_spatial_stats_kernel<false><<<nb * tiles, 256, smem_stats, st>>>(xc, avgc, mxc, w1, w2, smc, C, Cr, HW, tiles);
         }
-        const float* gcp = do_c ? gcc : nullptr;
-        const float* gsp = do_s ? gsc : nullptr;
-#define APPLY_CALL(NTL, NTS)                                                                                             \
-        do {                                                                                                              \
-            if (vec) cbam_apply_kernel<true, NTL, NTS><<<nb * groups, 256, 0, st>>>(xc, gcp, gsp, yc, C, HW, groups, tu.reverse);  \
-            else     cbam_apply_kernel<false, NTL, NTS><<<nb * groups, 256, 0, st>>>(xc, gcp, gsp, yc, C, HW, groups, tu.reverse); \
+#define APPLY_KS(KS_, NTL, NTS)                                                                                                   \
+        do {                                                                                                                       \
+            if (vec_band) cbam_apply_band_kernel<KS_, true, NTL, NTS><<<nb * bands, 256, smem_apply, st>>>(xc, avgc, mxc, w1, w2, smc, wconv, yc, C, Cr, H, W, ks, TR, bands);  \
+            else          cbam_apply_band_kernel<KS_, false, NTL, NTS><<<nb * bands, 256, smem_apply, st>>>(xc, avgc, mxc, w1, w2, smc, wconv, yc, C, Cr, H, W, ks, TR, bands); \
+        } while (0)
+#define APPLY_CALL(NTL, NTS)                                  \
+        do {                                                   \
+            if (ks == 7) APPLY_KS(7, NTL, NTS);                \
+            else if (ks == 3) APPLY_KS(3, NTL, NTS);           \
+            else APPLY_KS(0, NTL, NTS);                        \
         } while (0)
         NT_DISPATCH(tu.ntl, tu.nts, APPLY_CALL);
 #undef APPLY_CALL
+#undef APPLY_KS
     }
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -1,0 +1,211 @@
+// gemm16.hip -- the fast GEMM path: 16-bit operands resident in HBM, LDS-DMA staging, MFMA 16x16x32, fused epilogue.
+//
+//   Y (M x N) = resid + gamma * act( X16 (M x K) . W16^T (N x K) + bias )        X16, W16: IEEE half (precision 1) or bfloat16 (2)
+//
+// Why a second GEMM: with fp32 operands in HBM the 128x128 tile of gemm.hip moves 32 KB per 1 MFLOP through L2 (32 FLOP/B) and
+// tops out near 370 TFLOP/s -- L2-bandwidth bound (profiles/r01_*).  Keeping activations and weights in their MFMA operand
+// format in memory halves those bytes, removes the convert + ds_write pass, and lets the tile go straight from HBM/L2 into LDS
+// with `global_load_lds` (16 B per lane, no VGPR round trip).  The rounding point is unchanged (operands are rounded to 16 bit
+// exactly once, accumulate and epilogue stay fp32), so results are bit-identical to gemm.hip in the same precision mode.
+//
+// Tile 128 x 128 x 64, 256 threads (4 waves, 2 x 2, 64 x 64 per wave).  LDS rows are 128 B (64 elements) and UNPADDED because
+// the DMA writes lane-linear; bank conflicts of the fragment reads are removed by an XOR swizzle applied on the SOURCE address
+// (chunk ^= row & 7) and again on the ds_read (cdna_hip_programming.md rule 21).  Two stages, one barrier per K-step.
+#include "common.h"
+#include "mma.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE = (BM + BN) * BK;          // elements per stage
+constexpr int EPITCH = 68;
+
+struct G16Args {
+    const void* A; const void* B; void* C;
+    const float* bias; const float* gamma; const float* resid;
+    int M, N, K, lda, ldb, ldc;
+    int act;
+};
+
+template <typename T> struct Vec8;
+template <> struct Vec8<_Float16> { using t = h8; using t4 = h4; };
+template <> struct Vec8<__bf16> { using t = b8; using t4 = b4; };
+
+template <typename T>
+__device__ __forceinline__ f4 mma16(typename Vec8<T>::t a, typename Vec8<T>::t b, f4 c);
+template <>
+__device__ __forceinline__ f4 mma16<_Float16>(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <>
+__device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <typename T, bool OUT16>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(const G16Args g) {
+    using v8 = typename Vec8<T>::t;
+    using v4 = typename Vec8<T>::t4;
+    constexpr int STAGE_BYTES = 2 * STAGE * 2;
+    constexpr int EPI_BYTES = 4 * 32 * EPITCH * 4;
+    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+
+    // ---- LDS-DMA source pointers: this wave fills rows [wave*32, wave*32+32) of the A and of the B tile, 8 rows per instruction;
+    //      lane -> (row = lane >> 3, physical chunk = lane & 7) holds logical chunk (lane & 7) ^ (row & 7) ------------------------
+    const int lrow = lane >> 3, pch = lane & 7;
+    const T* a_src[4];
+    const T* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + lrow;
+        const int c = (pch ^ (r & 7)) * 8;
+        int ma = m0 + r; if (ma >= g.M) ma = g.M - 1;          // clamp: tail rows/cols are computed on valid data and discarded
+        int nb = n0 + r; if (nb >= g.N) nb = g.N - 1;
+        a_src[i] = A + (long)ma * g.lda + c;
+        b_src[i] = B + (long)nb * g.ldb + c;
+    }
+    auto issue = [&](int stage, int k0) {
+        T* sA = lds + stage * STAGE + (wave * 32) * BK;
+        T* sB = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+        }
+    };
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) issue(st ^ 1, (kt + 1) * BK);
+        const T* sA = lds + st * STAGE + (wr * 64 + frow) * BK;
+        const T* sB = lds + st * STAGE + BM * BK + (wc * 64 + frow) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = (((ks * 4 + fq) ^ fsw) * 8);
+            v8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off);
+                fb[i] = *reinterpret_cast<const v8*>(sB + i * 16 * BK + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue (same structure as gemm.hip): per-wave LDS slab, row-contiguous stores ------------------------------------------
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EPITCH;
+    float* Cf = static_cast<float*>(g.C);
+    T* Ch = static_cast<T*>(g.C);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[(ii * 16 + (lane >> 4) * 4 + r) * EPITCH + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
+            const int m = m0 + wr * 64 + p * 32 + rl, n = n0 + wc * 64 + cl;
+            if (m >= g.M || n >= g.N) continue;                 // N % 4 == 0 is a launch precondition
+            f4 v = *reinterpret_cast<const f4*>(slab + rl * EPITCH + cl);
+            if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
+            if (g.act == MI355_ACT_GELU) v = f4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+            if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
+            if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+            if constexpr (OUT16) {
+                *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+            } else {
+                *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fp32 -> 16-bit operand format, 8 elements per thread (2 x 16-B loads, 1 x 16-B store)
+template <typename T>
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, T* __restrict__ dst, long n8, long n) {
+    using v8 = typename Vec8<T>::t;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n8; i += stride) {
+        const f4 a = reinterpret_cast<const f4*>(src)[2 * i], b = reinterpret_cast<const f4*>(src)[2 * i + 1];
+        reinterpret_cast<v8*>(dst)[i] = v8{(T)a.x, (T)a.y, (T)a.z, (T)a.w, (T)b.x, (T)b.y, (T)b.z, (T)b.w};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = (T)src[n8 * 8 + threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_cast16_fwd(const float* src, void* dst16, size_t n, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(src && dst16 && n > 0 && aligned16(src) && aligned16(dst16));
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    const long n8 = (long)(n / 8);
+    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 + 1 : 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == MI355_PREC_FP16) cast16_kernel<_Float16><<<grid, 256, 0, st>>>(src, static_cast<_Float16*>(dst16), n8, (long)n);
+    else                              cast16_kernel<__bf16><<<grid, 256, 0, st>>>(src, static_cast<__bf16*>(dst16), n8, (long)n);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y, int M,
+                       int N, int K, int ldx, int ldy, int act, int out16, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X16 && W16 && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if ((K % BK) || (N & 3) || (ldx & 7) || (ldy & 3) || !aligned16(X16) || !aligned16(W16) || !aligned16(Y) ||
+        (bias && !aligned16(bias)) || (gamma && !aligned16(gamma)) || (resid && !aligned16(resid)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear16_fwd: needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows (K=%d N=%d ldx=%d)",
+                           K, N, ldx);
+    G16Args g{};
+    g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.gamma = gamma; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
+    const int grid = cdiv(M, BM) * cdiv(N, BN);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == MI355_PREC_FP16) {
+        if (out16) gemm16_kernel<_Float16, true><<<grid, 256, 0, st>>>(g);
+        else       gemm16_kernel<_Float16, false><<<grid, 256, 0, st>>>(g);
+    } else {
+        if (out16) gemm16_kernel<__bf16, true><<<grid, 256, 0, st>>>(g);
+        else       gemm16_kernel<__bf16, false><<<grid, 256, 0, st>>>(g);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,56 +1,82 @@
-// layernorm.hip -- nn.LayerNorm over the last axis (eps inside the sqrt, biased variance), fp32, one wave per row.
-// HBM-bound: a row (<= 4 KiB at C <= 1024) lives in registers between the statistics and the normalise pass, so each
-// element is read once and written once.  Mean and variance are two-pass (sum, then sum of squared deviations), the
-// same formulation as the reference's nn.LayerNorm (ViT.py:111-114, cswin.py:139,174, xcit.py:271-283, mlp_mixer.py:39-41).
+// layernorm.hip -- nn.LayerNorm over the last axis (eps inside the sqrt, biased variance), fp32 math.
+// HBM-bound: a row lives in registers between the statistics and the normalise pass, so each element is read once and
+// written once.  LPR lanes cooperate on one row (16 / 32 / 64, so that narrow rows -- C = 64 in CSWin stage 1 -- still
+// fill the wave with 4 / 2 rows), NV float4 per lane.  Mean and variance are two-pass (sum, then sum of squared
+// deviations), the formulation of the reference's nn.LayerNorm (ViT.py:111-114, cswin.py:139,174, xcit.py:271-283,
+// mlp_mixer.py:39-41).  The output is fp32, or directly the 16-bit MFMA operand format of the GEMM that consumes it.
 #include "common.h"
+#include "mma.h"
+#include <type_traits>
 
 namespace {
 using v4f = float __attribute__((ext_vector_type(4)));
 
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ b, float* __restrict__ y, long rows,
-                                                           int cols, float eps) {
-    const int lane = threadIdx.x & 63;
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+template <typename OT>
+__device__ __forceinline__ void store4(OT* p, v4f v) {
+    if constexpr (std::is_same<OT, float>::value) {
+        *reinterpret_cast<v4f*>(p) = v;
+    } else {
+        typedef OT o4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<o4*>(p) = o4{(OT)v.x, (OT)v.y, (OT)v.z, (OT)v.w};
+    }
+}
+
+template <int LPR, int NV, typename OT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, OT* __restrict__ y, long rows, int cols,
+                                                       float eps) {
+    constexpr int RPW = 64 / LPR;                       // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const int n4 = cols >> 2;
     const float inv = 1.0f / (float)cols;
-    for (long row = wave0; row < rows; row += nwaves) {
-        const v4f* xr = reinterpret_cast<const v4f*>(x + row * cols);
+    for (long r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+        const long row = r0 + rsel;
+        const bool rok = row < rows;
+        const v4f* xr = reinterpret_cast<const v4f*>(x + (rok ? row : 0) * cols);
         v4f v[NV];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            v[j] = (i < n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
+            const int i = sub + LPR * j;
+            v[j] = (rok && i < n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
-        const float mean = wave_sum(s) * inv;
+        const float mean = group_sum<LPR>(s) * inv;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
+            const int i = sub + LPR * j;
             if (i < n4) {
                 const v4f d = v[j] - mean;
                 q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv + eps);
-        v4f* yr = reinterpret_cast<v4f*>(y + row * cols);
+        const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) * inv + eps);
+        if (!rok) continue;
+        OT* yr = y + row * cols;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
+            const int i = sub + LPR * j;
             if (i < n4) {
                 const v4f ww = reinterpret_cast<const v4f*>(w)[i], bb = reinterpret_cast<const v4f*>(b)[i];
-                yr[i] = (v[j] - mean) * rstd * ww + bb;
+                store4<OT>(yr + 4 * i, (v[j] - mean) * rstd * ww + bb);
             }
         }
     }
 }
 
 // any width / alignment: three sweeps over the (cache-resident) row
+template <typename OT>
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               const float* __restrict__ b, float* __restrict__ y, long rows,
+                                                               const float* __restrict__ b, OT* __restrict__ y, long rows,
                                                                int cols, float eps) {
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -62,22 +88,53 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         float q = 0.f;
         for (int i = lane; i < cols; i += 64) { const float d = xr[i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
-        for (int i = lane; i < cols; i += 64) y[row * cols + i] = (xr[i] - mean) * rstd * w[i] + b[i];
+        for (int i = lane; i < cols; i += 64) y[row * cols + i] = (OT)((xr[i] - mean) * rstd * w[i] + b[i]);
     }
+}
+
+template <typename OT>
+int launch_ln(const float* x, const float* weight, const float* bias, OT* y, int rows, int cols, float eps, hipStream_t st) {
+    const bool vec = (cols % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) && aligned16(bias);
+#define LN(LPR_, NV_)                                                                                                \
+    do {                                                                                                             \
+        const long waves = ((long)rows + (64 / LPR_) - 1) / (64 / LPR_);                                            \
+        const int grid = (int)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);                                    \
+        layernorm_kernel<LPR_, NV_, OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);                \
+    } while (0)
+    if (vec && cols <= 64)        LN(16, 1);
+    else if (vec && cols <= 128)  LN(32, 1);
+    else if (vec && cols <= 256)  LN(64, 1);
+    else if (vec && cols <= 512)  LN(64, 2);
+    else if (vec && cols <= 1024) LN(64, 4);
+    else if (vec && cols <= 2048) LN(64, 8);
+    else {
+        const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
+        layernorm_generic_kernel<OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
+    }
+#undef LN
+    return MI355_OK;
 }
 }  // namespace
 
-extern "C" int mi355_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, int rows, int cols, float eps,
-                                   mi355_stream_t stream) {
+extern "C" {
+
+int mi355_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, int rows, int cols, float eps,
+                        mi355_stream_t stream) {
     MI355_CHECK_ARG(x && weight && bias && y && rows > 0 && cols > 0);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
-    const bool vec = (cols % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) && aligned16(bias);
-    if (vec && cols <= 256)       layernorm_reg_kernel<1><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
-    else if (vec && cols <= 512)  layernorm_reg_kernel<2><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
-    else if (vec && cols <= 1024) layernorm_reg_kernel<4><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
-    else if (vec && cols <= 2048) layernorm_reg_kernel<8><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
-    else                          layernorm_generic_kernel<<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
+    launch_ln<float>(x, weight, bias, y, rows, cols, eps, static_cast<hipStream_t>(stream));
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
+
+int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias, void* y16, int rows, int cols, float eps,
+                          int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && bias && y16 && rows > 0 && cols > 0);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == MI355_PREC_FP16) launch_ln<_Float16>(x, weight, bias, static_cast<_Float16*>(y16), rows, cols, eps, st);
+    else                              launch_ln<__bf16>(x, weight, bias, static_cast<__bf16*>(y16), rows, cols, eps, st);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+}  // extern "C"

@@ -169,6 +169,103 @@ def layernorm(x, weight, bias, eps=1e-5):
     return y
 
 
+# ---- 16-bit activation dataflow (fast path of the composite blocks) -----------------------------------------------
+def dtype16(precision):
+    p = _prec(precision)
+    if p == PREC_FP16:
+        return torch.float16
+    if p == PREC_BF16:
+        return torch.bfloat16
+    raise ValueError("the 16-bit dataflow exists for precision 1 (fp16) and 2 (bf16) only")
+
+
+def fast_gemm_ok(K, N):
+    """Shape envelope of mi355_linear16_fwd (K-step 64, float4 epilogue)."""
+    return K % 64 == 0 and N % 4 == 0
+
+
+def _require16(t, name, precision):
+    want = dtype16(precision)
+    if not t.is_cuda or t.dtype != want:
+        raise TypeError(f"{name}: expected a {want} device tensor, got {t.dtype} on {t.device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def cast16(x, precision=None):
+    """fp32 -> MFMA operand format (round-to-nearest-even), same shape."""
+    x = require_device_f32(x, "x")
+    y = torch.empty(x.shape, dtype=dtype16(precision), device=x.device)
+    check(lib().mi355_cast16_fwd(dptr(x), dptr(y), x.numel(), _prec(precision), stream_ptr(x.device)), "mi355_cast16_fwd")
+    return y
+
+
+_w16_cache = {}
+
+
+def weight16(param, precision=None):
+    """16-bit copy of a weight, converted once and reused until the parameter is modified (in-place version bump),
+    moved or re-precisioned."""
+    p = _prec(precision)
+    key = id(param)
+    tag = (param._version, param.data_ptr(), p, tuple(param.shape))
+    hit = _w16_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w16 = cast16(param.detach(), p)
+    _w16_cache[key] = (tag, w16)
+    return w16
+
+
+def layernorm16(x, weight, bias, eps=1e-5, precision=None):
+    x = require_device_f32(x, "x")
+    weight = require_device_f32(weight, "weight")
+    bias = require_device_f32(bias, "bias")
+    cols = x.shape[-1]
+    y = torch.empty(x.shape, dtype=dtype16(precision), device=x.device)
+    check(lib().mi355_layernorm16_fwd(dptr(x), dptr(weight), dptr(bias), dptr(y), x.numel() // cols, cols, float(eps),
+                                      _prec(precision), stream_ptr(x.device)), "mi355_layernorm16_fwd")
+    return y
+
+
+def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=False, precision=None):
+    """Y = resid + gamma * act(x16 @ w16^T + bias); 16-bit operands, fp32 or 16-bit result."""
+    x16 = _require16(x16, "x16", precision)
+    w16 = _require16(w16, "w16", precision)
+    bias, gamma, resid = _opt(bias, "bias"), _opt(gamma, "gamma"), _opt(resid, "resid")
+    N, K = w16.shape
+    if x16.shape[-1] != K:
+        raise ValueError(f"linear16: x last dim {x16.shape[-1]} != weight in_features {K}")
+    M = x16.numel() // K
+    if resid is not None and resid.numel() != M * N:
+        raise ValueError("linear16: residual shape mismatch")
+    y = torch.empty(*x16.shape[:-1], N, dtype=dtype16(precision) if out16 else torch.float32, device=x16.device)
+    check(lib().mi355_linear16_fwd(dptr(x16), dptr(w16), dptr(bias), dptr(gamma), dptr(resid), dptr(y), M, N, K, K, N, act,
+                                   1 if out16 else 0, _prec(precision), stream_ptr(x16.device)), "mi355_linear16_fwd")
+    return y
+
+
+def sdpa16(qkv16, num_heads, scale, precision=None):
+    qkv16 = _require16(qkv16, "qkv16", precision)
+    B, N, C3 = qkv16.shape
+    C = C3 // 3
+    out = torch.empty(B, N, C, dtype=qkv16.dtype, device=qkv16.device)
+    check(lib().mi355_sdpa16_fwd(dptr(qkv16), dptr(out), B, N, num_heads, C // num_heads, float(scale), _prec(precision),
+                                 stream_ptr(qkv16.device)), "mi355_sdpa16_fwd")
+    return out
+
+
+def cswin_lepe_attention16(qkv16, getv_w, getv_b, out16, reso, c0, Cb, heads, Hsp, Wsp, scale, precision=None):
+    qkv16 = _require16(qkv16, "qkv16", precision)
+    getv_w = require_device_f32(getv_w, "get_v.weight")
+    getv_b = require_device_f32(getv_b, "get_v.bias")
+    B = qkv16.shape[0]
+    Ctot = qkv16.shape[-1] // 3
+    check(lib().mi355_cswin_lepe_attn16_fwd(dptr(qkv16), dptr(getv_w), dptr(getv_b), dptr(out16), B, reso, Ctot, c0, Cb, heads,
+                                            Hsp, Wsp, float(scale), _prec(precision), stream_ptr(qkv16.device)),
+          "mi355_cswin_lepe_attn16_fwd")
+    return out16
+
+
 # ---- attention cores ----------------------------------------------------------------------------------------
 def sdpa(qkv, num_heads, scale, precision=None):
     """qkv (B,N,3*C) straight from the qkv Linear -> (B,N,C) = concat_heads(softmax(QK^T*scale) V)."""

@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
+from .vit import _fast, _mlp16
 
 
 def _stripe(resolution, idx, split_size):
@@ -33,6 +34,8 @@ class Mlp(nn.Module):
         self.precision = None
 
     def forward(self, x, resid=None):
+        if _fast(self.precision, self.fc1, self.fc2):
+            return _mlp16(x, self.fc1, self.fc2, self.precision, second_gelu=False, resid=resid)
         h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
         return F.linear(h, self.fc2.weight, self.fc2.bias, resid=resid, precision=self.precision)
 
@@ -49,9 +52,11 @@ class LePEAttention(nn.Module):
         self.precision = precision
 
     def run(self, qkv_blc, out, c0):
-        """Attend over channels [c0, c0+dim) of a (B,L,3,Ctot) buffer, writing the same slice of `out` (B,L,Ctot)."""
-        return F.cswin_lepe_attention(qkv_blc, self.get_v.weight, self.get_v.bias, out, self.resolution, c0, self.dim,
-                                      self.num_heads, self.H_sp, self.W_sp, self.scale, self.precision)
+        """Attend over channels [c0, c0+dim) of a (B,L,3,Ctot) buffer, writing the same slice of `out` (B,L,Ctot).
+        fp32 buffers use the converting kernel, 16-bit buffers the 16-bit-I/O kernel."""
+        fn = F.cswin_lepe_attention if qkv_blc.dtype == torch.float32 else F.cswin_lepe_attention16
+        return fn(qkv_blc, self.get_v.weight, self.get_v.bias, out, self.resolution, c0, self.dim, self.num_heads, self.H_sp,
+                  self.W_sp, self.scale, self.precision)
 
     def forward(self, qkv):
         """qkv: (3,B,L,C) as in the reference (cswin.py:101-105); returns (B,L,C)."""
@@ -88,14 +93,25 @@ class CSWinBlock(nn.Module):
     def forward(self, x):
         B, L, C = x.shape
         assert L == self.patches_resolution ** 2, "flatten img_tokens has wrong size"
-        u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = F.linear(u, self.qkv.weight, self.qkv.bias, precision=self.precision)        # (B,L,3C) == (B,L,3,C)
-        att = torch.empty(B, L, C, dtype=torch.float32, device=x.device)
+        p = F._prec(self.precision)
+        fast = _fast(p, self.qkv, self.proj, self.mlp.fc1, self.mlp.fc2) and self.attns[0].dim // self.attns[0].num_heads == 32
+        if fast:                     # LN -> qkv -> attention -> proj with every GEMM operand kept 16-bit in HBM
+            u = F.layernorm16(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
+            qkv = F.linear16(u, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
+            att = torch.empty(B, L, C, dtype=qkv.dtype, device=x.device)
+        else:
+            u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            qkv = F.linear(u, self.qkv.weight, self.qkv.bias, precision=self.precision)    # (B,L,3C) == (B,L,3,C)
+            att = torch.empty(B, L, C, dtype=torch.float32, device=x.device)
         if self.branch_num == 2:
             self.attns[0].run(qkv, att, 0)
             self.attns[1].run(qkv, att, C // 2)
         else:
             self.attns[0].run(qkv, att, 0)
-        x = F.linear(att, self.proj.weight, self.proj.bias, resid=x, precision=self.precision)
-        u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        if fast:
+            x = F.linear16(att, F.weight16(self.proj.weight, p), self.proj.bias, resid=x, precision=p)
+            u = F.layernorm16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
+        else:
+            x = F.linear(att, self.proj.weight, self.proj.bias, resid=x, precision=self.precision)
+            u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp(u, resid=x)

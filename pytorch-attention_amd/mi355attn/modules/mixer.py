@@ -6,6 +6,7 @@ Token mixing is a LEFT multiplication of each image's (N x C) matrix, so the ref
 from torch import nn
 
 from .. import functional as F
+from .vit import _fast, _mlp16
 
 
 class Mlp(nn.Module):
@@ -16,6 +17,8 @@ class Mlp(nn.Module):
         self.precision = None
 
     def forward(self, x, resid=None):
+        if _fast(self.precision, self.fc1, self.fc2):
+            return _mlp16(x, self.fc1, self.fc2, self.precision, second_gelu=False, resid=resid)
         h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
         return F.linear(h, self.fc2.weight, self.fc2.bias, resid=resid, precision=self.precision)
 
@@ -35,5 +38,9 @@ class MixerLayer(nn.Module):
         u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         hid = F.token_mix(t.fc1.weight, u, t.fc1.bias, act=F.ACT_GELU, precision=self.precision)     # (B,T,C)
         x = F.token_mix(t.fc2.weight, hid, t.fc2.bias, resid=x, precision=self.precision)            # (B,N,C)
-        u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.channel_mlp(u, resid=x)
+        c = self.channel_mlp
+        if _fast(self.precision, c.fc1, c.fc2):
+            u = F.layernorm16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, F._prec(self.precision))
+        else:
+            u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return c(u, resid=x)

@@ -19,6 +19,20 @@ def _bias(lin):
     return lin.bias if lin.bias is not None else None
 
 
+def _fast(precision, *linears):
+    """True when the 16-bit dataflow applies: a 16-bit operand mode and every GEMM inside the fast kernel's envelope."""
+    return F._prec(precision) != F.PREC_STRICT and all(F.fast_gemm_ok(l.in_features, l.out_features) for l in linears)
+
+
+def _mlp16(x, fc1, fc2, precision, second_gelu, gamma=None, resid=None):
+    """fc1 -> GELU -> fc2 (-> GELU) with the hidden activation kept in the MFMA operand format; x is fp32 or 16-bit."""
+    p = F._prec(precision)
+    x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
+    h16 = F.linear16(x16, F.weight16(fc1.weight, p), fc1.bias, act=F.ACT_GELU, out16=True, precision=p)
+    return F.linear16(h16, F.weight16(fc2.weight, p), fc2.bias, act=F.ACT_GELU if second_gelu else F.ACT_NONE, gamma=gamma,
+                      resid=resid, precision=p)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, drop=0):
         super().__init__()
@@ -28,6 +42,8 @@ class Mlp(nn.Module):
         self.drop = drop                     # inference engine: dropout is the identity (eval semantics)
 
     def forward(self, x, resid=None):
+        if _fast(self.precision, self.fc1, self.fc2):
+            return _mlp16(x, self.fc1, self.fc2, self.precision, second_gelu=True, resid=resid)
         h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
         return F.linear(h, self.fc2.weight, self.fc2.bias, act=F.ACT_GELU, resid=resid, precision=self.precision)
 
@@ -43,7 +59,18 @@ class Attention(nn.Module):
         self.precision = precision
         self.attn_drop, self.proj_drop = attn_drop, proj_drop   # identity at inference
 
+    def fast_ok(self, n_tokens):
+        """16-bit dataflow applies: 16-bit operand mode, GEMM shapes in the fast envelope, core kernel built for (d, N)."""
+        d = self.qkv.in_features // self.num_heads
+        return _fast(self.precision, self.qkv, self.proj) and d in (32, 64) and n_tokens <= 224
+
     def forward(self, x, resid=None):
+        if self.fast_ok(x.shape[1]):
+            p = F._prec(self.precision)                                                     # q/k/v/ctx stay 16-bit in HBM
+            x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
+            qkv16 = F.linear16(x16, F.weight16(self.qkv.weight, p), _bias(self.qkv), out16=True, precision=p)
+            ctx16 = F.sdpa16(qkv16, self.num_heads, self.scale, precision=p)
+            return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, resid=resid, precision=p)
         qkv = F.linear(x, self.qkv.weight, _bias(self.qkv), precision=self.precision)      # (B,N,3C)
         ctx = F.sdpa(qkv, self.num_heads, self.scale, precision=self.precision)             # (B,N,C)
         return F.linear(ctx, self.proj.weight, self.proj.bias, resid=resid, precision=self.precision)
@@ -77,11 +104,15 @@ class TransformerEncoder(nn.Module):
         self.mlp.precision = precision
         self.layernorm2 = nn.LayerNorm(dim)
 
+    def _norm(self, ln, x, fast):
+        if fast:                     # LayerNorm writes the GEMM's operand format directly
+            return F.layernorm16(x, ln.weight, ln.bias, ln.eps, F._prec(self.attn.precision))
+        return F.layernorm(x, ln.weight, ln.bias, ln.eps)
+
     def forward(self, x):
-        u = F.layernorm(x, self.layernorm1.weight, self.layernorm1.bias, self.layernorm1.eps)
-        x = self.attn(u, resid=x)
-        u = F.layernorm(x, self.layernorm2.weight, self.layernorm2.bias, self.layernorm2.eps)
-        return self.mlp(u, resid=x)
+        fast = self.attn.fast_ok(x.shape[1]) and _fast(self.attn.precision, self.mlp.fc1, self.mlp.fc2)
+        x = self.attn(self._norm(self.layernorm1, x, fast), resid=x)
+        return self.mlp(self._norm(self.layernorm2, x, fast), resid=x)
 
 
 class VisionTransformer(nn.Module):

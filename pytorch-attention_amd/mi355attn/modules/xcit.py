@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
+from .vit import _fast, _mlp16
 
 
 class Mlp(nn.Module):
@@ -22,6 +23,8 @@ class Mlp(nn.Module):
         self.precision = None
 
     def forward(self, x, gamma=None, resid=None):
+        if self.fc1.bias is not None and _fast(self.precision, self.fc1, self.fc2):
+            return _mlp16(x, self.fc1, self.fc2, self.precision, second_gelu=False, gamma=gamma, resid=resid)
         h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
         return F.linear(h, self.fc2.weight, self.fc2.bias, gamma=gamma, resid=resid, precision=self.precision)
 
@@ -52,6 +55,13 @@ class XCA(nn.Module):
         self.precision = precision
 
     def forward(self, x, gamma=None, resid=None):
+        if _fast(self.precision, self.qkv, self.proj):
+            p = F._prec(self.precision)      # GEMMs on 16-bit operands; the d x d covariance core itself is exact fp32
+            x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
+            qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, precision=p)
+            ctx = F.xca_core(qkv, self.temperature, self.num_heads, precision=p)
+            return F.linear16(F.cast16(ctx, p), F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid,
+                              precision=p)
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias, precision=self.precision)
         ctx = F.xca_core(qkv, self.temperature, self.num_heads, precision=self.precision)
         return F.linear(ctx, self.proj.weight, self.proj.bias, gamma=gamma, resid=resid, precision=self.precision)
@@ -77,9 +87,14 @@ class XCABlock(nn.Module):
         self.gamma3 = nn.Parameter(eta * torch.ones(dim), requires_grad=True)
 
     def forward(self, x, H, W):
-        u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn(u, gamma=self.gamma1, resid=x)
-        u = F.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        x = self.local_mp(u, H, W, gamma=self.gamma3, resid=x)
-        u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.mlp(u, gamma=self.gamma2, resid=x)
+        p = F._prec(self.attn.precision)
+        fast = _fast(p, self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
+
+        def norm(ln, t, to16):
+            if to16:
+                return F.layernorm16(t, ln.weight, ln.bias, ln.eps, p)
+            return F.layernorm(t, ln.weight, ln.bias, ln.eps)
+
+        x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
+        x = self.local_mp(norm(self.norm3, x, False), H, W, gamma=self.gamma3, resid=x)
+        return self.mlp(norm(self.norm2, x, fast), gamma=self.gamma2, resid=x)

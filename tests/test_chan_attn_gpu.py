@@ -60,11 +60,15 @@ def test_chunk_option_does_not_change_results():
     torch.manual_seed(9)
     x = torch.randn(13, 64, 28, 28).cuda()
     outs = []
-    for chunk in (0, 1, 5, 13):
+    old = {k: mi355attn.get_option(k) for k in ("chunk_images", "nt", "reverse")}
+    for chunk, nt, rev in ((0, 3, 0), (1, 0, 0), (5, 1, 1), (13, 2, 1), (4, 3, 1)):
         mi355attn.set_option("chunk_images", chunk)
+        mi355attn.set_option("nt", nt)
+        mi355attn.set_option("reverse", rev)
         with torch.no_grad():
             outs.append((se.cuda()(x).clone(), eca.cuda()(x).clone(), cbam.cuda()(x).clone()))
-    mi355attn.set_option("chunk_images", 0)
+    for k, v in old.items():
+        mi355attn.set_option(k, v)
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)

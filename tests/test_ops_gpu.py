@@ -284,3 +284,70 @@ def test_double_attention(B, C, cm, cn, H, W, prec):
     with torch.no_grad():
         y = m.cuda()(x.cuda()).cpu()
     assert_parity(y, ref.float(), TOL[prec], f"double_attention p{prec}")
+
+
+# ---------------------------------------------------------------------------------------------- 16-bit activation dataflow
+@pytest.mark.parametrize("prec,dt", [(1, torch.float16), (2, torch.bfloat16)])
+def test_cast16_is_round_to_nearest_even(prec, dt):
+    torch.manual_seed(0)
+    x = torch.cat([torch.randn(100003) * 3, torch.tensor([0.0, -0.0, 1e-8, 65504.0, 1e-5, 3.0e38 if prec == 2 else 6e4])]).cuda()
+    got = F().cast16(x, prec)
+    assert got.dtype == dt and torch.equal(got, x.to(dt))
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (130, 72, 64), (257, 132, 192), (64, 2304, 768), (50, 64, 256)])
+def test_linear16_bit_identical_to_fp32_entry(M, N, K, prec):
+    """Same rounding point, same accumulation order: the 16-bit-operand GEMM must reproduce mi355_linear_fwd exactly."""
+    torch.manual_seed(M + N + K)
+    f = F()
+    x, w, b = torch.randn(M, K).cuda(), (torch.randn(N, K) / math.sqrt(K)).cuda(), torch.randn(N).cuda()
+    gamma, resid = (torch.rand(N) + 0.5).cuda(), torch.randn(M, N).cuda()
+    x16, w16 = f.cast16(x, prec), f.cast16(w, prec)
+    ref = f.linear(x, w, b, precision=prec)
+    assert torch.equal(f.linear16(x16, w16, b, precision=prec), ref)
+    ref2 = f.linear(x, w, b, act=f.ACT_GELU, gamma=gamma, resid=resid, precision=prec)
+    assert torch.equal(f.linear16(x16, w16, b, act=f.ACT_GELU, gamma=gamma, resid=resid, precision=prec), ref2)
+    out16 = f.linear16(x16, w16, b, act=f.ACT_GELU, out16=True, precision=prec)
+    assert torch.equal(out16, f.linear(x, w, b, act=f.ACT_GELU, precision=prec).to(out16.dtype))
+
+
+def test_linear16_rejects_shapes_outside_the_envelope():
+    from mi355attn import Mi355Error
+    f = F()
+    x16, w16 = torch.randn(8, 96).cuda().half(), torch.randn(16, 96).cuda().half()       # K = 96 is not a multiple of 64
+    with pytest.raises(Mi355Error):
+        f.linear16(x16, w16, precision=1)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("rows,cols", [(300, 384), (1000, 768), (802, 64), (33, 128), (9, 52)])
+def test_layernorm16(rows, cols, prec):
+    torch.manual_seed(rows)
+    x, w, b = (torch.randn(rows, cols) * 2 + 0.5).cuda(), torch.randn(cols).cuda(), torch.randn(cols).cuda()
+    y32 = F().layernorm(x, w, b, 1e-5)
+    y16 = F().layernorm16(x, w, b, 1e-5, prec)
+    assert torch.equal(y16, y32.to(y16.dtype))
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,N,h,d", [(2, 197, 12, 64), (3, 64, 4, 32), (1, 130, 2, 64)])
+def test_sdpa16_matches_fp32_io_kernel(B, N, h, d, prec):
+    torch.manual_seed(N)
+    f = F()
+    qkv16 = f.cast16(torch.randn(B, N, 3 * h * d).cuda(), prec)
+    ref = f.sdpa(qkv16.float(), h, d ** -0.5, precision=prec)
+    got = f.sdpa16(qkv16, h, d ** -0.5, precision=prec)
+    assert torch.equal(got, ref.to(got.dtype))
+
+
+def test_weight16_cache_tracks_inplace_updates():
+    f = F()
+    w = torch.nn.Parameter(torch.randn(8, 64).cuda())
+    a = f.weight16(w, 1)
+    assert f.weight16(w, 1) is a                         # cached
+    with torch.no_grad():
+        w.mul_(2.0)                                      # version bump -> re-converted
+    b = f.weight16(w, 1)
+    assert b is not a and torch.equal(b, w.detach().half())
+    assert f.weight16(w, 2).dtype == torch.bfloat16
