@@ -54,7 +54,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "chunk_images"  images per pool->scale chunk (0 = auto: ~200 MB of x per chunk so that a chunk's re-read is served
  *                   by the 256 MiB Infinity Cache -- default; a value >= B disables chunking);
  *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 3);
- *   "reverse"       1 = the final pass walks the batch backwards (most recently touched rows first), default 0.
+ *   "reverse"       1 = the final pass walks the batch backwards (most recently touched rows first), default 0;
+ *   "fused"         0 = two streaming passes (default); 1 = experimental single-pass register-resident SE/ECA kernel for
+ *                   large shapes (x read once; measured slower on MI355X -- inter-workgroup hand-off latency),
+ *                   2 = single pass whenever the shape is supported, regardless of size (tests).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
 long        mi355_get_option(const char* key);

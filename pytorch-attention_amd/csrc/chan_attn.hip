@@ -445,8 +445,10 @@ inline Tune resolve_tune(int B, long bytes_per_image) {
 // ===================================================================================================
 extern "C" {
 
-size_t mi355_se_workspace_bytes(int B, int C, int, int) { return (size_t)B * C * sizeof(float); }
-size_t mi355_eca_workspace_bytes(int B, int C, int, int) { return (size_t)B * C * sizeof(float); }
+// workspace: pooled means [B*C] (rounded to 16 B) | single-pass sync state (arrive[B], ticket, err)
+static inline size_t pooled_bytes(int B, int C) { return (((size_t)B * C * sizeof(float)) + 15) & ~(size_t)15; }
+size_t mi355_se_workspace_bytes(int B, int C, int, int) { return pooled_bytes(B, C) + mi355::fused_state_bytes(B); }
+size_t mi355_eca_workspace_bytes(int B, int C, int, int) { return pooled_bytes(B, C) + mi355::fused_state_bytes(B); }
 
 static int se_eca_common(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr,
                          int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -456,6 +458,8 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     const int groups = cdiv(C, RPB);
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
+    if (vec && mi355::opt_fused() && mi355::fused_applicable(B, C, H, W))      // x read once, y written once
+        return mi355::se_eca_fused(mode, x, wa, wb, y, B, C, Cr, H, W, pooled, static_cast<char*>(ws) + pooled_bytes(B, C), st);
     const Tune tu = resolve_tune(B, (long)C * HW * 4);
     for (int b0 = 0; b0 < B; b0 += tu.chunk) {
         const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;

@@ -16,6 +16,11 @@ int   fail(int code, const char* fmt, ...);
 long  opt_chunk_images();
 long  opt_nt();
 long  opt_reverse();
+long  opt_fused();
+size_t fused_state_bytes(int B);
+bool  fused_applicable(int B, int C, int H, int W);
+int   se_eca_fused(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr, int H, int W,
+                   float* means, void* state, hipStream_t st);
 // GEMM engine (gemm.hip), shared by the other translation units.  NT: B is (N,K) K-contiguous; KN: B is (K,N) N-contiguous.
 int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
             int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st);

@@ -38,6 +38,19 @@ def _opt(t, name):
 
 
 # ---- channel / spatial attention -------------------------------------------------------------------------
+def _check_sync_state(ws, B, C, what):
+    """Debug aid (MI355_CHECK_SYNC=1): the single-pass SE/ECA kernel bounds its inter-workgroup spins and raises an error
+    word in the workspace instead of hanging; reading it costs a device sync, so it is off by default."""
+    import os
+    if os.environ.get("MI355_CHECK_SYNC") != "1":
+        return
+    torch.cuda.synchronize()
+    off = ((B * C * 4 + 15) // 16) * 16 + (B + 1) * 4
+    err = int(ws[off:off + 4].view(torch.int32).item())
+    if err:
+        raise _ffi.Mi355Error(f"{what}: inter-workgroup wait timed out (error word {err})")
+
+
 def se_forward(x, w1, w2):
     """SELayer forward: x (B,C,H,W), w1 (C/r,C), w2 (C,C/r)."""
     x = require_device_f32(x, "x")
@@ -52,6 +65,7 @@ def se_forward(x, w1, w2):
     ws = workspace(n, x.device)
     check(lib().mi355_se_fwd(dptr(x), dptr(w1), dptr(w2), dptr(y), B, C, Cr, H, W, dptr(ws), ws.numel(),
                              stream_ptr(x.device)), "mi355_se_fwd")
+    _check_sync_state(ws, B, C, "mi355_se_fwd")
     return y
 
 
@@ -66,6 +80,7 @@ def eca_forward(x, wconv):
     ws = workspace(n, x.device)
     check(lib().mi355_eca_fwd(dptr(x), dptr(wconv), dptr(y), B, C, k, H, W, dptr(ws), ws.numel(),
                               stream_ptr(x.device)), "mi355_eca_fwd")
+    _check_sync_state(ws, B, C, "mi355_eca_fwd")
     return y
 
 
