@@ -58,6 +58,7 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "fused"         0 = two streaming passes (default); 1 = experimental single-pass register-resident SE/ECA kernel for
  *                   large shapes (x read once; measured slower on MI355X -- inter-workgroup hand-off latency),
  *                   2 = single pass whenever the shape is supported, regardless of size (tests).
+ *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
 long        mi355_get_option(const char* key);

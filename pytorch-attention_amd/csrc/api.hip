@@ -8,6 +8,7 @@ static thread_local char g_err[512] = "";
 static std::atomic<long> g_chunk_images{0};   // 0 = auto (about 200 MB of x per chunk)
 static std::atomic<long> g_nt{3};        // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
 static std::atomic<long> g_reverse{0};
+static std::atomic<long> g_gemm_variant{0};   // tile/schedule variant of the 16-bit GEMM (gemm16.hip)
 static std::atomic<long> g_fused{0};     // experimental single-pass SE/ECA kernel (measured 4x slower than two passes: DESIGN.md 6.1)
 
 char* err_buf() { return g_err; }
@@ -23,6 +24,7 @@ long opt_chunk_images() { return g_chunk_images.load(std::memory_order_relaxed);
 long opt_nt() { return g_nt.load(std::memory_order_relaxed); }
 long opt_reverse() { return g_reverse.load(std::memory_order_relaxed); }
 long opt_fused() { return g_fused.load(std::memory_order_relaxed); }
+long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
 struct mi355_timer {
@@ -46,6 +48,11 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_nt.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "gemm_variant") == 0) {
+        MI355_CHECK_ARG(value >= 0 && value <= 9);
+        mi355::g_gemm_variant.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "fused") == 0) {
         MI355_CHECK_ARG(value >= 0 && value <= 2);
         mi355::g_fused.store(value, std::memory_order_relaxed);
@@ -64,6 +71,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "nt") == 0) return mi355::opt_nt();
     if (key && std::strcmp(key, "reverse") == 0) return mi355::opt_reverse();
     if (key && std::strcmp(key, "fused") == 0) return mi355::opt_fused();
+    if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
     return -1;
 }

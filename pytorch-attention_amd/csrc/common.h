@@ -17,6 +17,7 @@ long  opt_chunk_images();
 long  opt_nt();
 long  opt_reverse();
 long  opt_fused();
+long  opt_gemm_variant();
 size_t fused_state_bytes(int B);
 bool  fused_applicable(int B, int C, int H, int W);
 int   se_eca_fused(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr, int H, int W,
@@ -66,6 +67,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
-// exact-erf GELU (nn.GELU() default)
+// exact-erf GELU (nn.GELU() default), library erff: used off the hot path (LPI)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-form GELU for the GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level) on the
+// v_rcp_f32 / v_exp_f32 units -- ~15 instructions instead of ~40 for erff, which matters because the epilogue is not
+// overlapped with MFMA work (profiles: the erff epilogue cost more than the 768-deep MFMA loop of the fc1 GEMM).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);
+    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
+    return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, z));
+}
 #endif

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 float z = vv[c];
                 if (g.bias) z += g.bias_per_row ? g.bias[m] : g.bias[n + c];
                 if constexpr (AMODE == 1) z += g.pos[(long)(m % g.P) * g.N + n + c];
-                if (g.act == MI355_ACT_GELU) z = gelu_erf(z);
+                if (g.act == MI355_ACT_GELU) z = gelu_fast(z);
                 if (g.gamma) z *= g.gamma[n + c];
                 if (Rb) z += Rb[orow * g.ldc + n + c];
                 vv[c] = z;

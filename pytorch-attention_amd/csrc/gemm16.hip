@@ -8,17 +8,16 @@
 // with `global_load_lds` (16 B per lane, no VGPR round trip).  The rounding point is unchanged (operands are rounded to 16 bit
 // exactly once, accumulate and epilogue stay fp32), so results are bit-identical to gemm.hip in the same precision mode.
 //
-// Tile 128 x 128 x 64, 256 threads (4 waves, 2 x 2, 64 x 64 per wave).  LDS rows are 128 B (64 elements) and UNPADDED because
+// Tile BM x BN x 64 (default 128 x 256, 8 waves of 64 x 64; variants in the launcher).  LDS rows are 128 B and UNPADDED because
 // the DMA writes lane-linear; bank conflicts of the fragment reads are removed by an XOR swizzle applied on the SOURCE address
-// (chunk ^= row & 7) and again on the ds_read (cdna_hip_programming.md rule 21).  Two stages, one barrier per K-step.
+// (chunk ^= row & 7) and again on the ds_read (cdna_hip_programming.md rule 21).  One LDS buffer + two barriers per K-step and
+// three resident workgroups per CU (24 waves) measured faster than double buffering at two workgroups per CU.
 #include "common.h"
 #include "mma.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE = (BM + BN) * BK;          // elements per stage
-constexpr int EPITCH = 68;
+constexpr int BK = 64;
 
 struct G16Args {
     const void* A; const void* B; void* C;
@@ -38,18 +37,25 @@ __device__ __forceinline__ f4 mma16<_Float16>(h8 a, h8 b, f4 c) { return __built
 template <>
 __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-template <typename T, bool OUT16>
-__global__ __launch_bounds__(256, 2) void gemm16_kernel(const G16Args g) {
+// Tile BM x BN x 64 per workgroup of WM x WN waves; each wave owns a (BM/WM) x (BN/WN) sub-tile = MF x NF MFMA 16x16 tiles.
+template <typename T, bool OUT16, int BM, int BN, int WM, int WN, bool PRIO, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
-    constexpr int STAGE_BYTES = 2 * STAGE * 2;
-    constexpr int EPI_BYTES = 4 * 32 * EPITCH * 4;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MF = TM / 16, NF = TN / 16;
+    constexpr int STAGE = (BM + BN) * BK;                       // elements per stage
+    constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;           // LDS-DMA instructions per wave per stage (8 rows each)
+    constexpr int EP = TN + 4;                                  // epilogue slab pitch (floats)
+    constexpr int STAGE_BYTES = STAGES * STAGE * 2;
+    constexpr int EPI_BYTES = NW * 32 * EP * 4;
     constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 32 == 0 && TN % 16 == 0, "tile/wave geometry");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     T* lds = reinterpret_cast<T*>(lds_raw);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int tiles_n = (g.N + BN - 1) / BN;
     int wg;
     {
@@ -60,88 +66,108 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const G16Args g) {
     const T* __restrict__ A = static_cast<const T*>(g.A);
     const T* __restrict__ B = static_cast<const T*>(g.B);
 
-    // ---- LDS-DMA source pointers: this wave fills rows [wave*32, wave*32+32) of the A and of the B tile, 8 rows per instruction;
-    //      lane -> (row = lane >> 3, physical chunk = lane & 7) holds logical chunk (lane & 7) ^ (row & 7) ------------------------
+    // ---- LDS-DMA source pointers: each instruction fills 8 rows of 128 B; lane -> (row = lane >> 3, physical chunk = lane & 7)
+    //      holds logical chunk (lane & 7) ^ (row & 7) ----------------------------------------------------------------------------
     const int lrow = lane >> 3, pch = lane & 7;
-    const T* a_src[4];
-    const T* b_src[4];
+    const int csw = (pch ^ lrow) * 8;                           // row & 7 == lrow: every 8-row group starts at a multiple of 8
+    const T* a_src[IA];
+    const T* b_src[IB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + lrow;
-        const int c = (pch ^ (r & 7)) * 8;
-        int ma = m0 + r; if (ma >= g.M) ma = g.M - 1;          // clamp: tail rows/cols are computed on valid data and discarded
-        int nb = n0 + r; if (nb >= g.N) nb = g.N - 1;
-        a_src[i] = A + (long)ma * g.lda + c;
-        b_src[i] = B + (long)nb * g.ldb + c;
+    for (int i = 0; i < IA; ++i) {
+        int ma = m0 + (wave * IA + i) * 8 + lrow; if (ma >= g.M) ma = g.M - 1;   // clamp: tail rows are computed and discarded
+        a_src[i] = A + (long)ma * g.lda + csw;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        int nb = n0 + (wave * IB + i) * 8 + lrow; if (nb >= g.N) nb = g.N - 1;
+        b_src[i] = B + (long)nb * g.ldb + csw;
     }
     auto issue = [&](int stage, int k0) {
-        T* sA = lds + stage * STAGE + (wave * 32) * BK;
-        T* sB = sA + BM * BK;
+        T* sA = lds + stage * STAGE + (wave * IA * 8) * BK;
+        T* sB = lds + stage * STAGE + BM * BK + (wave * IB * 8) * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < IA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
                                              (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
                                              (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
-        }
     };
 
-    f4 acc[4][4];
+    f4 acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nk) issue(st ^ 1, (kt + 1) * BK);
-        const T* sA = lds + st * STAGE + (wr * 64 + frow) * BK;
-        const T* sB = lds + st * STAGE + BM * BK + (wc * 64 + frow) * BK;
+    auto compute = [&](int st) {
+        const T* sA = lds + st * STAGE + (wr * TM + frow) * BK;
+        const T* sB = lds + st * STAGE + BM * BK + (wc * TN + frow) * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = (((ks * 4 + fq) ^ fsw) * 8);
-            v8 fa[4], fb[4];
+            v8 fa[MF], fb[NF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off);
-                fb[i] = *reinterpret_cast<const v8*>(sB + i * 16 * BK + off);
-            }
+            for (int j = 0; j < NF; ++j) fb[j] = *reinterpret_cast<const v8*>(sB + j * 16 * BK + off);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MF; ++i) fa[i] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
+    };
+    if constexpr (STAGES == 2) {          // double-buffered: next tile's DMA in flight under this tile's MFMAs, one barrier per K-step
+        issue(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st = kt & 1;
+            if (kt + 1 < nk) issue(st ^ 1, (kt + 1) * BK);
+            compute(st);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {                               // single buffer, two barriers per K-step: half the LDS, twice the resident workgroups --
+        for (int kt = 0; kt < nk; ++kt) {  // load/compute overlap comes from the other workgroups on the CU
+            issue(0, kt * BK);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue (same structure as gemm.hip): per-wave LDS slab, row-contiguous stores ------------------------------------------
-    float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EPITCH;
+    // ---- epilogue: 32 rows at a time through a per-wave LDS slab (aliases the stage buffers: the loop's last barrier has
+    //      retired every read of them), row-contiguous stores; only wave-level ordering is needed from here on ---------------
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EP;
     float* Cf = static_cast<float*>(g.C);
     T* Ch = static_cast<T*>(g.C);
+    constexpr int LPR = TN / 4, RPI = 64 / LPR;                 // lanes per row, rows per store instruction
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < TM / 32; ++p) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    slab[(ii * 16 + (lane >> 4) * 4 + r) * EPITCH + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
-        __syncthreads();
+                    slab[(ii * 16 + (lane >> 4) * 4 + r) * EP + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
-            const int m = m0 + wr * 64 + p * 32 + rl, n = n0 + wc * 64 + cl;
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rl = it * RPI + lane / LPR, cl = (lane % LPR) * 4;
+            const int m = m0 + wr * TM + p * 32 + rl, n = n0 + wc * TN + cl;
             if (m >= g.M || n >= g.N) continue;                 // N % 4 == 0 is a launch precondition
-            f4 v = *reinterpret_cast<const f4*>(slab + rl * EPITCH + cl);
+            f4 v = *reinterpret_cast<const f4*>(slab + rl * EP + cl);
             if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
-            if (g.act == MI355_ACT_GELU) v = f4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+            if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
             if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
             if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
             if constexpr (OUT16) {
@@ -150,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const G16Args g) {
                 *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -195,15 +222,34 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     G16Args g{};
     g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.gamma = gamma; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
-    const int grid = cdiv(M, BM) * cdiv(N, BN);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    long variant = mi355::opt_gemm_variant();
+    if (variant == 0)          // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups
+        variant = (N <= 64) ? 9 : (N < 256 ? 1 : 7);   // per CU; narrow outputs use 256x64 / 128x128 tiles instead
+    else if (variant == 8) variant = 0;     // 8 = plain 128x128 without priority hints (tuning experiments)
+#define LAUNCH(T_, O_, BM_, BN_, WM_, WN_, P_, S_)                                                         \
+    gemm16_kernel<T_, O_, BM_, BN_, WM_, WN_, P_, S_><<<cdiv(M, BM_) * cdiv(N, BN_), WM_ * WN_ * 64, 0, st>>>(g)
+#define BY_VARIANT(T_, O_)                                                 \
+    do {                                                                   \
+        switch (variant) {                                                 \
+            case 1: LAUNCH(T_, O_, 128, 128, 2, 2, true, 2); break;        \
+            case 2: LAUNCH(T_, O_, 256, 128, 4, 2, false, 2); break;       \
+            case 3: LAUNCH(T_, O_, 256, 256, 2, 4, false, 2); break;       \
+            case 4: LAUNCH(T_, O_, 256, 256, 2, 4, true, 2); break;        \
+            case 5: LAUNCH(T_, O_, 128, 128, 2, 2, true, 1); break;        \
+            case 6: LAUNCH(T_, O_, 256, 128, 4, 2, true, 1); break;        \
+            case 7: LAUNCH(T_, O_, 128, 256, 2, 4, true, 1); break;        \
+            case 9: LAUNCH(T_, O_, 256, 64, 4, 1, true, 1); break;         \
+            default: LAUNCH(T_, O_, 128, 128, 2, 2, false, 2); break;      \
+        }                                                                  \
+    } while (0)
     if (precision == MI355_PREC_FP16) {
-        if (out16) gemm16_kernel<_Float16, true><<<grid, 256, 0, st>>>(g);
-        else       gemm16_kernel<_Float16, false><<<grid, 256, 0, st>>>(g);
+        if (out16) BY_VARIANT(_Float16, true); else BY_VARIANT(_Float16, false);
     } else {
-        if (out16) gemm16_kernel<__bf16, true><<<grid, 256, 0, st>>>(g);
-        else       gemm16_kernel<__bf16, false><<<grid, 256, 0, st>>>(g);
+        if (out16) BY_VARIANT(__bf16, true); else BY_VARIANT(__bf16, false);
     }
+#undef BY_VARIANT
+#undef LAUNCH
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Time mi355_linear16_fwd under every tile/schedule variant on the ViT-Base GEMM shapes (B=256) and check that all
+variants agree bit-for-bit with variant 0."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-attention_amd"))
+import torch  # noqa: E402
+import mi355attn  # noqa: E402
+from mi355attn import StreamTimer  # noqa: E402
+from mi355attn import functional as F  # noqa: E402
+
+dev = torch.device("cuda", 0)
+M = 256 * 197
+# (name, N, K, out16, with_resid, gelu)
+shapes = [("qkv", 2304, 768, True, False, False), ("proj", 768, 768, False, True, False), ("fc1", 3072, 768, True, False, True),
+          ("fc2", 768, 3072, False, True, True), ("fc1_nogelu", 3072, 768, True, False, False)]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,4,5,6,7".split(","))]
+res = []
+for name, N, K, out16, with_resid, gelu in shapes:
+    torch.manual_seed(0)
+    x16 = torch.randn(M, K, device=dev).half()
+    w16 = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+    b = torch.randn(N, device=dev)
+    resid = torch.randn(M, N, device=dev) if with_resid else None
+    ref = None
+    for v in variants:
+        mi355attn.set_option("gemm_variant", v)
+        act = F.ACT_GELU if gelu else F.ACT_NONE
+        y = F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
+        torch.cuda.synchronize()
+        same = True if ref is None else bool(torch.equal(y, ref))
+        if ref is None:
+            ref = y.clone()
+        for _ in range(3):
+            F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
+        torch.cuda.synchronize()
+        tm = StreamTimer(dev); tm.start()
+        for _ in range(10):
+            F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
+        ms = tm.stop_ms() / 10
+        tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+        res.append(dict(shape=name, N=N, K=K, variant=v, ms=round(ms, 4), tflops=round(tf, 1), same_as_v0=same))
+        print(res[-1], flush=True)
+mi355attn.set_option("gemm_variant", 0)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
