@@ -46,10 +46,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
     constexpr int TM = BM / WM, TN = BN / WN, MF = TM / 16, NF = TN / 16;
     constexpr int STAGE = (BM + BN) * BK;                       // elements per stage
     constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;           // LDS-DMA instructions per wave per stage (8 rows each)
-    constexpr int EP = TN + 4;                                  // epilogue slab pitch (floats)
-    constexpr int STAGE_BYTES = STAGES * STAGE * 2;
-    constexpr int EPI_BYTES = NW * 32 * EP * 4;
-    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    constexpr int LDS_BYTES = STAGES * STAGE * 2;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 32 == 0 && TN % 16 == 0, "tile/wave geometry");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     T* lds = reinterpret_cast<T*>(lds_raw);
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fb[j], fa[i], acc[i][j]);   // D^T = W.X^T: see the epilogue
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -143,28 +140,226 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
         }
     }
 
-    // ---- epilogue: 32 rows at a time through a per-wave LDS slab (aliases the stage buffers: the loop's last barrier has
-    //      retired every read of them), row-contiguous stores; only wave-level ordering is needed from here on ---------------
+    // ---- epilogue straight from the accumulators.  The MFMAs above compute the TRANSPOSED 16x16 tiles (weights as the A
+    //      operand, activations as B), so lane (l15, g) holds output row m = i*16 + l15 and four CONSECUTIVE columns
+    //      n = j*16 + g*4 + [0,4): one 16-byte (fp32) / 8-byte (16-bit) store per tile and lane, the four lane groups of a row
+    //      completing a 64-byte run -- no LDS transpose, ~8x fewer epilogue instructions than the slab version -----------------
+    {
+        float* Cf = static_cast<float*>(g.C);
+        T* Ch = static_cast<T*>(g.C);
+        const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+        f4 bias4[NF], gam4[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = n0 + wc * TN + j * 16 + g4;
+            bias4[j] = (g.bias && n < g.N) ? *reinterpret_cast<const f4*>(g.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
+            gam4[j] = (g.gamma && n < g.N) ? *reinterpret_cast<const f4*>(g.gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + wr * TM + i * 16 + l15;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + wc * TN + j * 16 + g4;
+                if (n >= g.N) continue;                         // N % 4 == 0 is a launch precondition
+                f4 v = acc[i][j] + bias4[j];
+                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.gamma) v = v * gam4[j];
+                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+                if constexpr (OUT16) {
+                    *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                } else {
+                    *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ping-pong schedule (variant 10): 256 x 256 x 64 tile, ONE workgroup of 8 waves per CU, 128 KB LDS = two whole K-tiles.
+// The two waves that share a SIMD (wave w and w+4: row groups wr = 0 / 1) run the same 8-slot program per K-tile, shifted by one
+// slot with an extra raw s_barrier, so that in every slot one of them feeds the matrix pipe (16 MFMAs = one 64 x 32 quadrant of
+// its 128 x 64 output over K = 64) while the other pulls its next fragments from LDS:
+//     slot        0      1      2      3      4      5      6            7
+//     group 0   R(A0,B0) M(q00) R(B1)  M(q01) R(A1)  M(q11) issue t+2    M(q10) + wait(t+1)
+//     group 1   M'(q10)  R(A0,B0) M(q00) R(B1) M(q01) R(A1) M(q11)+issue  wait(t+1)        (M' = previous tile)
+// LDS-DMA for tile t+2 is issued only after the barrier that closes slot 5 (the last ds_read of tile t's buffer, retired by an
+// explicit lgkmcnt(0) before that barrier), and tile t+1 is first read one slot after the counted vmcnt + barrier that
+// retires it (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it").  Raw s_barrier only:
+// __syncthreads() would drain the DMA queue.
+// ---------------------------------------------------------------------------------------------------------------------------
+// ABL: timing-only ablation mask for tuning experiments (results are WRONG when non-zero): 1 = no LDS fragment reads inside the
+// loop, 2 = no barriers inside the loop, 4 = no LDS-DMA inside the loop.
+template <typename T, bool OUT16, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
+    using v8 = typename Vec8<T>::t;
+    using v4 = typename Vec8<T>::t4;
+    constexpr int BM = 256, BN = 256;
+    constexpr int TILE = (BM + BN) * BK;                        // elements per K-tile buffer (64 KB)
+    constexpr int EP = 64 + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * TILE * 2];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                    // 2 (M) x 4 (N) waves, 128 x 64 outputs each
+    const int tiles_n = (g.N + BN - 1) / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+
+    // DMA sources: per K-tile every wave moves 4 x 8 rows of A and 4 x 8 rows of B (8 instructions of 1 KB)
+    const int lrow = lane >> 3, pch = lane & 7;
+    const int csw = (pch ^ lrow) * 8;
+    const T* a_src[4];
+    const T* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ma = m0 + (wave * 4 + i) * 8 + lrow; if (ma >= g.M) ma = g.M - 1;
+        int nb = n0 + (wave * 4 + i) * 8 + lrow; if (nb >= g.N) nb = g.N - 1;
+        a_src[i] = A + (long)ma * g.lda + csw;
+        b_src[i] = B + (long)nb * g.ldb + csw;
+    }
+    auto issue = [&](int buf, int k0) {
+        T* sA = lds + buf * TILE + (wave * 32) * BK;
+        T* sB = lds + buf * TILE + BM * BK + (wave * 32) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
+        }
+    };
+
+    f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    v8 fa[4][2], fb[4][2];                                      // A: 4 m-frags x 2 k-halves (one 64-row half); B: 4 n-frags x 2
+
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    const int off0 = ((fq ^ fsw) * 8), off1 = (((4 + fq) ^ fsw) * 8);
+    auto read_a = [&](int buf, int mh) {                        // rows wr*128 + mh*64 + i*16 + frow
+        const T* sA = lds + buf * TILE + (wr * 128 + mh * 64 + frow) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off0);
+            fa[i][1] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off1);
+        }
+    };
+    auto read_b = [&](int buf, int nh) {                        // cols wc*64 + nh*32 + j*16 + frow -> fb[nh*2 + j]
+        const T* sB = lds + buf * TILE + BM * BK + (wc * 64 + nh * 32 + frow) * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[nh * 2 + j][0] = *reinterpret_cast<const v8*>(sB + j * 16 * BK + off0);
+            fb[nh * 2 + j][1] = *reinterpret_cast<const v8*>(sB + j * 16 * BK + off1);
+        }
+    };
+#define PP_MMA(MH, NH)                                                                                          \
+    do {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+                    acc[(MH) * 4 + i][(NH) * 2 + j] = mma16<T>(fa[i][kk], fb[(NH) * 2 + j][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+    } while (0)
+#define PP_BAR() do { if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } while (0)
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PP_RA(B_, H_) do { if constexpr (!(ABL & 1)) read_a(B_, H_); } while (0)
+#define PP_RB(B_, H_) do { if constexpr (!(ABL & 1)) read_b(B_, H_); } while (0)
+#define PP_ISSUE(B_, K_) do { if constexpr (!(ABL & 4)) issue(B_, K_); } while (0)
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    if (nk > 1) {
+        issue(1, BK);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed, tile 1 may still fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BAR();
+    if (wr == 1) PP_BAR();                                      // one-slot shift of the second row group
+    if constexpr (ABL & 1) { read_a(0, 0); read_b(0, 0); read_b(0, 1); }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 2 < nk;
+        // position 0: R(A0, B0)
+        PP_RA(cur, 0);
+        PP_RB(cur, 0);
+        PP_LGKM0();
+        PP_BAR();
+        // position 1: M(q00)
+        PP_MMA(0, 0);
+        PP_BAR();
+        // position 2: R(B1)
+        PP_RB(cur, 1);
+        PP_LGKM0();
+        PP_BAR();
+        // position 3: M(q01)
+        PP_MMA(0, 1);
+        PP_BAR();
+        // position 4: R(A1)      (last LDS read of this buffer by this wave; retired before the barrier)
+        PP_RA(cur, 1);
+        PP_LGKM0();
+        PP_BAR();
+        // position 5: M(q11)     group 1 is in global slot 6 here: buffer `cur` is free for every wave -> refill it
+        if (wr == 1 && more) PP_ISSUE(cur, (kt + 2) * BK);
+        PP_MMA(1, 1);
+        PP_BAR();
+        // position 6: (no reads) group 0 is in global slot 6: refill; group 1 is in slot 7: retire tile kt+1
+        if (wr == 0 && more) PP_ISSUE(cur, (kt + 2) * BK);
+        if (wr == 1) {
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+        // position 7: M(q10)     group 0 is in slot 7: retire tile kt+1 before the closing barrier
+        PP_MMA(1, 0);
+        if (wr == 0) {
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+    }
+    if (wr == 0) PP_BAR();                                      // balance the shift: every wave executed 8*nk + 2 barriers
+    PP_BAR();                                                   // everybody is done with the K-tile buffers
+#undef PP_MMA
+#undef PP_LGKM0
+#undef PP_RA
+#undef PP_RB
+#undef PP_ISSUE
+
+    // ---- epilogue (per-wave slab aliasing the K-tile buffers; wave-level ordering only) ------------------------------------------
     float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EP;
     float* Cf = static_cast<float*>(g.C);
     T* Ch = static_cast<T*>(g.C);
-    constexpr int LPR = TN / 4, RPI = 64 / LPR;                 // lanes per row, rows per store instruction
 #pragma unroll
-    for (int p = 0; p < TM / 32; ++p) {
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < NF; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     slab[(ii * 16 + (lane >> 4) * 4 + r) * EP + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rl = it * RPI + lane / LPR, cl = (lane % LPR) * 4;
-            const int m = m0 + wr * TM + p * 32 + rl, n = n0 + wc * TN + cl;
-            if (m >= g.M || n >= g.N) continue;                 // N % 4 == 0 is a launch precondition
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
+            const int m = m0 + wr * 128 + p * 32 + rl, n = n0 + wc * 64 + cl;
+            if (m >= g.M || n >= g.N) continue;
             f4 v = *reinterpret_cast<const f4*>(slab + rl * EP + cl);
             if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
             if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
@@ -179,6 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+#undef PP_BAR
 }
 
 // fp32 -> 16-bit operand format, 8 elements per thread (2 x 16-B loads, 1 x 16-B store)
@@ -240,6 +436,11 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
             case 6: LAUNCH(T_, O_, 256, 128, 4, 2, true, 1); break;        \
             case 7: LAUNCH(T_, O_, 128, 256, 2, 4, true, 1); break;        \
             case 9: LAUNCH(T_, O_, 256, 64, 4, 1, true, 1); break;         \
+            case 10: gemm16_pp_kernel<T_, O_><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
+            case 11: gemm16_pp_kernel<T_, O_, 1><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
+            case 12: gemm16_pp_kernel<T_, O_, 2><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
+            case 13: gemm16_pp_kernel<T_, O_, 4><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
+            case 14: gemm16_pp_kernel<T_, O_, 7><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
             default: LAUNCH(T_, O_, 128, 128, 2, 2, false, 2); break;      \
         }                                                                  \
     } while (0)

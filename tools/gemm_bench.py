@@ -17,6 +17,10 @@ M = 256 * 197
 # (name, N, K, out16, with_resid, gelu)
 shapes = [("qkv", 2304, 768, True, False, False), ("proj", 768, 768, False, True, False), ("fc1", 3072, 768, True, False, True),
           ("fc2", 768, 3072, False, True, True), ("fc1_nogelu", 3072, 768, True, False, False)]
+if os.environ.get("GEMM_SHAPES"):
+    shapes = [s_ for s_ in shapes if s_[0] in os.environ["GEMM_SHAPES"].split(",")]
+if os.environ.get("GEMM_LONGK"):
+    shapes.append(("longK", 2304, 6144, True, False, False))
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,4,5,6,7".split(","))]
 res = []
 for name, N, K, out16, with_resid, gelu in shapes:
