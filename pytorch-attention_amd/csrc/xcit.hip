@@ -1,7 +1,7 @@
 // xcit.hip -- XCiT cross-covariance attention core (XCA) and the LPI depth-wise stencil block for gfx950.
 //
-// XCA (xcit.py:249-262): per (image, head) the attention matrix is only d x d (48 x 48 for XCiT-S) and both
-// contractions run over <= 224 tokens, so the whole head lives in one workgroup's LDS and the arithmetic is done in
+// XCA (xcit.py:249-262): per (image, head) the attention matrix is only d x d (48 x 48 for XCiT-S); one workgroup streams
+// the head's tokens through LDS in chunks of 64 (any token count) and the arithmetic is done in
 // EXACT fp32 on the matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain, cdna_hip_programming.md section 3) --
 // no operand rounding, hence the `precision` argument does not change the result:
 //     G = Q^T K (d x d, contraction over tokens)   ->  G_ij / (max(|q_i|,eps) max(|k_j|,eps)) * temperature_h
@@ -9,72 +9,113 @@
 // HBM traffic = read the head's q,k,v once + write out once.
 //
 // LPI (xcit.py:149-157): tokens -> (C,H,W) image -> dw3x3 -> GELU -> BatchNorm(eval) -> dw3x3 -> tokens, fused in one
-// kernel per (image, 32-channel group): the token tile and the intermediate sit in LDS, lanes run along channels so
-// every LDS access is conflict-free and every HBM access is a 128-byte row piece; LayerScale + residual fused.
+// kernel per (image, 32-channel group): the token tile and the intermediate sit in LDS, a lane owns 4 channels (16-byte LDS
+// and HBM accesses, 128-byte row pieces per token); LayerScale + residual fused.
 #include "common.h"
 #include "mma.h"
 
 namespace {
 
-constexpr int XCA_NP = 224;     // max tokens (multiple of 16)
+// ---------------------------------------------------------------------------------------------------------------------------
+// XCA core, streaming over tokens in chunks of 64: LDS holds one q/k (then v) chunk + the d x d matrix, so 4 workgroups fit a
+// CU (latency hiding comes from the neighbours) and the token count is unbounded.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int XCA_TC = 64;      // tokens per chunk
 
 template <int D>
 __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv, const float* __restrict__ temperature,
                                                  float* __restrict__ out, int N, int heads) {
     constexpr int P = D + 1;                 // LDS pitch (floats): odd -> conflict-free column walks
-    constexpr int DT = D / 16;
-    __shared__ float s_a[XCA_NP * P];        // q, later v
-    __shared__ float s_b[XCA_NP * P];        // k
+    constexpr int DT = D / 16, D4 = D / 4;
+    constexpr int NLD = (XCA_TC * D4 + 255) / 256;          // float4 loads per thread per array per chunk
+    __shared__ float s_a[XCA_TC * P];        // q chunk, later v chunk
+    __shared__ float s_b[XCA_TC * P];        // k chunk
     __shared__ float s_g[D * P];             // G, then A = softmax(G)
-    __shared__ float s_n[2 * D];             // column norms of q and k
+    __shared__ float s_n[2 * D];             // squared column norms of q and k (running), then the norms
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     const int h = blockIdx.x % heads, b = blockIdx.x / heads;
     const int C = heads * D;
     const long row3 = 3L * C;
     const float* base = qkv + (long)b * N * row3 + h * D;
-    const int NP4 = (N + 3) & ~3, NP16 = (N + 15) & ~15;
+    const int nchunks = (N + XCA_TC - 1) / XCA_TC;
 
-    // ---- stage q, k (rows >= N zeroed up to the 16-token boundary) ---------------------------------------------------
-    constexpr int D4 = D / 4;
-    for (int idx = t; idx < NP16 * D4; idx += 256) {
-        const int n = idx / D4, d4 = idx % D4;
-        f4 q = {0.f, 0.f, 0.f, 0.f}, k = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) {
-            q = *reinterpret_cast<const f4*>(base + (long)n * row3 + d4 * 4);
-            k = *reinterpret_cast<const f4*>(base + (long)n * row3 + C + d4 * 4);
-        }
-        float* pa = s_a + n * P + d4 * 4;
-        float* pb = s_b + n * P + d4 * 4;
-        pa[0] = q.x; pa[1] = q.y; pa[2] = q.z; pa[3] = q.w;
-        pb[0] = k.x; pb[1] = k.y; pb[2] = k.z; pb[3] = k.w;
-    }
-    __syncthreads();
-    // ---- column L2 norms over tokens (F.normalize: x / max(||x||, 1e-12)) --------------------------------------------
-    if (t < 2 * D) {
-        const float* src = (t < D ? s_a : s_b) + (t % D);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int n = 0;
-        for (; n + 3 < N; n += 4) {
-            const float v0 = src[n * P], v1 = src[(n + 1) * P], v2 = src[(n + 2) * P], v3 = src[(n + 3) * P];
-            a0 += v0 * v0; a1 += v1 * v1; a2 += v2 * v2; a3 += v3 * v3;
-        }
-        for (; n < N; ++n) { const float v = src[n * P]; a0 += v * v; }
-        s_n[t] = fmaxf(sqrtf((a0 + a1) + (a2 + a3)), 1e-12f);
-    }
-    // ---- G = Q^T K on exact-fp32 MFMA: A[i][k=n] = q[n][i], B[k=n][j] = k[n][j] ------------------------------------------
-    for (int tl = wave; tl < DT * DT; tl += 4) {
-        const int it = tl / DT, jt = tl % DT;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < NP4 / 4; ++ks) {
-            const float av = s_a[(ks * 4 + g) * P + it * 16 + l15];
-            const float bv = s_b[(ks * 4 + g) * P + jt * 16 + l15];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    // which G tiles this wave accumulates (DT*DT tiles round-robin over the 4 waves, at most 4 each for D = 64)
+    constexpr int TPW = (DT * DT + 3) / 4;
+    f4 gacc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) gacc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float nsq = 0.f;                                        // threads t < 2D: running sum of squares of one q / k column
+    if (t < 2 * D) s_n[t] = 0.f;
+
+    auto stage = [&](int chunk, int which_a, int which_b, bool two) {     // which_*: 0 = q, 1 = k, 2 = v
+        f4 ra[NLD], rb[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = t + it * 256, nl = idx / D4, d4 = idx % D4, n = chunk * XCA_TC + nl;
+            ra[it] = f4{0.f, 0.f, 0.f, 0.f};
+            rb[it] = f4{0.f, 0.f, 0.f, 0.f};
+            if (idx < XCA_TC * D4 && n < N) {
+                ra[it] = *reinterpret_cast<const f4*>(base + (long)n * row3 + which_a * C + d4 * 4);
+                if (two) rb[it] = *reinterpret_cast<const f4*>(base + (long)n * row3 + which_b * C + d4 * 4);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_g[(it * 16 + g * 4 + r) * P + jt * 16 + l15] = acc[r];
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = t + it * 256, nl = idx / D4, d4 = idx % D4;
+            if (idx < XCA_TC * D4) {
+                float* pa = s_a + nl * P + d4 * 4;
+                pa[0] = ra[it].x; pa[1] = ra[it].y; pa[2] = ra[it].z; pa[3] = ra[it].w;
+                if (two) {
+                    float* pb = s_b + nl * P + d4 * 4;
+                    pb[0] = rb[it].x; pb[1] = rb[it].y; pb[2] = rb[it].z; pb[3] = rb[it].w;
+                }
+            }
+        }
+    };
+
+    // ---- phase 1: G = Q^T K and the column norms, chunk by chunk (exact fp32 MFMA 16x16x4) -------------------------------------
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage(ch, 0, 1, true);
+        __syncthreads();
+        if (t < 2 * D) {
+            const float* src = (t < D ? s_a : s_b) + (t % D);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+            for (int n = 0; n < XCA_TC; n += 4) {
+                const float v0 = src[n * P], v1 = src[(n + 1) * P], v2 = src[(n + 2) * P], v3 = src[(n + 3) * P];
+                a0 += v0 * v0; a1 += v1 * v1; a2 += v2 * v2; a3 += v3 * v3;
+            }
+            nsq += (a0 + a1) + (a2 + a3);
+        }
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            const int tl = wave + 4 * ti;
+            if (tl < DT * DT) {
+                const int it = tl / DT, jt = tl % DT;
+                f4 acc = gacc[ti];
+#pragma unroll
+                for (int ks = 0; ks < XCA_TC / 4; ++ks) {
+                    const float av = s_a[(ks * 4 + g) * P + it * 16 + l15];
+                    const float bv = s_b[(ks * 4 + g) * P + jt * 16 + l15];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+                gacc[ti] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (t < 2 * D) s_n[t] = fmaxf(sqrtf(nsq), 1e-12f);      // F.normalize: x / max(||x||, 1e-12)
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tl = wave + 4 * ti;
+        if (tl < DT * DT) {
+            const int it = tl / DT, jt = tl % DT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_g[(it * 16 + g * 4 + r) * P + jt * 16 + l15] = gacc[ti][r];
+        }
     }
     __syncthreads();
-    // ---- A = softmax_rows(G / (|q_i| |k_j|) * temperature): 16 lanes per row ------------------------------------------
+    // ---- phase 2: A = softmax_rows(G / (|q_i| |k_j|) * temperature): 16 lanes per row ------------------------------------------
     {
         const float temp = temperature[h];
         const int tj = t & 15;
@@ -98,33 +139,29 @@ __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv,
             for (int c = 0; c < DT; ++c) s_g[i * P + tj + 16 * c] = v[c] / sum;
         }
     }
-    // ---- stage v over q's buffer -----------------------------------------------------------------------------------------
-    for (int idx = t; idx < NP16 * D4; idx += 256) {
-        const int n = idx / D4, d4 = idx % D4;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) v = *reinterpret_cast<const f4*>(base + (long)n * row3 + 2 * C + d4 * 4);
-        float* pa = s_a + n * P + d4 * 4;
-        pa[0] = v.x; pa[1] = v.y; pa[2] = v.z; pa[3] = v.w;
-    }
     __syncthreads();
-    // ---- O[i][n] = sum_j A[i][j] v[n][j]:  A-operand rows i, B-operand columns n ------------------------------------------
-    const int NT = NP16 / 16;
-    for (int tl = wave; tl < DT * NT; tl += 4) {
-        const int it = tl % DT, nt = tl / DT;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- phase 3: O[i][n] = sum_j A[i][j] v[n][j], chunk by chunk; lane holds 4 consecutive i of one token -> 16-byte stores ----
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage(ch, 2, 2, false);
+        __syncthreads();
+        for (int tl = wave; tl < DT * (XCA_TC / 16); tl += 4) {
+            const int it = tl % DT, nt = tl / DT;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < D / 4; ++ks) {
-            const float av = s_g[(it * 16 + l15) * P + ks * 4 + g];
-            const float bv = s_a[(nt * 16 + l15) * P + ks * 4 + g];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            for (int ks = 0; ks < D / 4; ++ks) {
+                const float av = s_g[(it * 16 + l15) * P + ks * 4 + g];
+                const float bv = s_a[(nt * 16 + l15) * P + ks * 4 + g];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            const int n = ch * XCA_TC + nt * 16 + l15;
+            if (n < N) *reinterpret_cast<f4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = acc;
         }
-        const int n = nt * 16 + l15;
-        if (n < N) *reinterpret_cast<f4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = acc;
+        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// LPI: workgroup = (image, 32 channels); 256 threads = 8 token lanes x 32 channel lanes.
+// LPI: workgroup = (image, 32 channels); 256 threads = 32 token lanes x 8 channel quads (16-byte LDS / HBM accesses).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int LPI_CG = 32;
 
@@ -139,43 +176,63 @@ __global__ __launch_bounds__(256) void lpi_kernel(const float* __restrict__ x, c
     const int N = H * W;
     float* s_x = smem;                 // [N][32]
     float* s_m = smem + N * LPI_CG;    // [N][32] intermediate
-    const int t = threadIdx.x, cl = t & 31, tl = t >> 5;
-    const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * LPI_CG + cl;
-    const bool cok = c < C;
+    const int t = threadIdx.x, cq = t & 7, tl = t >> 3;              // channel quad, token lane
+    const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * LPI_CG + cq * 4;
+    const bool vec = ((C & 3) == 0) && (c + 3 < C);                  // whole quad in range and 16-byte aligned rows
     const float* xb = x + (long)b * N * C;
-    for (int n = tl; n < N; n += 8) s_x[n * LPI_CG + cl] = cok ? xb[(long)n * C + c] : 0.f;
-    float k1[9], k2[9];
+    auto ldc = [&](const float* p, int cc, float dflt) { return cc < C ? p[cc] : dflt; };
+    for (int n = tl; n < N; n += 32) {
+        f4 v;
+        if (vec) v = *reinterpret_cast<const f4*>(xb + (long)n * C + c);
+        else v = f4{ldc(xb + (long)n * C, c, 0.f), ldc(xb + (long)n * C, c + 1, 0.f), ldc(xb + (long)n * C, c + 2, 0.f),
+                    ldc(xb + (long)n * C, c + 3, 0.f)};
+        *reinterpret_cast<f4*>(s_x + n * LPI_CG + cq * 4) = v;
+    }
+    auto tap = [&](const float* p, int ch, int i) { return ch < C ? p[(long)ch * 9 + i] : 0.f; };     // dw weight (C,3,3)
+    f4 k1[9], k2[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { k1[i] = cok ? w1[(long)c * 9 + i] : 0.f; k2[i] = cok ? w2[(long)c * 9 + i] : 0.f; }
-    const float bias1 = cok ? b1[c] : 0.f, bias2 = cok ? b2[c] : 0.f;
-    const float mean = cok ? bn_m[c] : 0.f, var = cok ? bn_v[c] : 1.f, bw = cok ? bn_w[c] : 0.f, bb = cok ? bn_b[c] : 0.f;
-    const float rstd = 1.0f / sqrtf(var + bn_eps);
+    for (int i = 0; i < 9; ++i) {
+        k1[i] = f4{tap(w1, c, i), tap(w1, c + 1, i), tap(w1, c + 2, i), tap(w1, c + 3, i)};
+        k2[i] = f4{tap(w2, c, i), tap(w2, c + 1, i), tap(w2, c + 2, i), tap(w2, c + 3, i)};
+    }
+    auto ld4 = [&](const float* p, float dflt) { return f4{ldc(p, c, dflt), ldc(p, c + 1, dflt), ldc(p, c + 2, dflt), ldc(p, c + 3, dflt)}; };
+    const f4 bias1 = ld4(b1, 0.f), bias2 = ld4(b2, 0.f);
+    const f4 mean = ld4(bn_m, 0.f), var = ld4(bn_v, 1.f), bw = ld4(bn_w, 0.f), bb = ld4(bn_b, 0.f);
+    const f4 rstd = f4{1.0f / sqrtf(var.x + bn_eps), 1.0f / sqrtf(var.y + bn_eps), 1.0f / sqrtf(var.z + bn_eps),
+                       1.0f / sqrtf(var.w + bn_eps)};
     __syncthreads();
-    auto conv = [&](const float* src, const float* k, float bias, int n) {
+    auto conv = [&](const float* src, const f4* k, f4 bias, int n) {
         const int yy = n / W, xx = n % W;
-        float acc = bias;
+        f4 acc = bias;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const int y2 = yy + dy, x2 = xx + dx;
-                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) acc += k[(dy + 1) * 3 + dx + 1] * src[(y2 * W + x2) * LPI_CG + cl];
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W)
+                    acc = acc + k[(dy + 1) * 3 + dx + 1] * *reinterpret_cast<const f4*>(src + (y2 * W + x2) * LPI_CG + cq * 4);
             }
         return acc;
     };
-    for (int n = tl; n < N; n += 8) {
-        const float v = gelu_erf(conv(s_x, k1, bias1, n));
-        s_m[n * LPI_CG + cl] = (v - mean) * rstd * bw + bb;
+    for (int n = tl; n < N; n += 32) {
+        const f4 u = conv(s_x, k1, bias1, n);
+        const f4 v = f4{gelu_erf(u.x), gelu_erf(u.y), gelu_erf(u.z), gelu_erf(u.w)};
+        *reinterpret_cast<f4*>(s_m + n * LPI_CG + cq * 4) = (v - mean) * rstd * bw + bb;
     }
     __syncthreads();
-    if (!cok) return;
-    const float gm = gamma ? gamma[c] : 1.0f;
-    for (int n = tl; n < N; n += 8) {
-        float v = conv(s_m, k2, bias2, n);
+    const f4 gm = gamma ? ld4(gamma, 1.f) : f4{1.f, 1.f, 1.f, 1.f};
+    for (int n = tl; n < N; n += 32) {
+        f4 v = conv(s_m, k2, bias2, n);
         const long o = ((long)b * N + n) * C + c;
-        v = gamma ? v * gm : v;
-        if (resid) v += resid[o];
-        y[o] = v;
+        if (gamma) v = v * gm;
+        if (vec) {
+            if (resid) v = v + *reinterpret_cast<const f4*>(resid + o);
+            *reinterpret_cast<f4*>(y + o) = v;
+        } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int q = 0; q < 4; ++q)
+                if (c + q < C) y[o + q] = vv[q] + (resid ? resid[o + q] : 0.f);
+        }
     }
 }
 
@@ -188,7 +245,6 @@ int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B,
     MI355_CHECK_ARG(qkv && temperature && out && B > 0 && N > 0 && heads > 0);
     MI355_CHECK_ARG(precision >= 0 && precision <= 2);      // accepted for API symmetry; the core is exact fp32 in every mode
     MI355_CHECK_ARG(aligned16(qkv) && aligned16(out));
-    if (N > XCA_NP) return mi355::fail(MI355_EUNSUPPORTED, "mi355_xca_fwd: %d tokens > %d (one head must fit one workgroup's LDS)", N, XCA_NP);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = B * heads;
     switch (d) {

@@ -230,7 +230,8 @@ def test_lepe_accepts_permuted_view_without_copy():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B,N,h,d", [(2, 196, 8, 48), (1, 49, 4, 32), (2, 10, 2, 64), (1, 224, 2, 48), (3, 196, 4, 32)])
+@pytest.mark.parametrize("B,N,h,d", [(2, 196, 8, 48), (1, 49, 4, 32), (2, 10, 2, 64), (1, 224, 2, 48), (3, 196, 4, 32), (1, 784, 2, 48),
+                                    (2, 64, 3, 64), (1, 65, 1, 32), (1, 1, 2, 48)])
 def test_xca_core(B, N, h, d):
     torch.manual_seed(N + d)
     C = h * d
@@ -252,7 +253,7 @@ def _xca_core_ref(qkv, temp, h):
     return (a @ v).permute(0, 3, 1, 2).reshape(B, N, C)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 14, 14, 384), (1, 7, 7, 40), (3, 4, 9, 100), (1, 1, 1, 32)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 14, 14, 384), (1, 7, 7, 40), (3, 4, 9, 100), (1, 1, 1, 32), (2, 5, 3, 30), (1, 14, 14, 130)])
 def test_lpi(B, H, W, C):
     torch.manual_seed(H * W + C)
     x = torch.randn(B, H * W, C)
