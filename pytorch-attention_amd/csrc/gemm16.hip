@@ -198,7 +198,6 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
     using v4 = typename Vec8<T>::t4;
     constexpr int BM = 256, BN = 256;
     constexpr int TILE = (BM + BN) * BK;                        // elements per K-tile buffer (64 KB)
-    constexpr int EP = 64 + 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * TILE * 2];
     T* lds = reinterpret_cast<T*>(lds_raw);
 
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-                    acc[(MH) * 4 + i][(NH) * 2 + j] = mma16<T>(fa[i][kk], fb[(NH) * 2 + j][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
+                    acc[(MH) * 4 + i][(NH) * 2 + j] = mma16<T>(fb[(NH) * 2 + j][kk], fa[i][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
         __builtin_amdgcn_s_setprio(0);                                                                          \
     } while (0)
 #define PP_BAR() do { if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } while (0)
@@ -340,39 +339,37 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
 #undef PP_RB
 #undef PP_ISSUE
 
-    // ---- epilogue (per-wave slab aliasing the K-tile buffers; wave-level ordering only) ------------------------------------------
-    float* slab = reinterpret_cast<float*>(lds_raw) + wave * 32 * EP;
-    float* Cf = static_cast<float*>(g.C);
-    T* Ch = static_cast<T*>(g.C);
+    // ---- epilogue straight from the accumulators (transposed MFMA tiles: lane = one row, 4 consecutive columns) -------------------
+    {
+        float* Cf = static_cast<float*>(g.C);
+        T* Ch = static_cast<T*>(g.C);
+        const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+        f4 bias4[4], gam4[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + g4;
+            bias4[j] = (g.bias && n < g.N) ? *reinterpret_cast<const f4*>(g.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
+            gam4[j] = (g.gamma && n < g.N) ? *reinterpret_cast<const f4*>(g.gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
+        }
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + l15;
+            if (m >= g.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    slab[(ii * 16 + (lane >> 4) * 4 + r) * EP + j * 16 + (lane & 15)] = acc[p * 2 + ii][j][r];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
-            const int m = m0 + wr * 128 + p * 32 + rl, n = n0 + wc * 64 + cl;
-            if (m >= g.M || n >= g.N) continue;
-            f4 v = *reinterpret_cast<const f4*>(slab + rl * EP + cl);
-            if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
-            if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
-            if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
-            if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
-            if constexpr (OUT16) {
-                *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
-            } else {
-                *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + g4;
+                if (n >= g.N) continue;
+                f4 v = acc[i][j] + bias4[j];
+                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.gamma) v = v * gam4[j];
+                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+                if constexpr (OUT16) {
+                    *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                } else {
+                    *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #undef PP_BAR
 }
