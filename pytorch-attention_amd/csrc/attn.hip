@@ -30,6 +30,7 @@ struct AttnArgs {
     int L, Ctot, c0, heads;
     int reso, Hsp, Wsp, nWx, nwin;   // window geometry on the token grid
     int T;                 // tokens per window
+    unsigned wsp_magic;    // ceil(2^32 / Wsp): slot / Wsp == umulhi(slot, magic) for slot, Wsp < 2^16 (no integer divide in the kernel)
     float scale;
     int pre_scale;         // 1: q*scale before QK^T (CSWin), 0: (QK^T)*scale (ViT)
 };
@@ -64,7 +65,36 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
     const long row3 = 3L * a.Ctot;
     using gel = typename std::conditional<IO16, el, float>::type;        // element type in HBM
     const gel* base = static_cast<const gel*>(a.qkv) + (long)b * a.L * row3 + ch0;
-    auto tok = [&](int s) { return (wy0 + s / a.Wsp) * a.reso + wx0 + s % a.Wsp; };   // window slot -> token index
+    auto srow = [&](int s) { return a.Wsp == 1 ? s : (int)__umulhi((unsigned)s, a.wsp_magic); };   // s / Wsp (magic overflows at 1)
+    auto tok = [&](int s) { const int r = srow(s); return (wy0 + r) * a.reso + wx0 + (s - r * a.Wsp); };   // window slot -> token
+
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqt = (T + 15) >> 4;
+    // ---- everything this wave will need from HBM is requested up front (one memory latency per workgroup): its Q fragments
+    //      (16-bit I/O path), its LePE taps, then the K / V staging loads below --------------------------------------------------
+    constexpr int NQ = (KT + NW - 1) / NW;                         // query tiles per wave
+    v8 qraw[IO16 ? NQ : 1][D / 32];
+    if constexpr (IO16) {
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) {
+            const int qs = (wave + iq * NW) * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < D / 32; ++ks) {
+                qraw[iq][ks] = v8{};
+                if (qs < T) qraw[iq][ks] = *reinterpret_cast<const v8*>(base + (long)tok(qs) * row3 + ks * 32 + g * 8);
+            }
+        }
+    }
+    float lw[LEPE ? D / 16 : 1][9], lb[LEPE ? D / 16 : 1];
+    if constexpr (LEPE) {
+#pragma unroll
+        for (int nt = 0; nt < D / 16; ++nt) {
+            const int cidx = head * D + nt * 16 + l15;
+            lb[nt] = a.lepe_b[cidx];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) lw[nt][i] = a.lepe_w[(long)cidx * 9 + i];
+        }
+    }
 
     // ---- phase A: K -> LDS [key][d],  V -> LDS transposed [d][key] -------------------------------------------------
     constexpr int D4 = D / 4;
@@ -139,10 +169,11 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
     __syncthreads();
 
     // ---- phase B: each wave owns 16-query tiles ------------------------------------------------------------------------
-    const int l15 = lane & 15, g = lane >> 4;
-    const int nqt = (T + 15) >> 4;
     slab_t* slab = s_o + wave * 16 * OP;
-    for (int qt = wave; qt < nqt; qt += NW) {
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        const int qt = wave + iq * NW;
+        if (qt >= nqt) break;
         // Q fragments (B operand of S^T = K.Q^T): column q = l15, k = d = ks*32 + g*8 + [0,8)
         const int qs = qt * 16 + l15;
         v8 qf[D / 32][NS];
@@ -152,12 +183,10 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
             for (int ks = 0; ks < D / 32; ++ks) {
                 f4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (IO16) {
-                    if (qs < T) {
-                        const v8 raw = *reinterpret_cast<const v8*>(qrow + ks * 32 + g * 8);
-                        if (!a.pre_scale) { qf[ks][0] = raw; continue; }
-                        lo4 = f4{(float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]};
-                        hi4 = f4{(float)raw[4], (float)raw[5], (float)raw[6], (float)raw[7]};
-                    }
+                    const v8 raw = qraw[iq][ks];                  // zero beyond T
+                    if (!a.pre_scale) { qf[ks][0] = raw; continue; }
+                    lo4 = f4{(float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]};
+                    hi4 = f4{(float)raw[4], (float)raw[5], (float)raw[6], (float)raw[7]};
                 } else if (qs < T) {
                     lo4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8);
                     hi4 = *reinterpret_cast<const f4*>(qrow + ks * 32 + g * 8 + 4);
@@ -257,10 +286,9 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
                     // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo
                     const int qslot = qt * 16 + g * 4 + r;
                     if (qslot < T) {
-                        const int d = nt * 16 + l15, cidx = head * D + d;        // channel inside this branch
-                        const int ty = qslot / a.Wsp, tx = qslot % a.Wsp;
-                        float acc = a.lepe_b[cidx];
-                        const float* w9 = a.lepe_w + (long)cidx * 9;
+                        const int d = nt * 16 + l15;                              // channel inside this head
+                        const int ty = srow(qslot), tx = qslot - ty * a.Wsp;
+                        float acc = lb[nt];
 #pragma unroll
                         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
                                     const int ss = yy * a.Wsp + xx;
                                     float vv = (float)(*reinterpret_cast<const el*>(s_v + d * VP + ss));
                                     if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(s_v + V_EL + d * VP + ss));
-                                    acc += w9[(dy + 1) * 3 + dx + 1] * vv;
+                                    acc += lw[nt][(dy + 1) * 3 + dx + 1] * vv;
                                 }
                             }
                         val += acc;
@@ -339,6 +367,7 @@ static int sdpa_common(const void* qkv, void* out, int B, int N, int heads, int 
     AttnArgs a{};
     a.qkv = qkv; a.out = out; a.L = N; a.Ctot = heads * d; a.c0 = 0; a.heads = heads;
     a.reso = N; a.Hsp = 1; a.Wsp = N; a.nWx = 1; a.nwin = 1; a.T = N; a.scale = scale; a.pre_scale = 0;
+    a.wsp_magic = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
     if (d == 64) return io16 ? launch_attn<64, false, true>(a, B, precision, st) : launch_attn<64, false, false>(a, B, precision, st);
     return io16 ? launch_attn<32, false, true>(a, B, precision, st) : launch_attn<32, false, false>(a, B, precision, st);
 }
@@ -350,6 +379,7 @@ static int lepe_common(const void* qkv, const float* getv_w, const float* getv_b
     a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
     a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = Hsp * Wsp;
     a.scale = scale; a.pre_scale = 1;
+    a.wsp_magic = (unsigned)(((1ull << 32) + (unsigned)Wsp - 1) / (unsigned)Wsp);
     return io16 ? launch_attn<32, true, true>(a, B, precision, st) : launch_attn<32, true, false>(a, B, precision, st);
 }
 
