@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--nt", type=int, default=None, help="channel-attention final pass: bit0 NT loads, bit1 NT stores")
     ap.add_argument("--reverse", type=int, default=None, help="channel-attention final pass walks the batch backwards")
     ap.add_argument("--precision", type=int, default=None, help="MFMA operand precision 0 strict / 1 fp16 / 2 bf16")
+    ap.add_argument("--only", default=None, help="keep only the blocks of the workload whose name contains this text (profiling aid)")
     args = ap.parse_args()
     _extra_workloads()
 
@@ -121,6 +122,11 @@ def main():
 
     wl = WORKLOADS[args.workload](args.batch, dev)
     wname, blocks, gather = wl["name"], wl["blocks"], wl.get("gather")
+    if args.only:
+        blocks = [b for b in blocks if args.only in b["name"]]
+        wname += " [only: %s]" % args.only
+        if not blocks:
+            raise SystemExit("--only matched no block")
 
     def step():
         outs = []
