@@ -374,6 +374,145 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
 #undef PP_BAR
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight-stationary streaming GEMM for SHORT K (64 / 128: CSWin stages 1-2, where every Linear is HBM-bound): a workgroup parks
+// its BN x K slice of W in LDS once and then walks 128-row tiles of X -- A tiles double-buffered by LDS-DMA, one barrier pair per
+// tile, direct-store epilogue -- so X is read once, Y written once and W is never re-fetched per tile (the generic kernel re-loads
+// W for every 128 rows and exposes a full load->barrier->compute->store latency chain per tile: 2.2-2.6x off the streaming bound).
+// 8 waves; wave grid (8/WN) x WN with WN = BN/64, i.e. every wave owns (128*WN/8) rows x 64 columns.
+// LDS images are [k-chunk of 64][row][64] panels with the same source-side XOR swizzle as above.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T, bool OUT16, int BN, int KK>
+__global__ __launch_bounds__(512, (KK == 64 ? 4 : 2)) void gemm16_ws_kernel(const G16Args g, int workers) {
+    using v8 = typename Vec8<T>::t;
+    using v4 = typename Vec8<T>::t4;
+    constexpr int BM = 128, KC = KK / 64;
+    constexpr int WN = BN / 64, WM = 8 / WN, TM = BM / WM, MF = TM / 16, NF = 4;
+    constexpr int W_EL = BN * KK, A_EL = BM * KK;
+    constexpr int SP = 64;                                      // 16-bit output slab: 16 rows x 64 columns per wave, 16-byte chunks XOR-swizzled by row
+    constexpr int SLAB_EL = OUT16 ? 8 * 16 * SP : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(W_EL + 2 * A_EL + SLAB_EL) * 2];
+    T* sW = reinterpret_cast<T*>(lds_raw);
+    T* sAb = sW + W_EL;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    T* slab = reinterpret_cast<T*>(lds_raw) + W_EL + 2 * A_EL + wave * 16 * SP;
+    const int nt = blockIdx.x % tiles_n, worker = blockIdx.x / tiles_n;
+    const int n0 = nt * BN;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+    const int lrow = lane >> 3, pch = lane & 7, csw = (pch ^ lrow) * 8;
+
+    // W slice: BN*KC groups of 8 rows x 128 B, round-robin over the 8 waves
+    for (int i = wave; i < (BN / 8) * KC; i += 8) {
+        const int kc = i / (BN / 8), rg = i % (BN / 8);
+        int nb = n0 + rg * 8 + lrow; if (nb >= g.N) nb = g.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (long)nb * g.ldb + kc * 64 + csw),
+                                         (__attribute__((address_space(3))) void*)(sW + (kc * BN + rg * 8) * 64), 16, 0, 0);
+    }
+    auto issue_a = [&](int buf, int mt) {
+        const int m0 = mt * BM;
+        for (int i = wave; i < (BM / 8) * KC; i += 8) {
+            const int kc = i / (BM / 8), rg = i % (BM / 8);
+            int ma = m0 + rg * 8 + lrow; if (ma >= g.M) ma = g.M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)ma * g.lda + kc * 64 + csw),
+                                             (__attribute__((address_space(3))) void*)(sAb + buf * A_EL + (kc * BM + rg * 8) * 64), 16, 0, 0);
+        }
+    };
+
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7, l15 = frow, g4 = fq * 4;
+    float* Cf = static_cast<float*>(g.C);
+    T* Ch = static_cast<T*>(g.C);
+
+    int mt = worker;
+    if (mt < tiles_m) issue_a(0, mt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; mt < tiles_m; mt += workers, ++it) {
+        const int cur = it & 1;
+        if (mt + workers < tiles_m) issue_a(cur ^ 1, mt + workers);          // next tile flies under this tile's math
+        f4 acc[MF][NF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const T* pa = sAb + cur * A_EL + (kc * BM + wr * TM + frow) * 64;
+            const T* pb = sW + (kc * BN + wc * 64 + frow) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = (((ks * 4 + fq) ^ fsw) * 8);
+                v8 fa[MF], fb[NF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) fb[j] = *reinterpret_cast<const v8*>(pb + j * 16 * 64 + off);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) fa[i] = *reinterpret_cast<const v8*>(pa + i * 16 * 64 + off);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fb[j], fa[i], acc[i][j]);   // transposed tiles, see above
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // next A tile landed (and older stores retired)
+        __syncthreads();                                                      // ... for every wave; buffer `cur` is free again
+        const int m0 = mt * BM;
+        if constexpr (OUT16) {
+            // 16-bit output: 8-byte per-lane stores would touch each 128-byte line four times; go through a per-wave LDS slab
+            // (16 rows x 64 columns) instead and write whole 128-byte rows, 16 bytes per lane
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int n = n0 + wc * 64 + j * 16 + g4;
+                    f4 v = acc[i][j];
+                    if (n < g.N) {
+                        if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
+                        if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                        if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
+                        const int m = m0 + wr * TM + i * 16 + l15;
+                        if (g.resid && m < g.M) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+                    }
+                    *reinterpret_cast<v4*>(slab + l15 * SP + (((j * 2 + (fq >> 1)) ^ (l15 & 7)) * 8) + (fq & 1) * 4) =
+                        v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rl = h * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                    const int m = m0 + wr * TM + i * 16 + rl, n = n0 + wc * 64 + c8;
+                    if (m < g.M && n < g.N)                           // N % 8 == 0 on this path (launcher)
+                        *reinterpret_cast<v8*>(Ch + (long)m * g.ldc + n) =
+                            *reinterpret_cast<const v8*>(slab + rl * SP + (((lane & 7) ^ (rl & 7)) * 8));
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        } else {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + wr * TM + i * 16 + l15;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + g4;
+                if (n >= g.N) continue;
+                f4 v = acc[i][j];
+                if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);       // L1-resident, reloaded per tile to keep VGPRs <= 128
+                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
+                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+                *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
+            }
+        }
+        }
+    }
+}
+
 // fp32 -> 16-bit operand format, 8 elements per thread (2 x 16-B loads, 1 x 16-B store)
 template <typename T>
 __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, T* __restrict__ dst, long n8, long n) {
@@ -417,6 +556,30 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
     hipStream_t st = static_cast<hipStream_t>(stream);
     long variant = mi355::opt_gemm_variant();
+    if (variant == 0 && (K == 64 || K == 128) && M >= 2048 && (!out16 || (N & 7) == 0)) {       // short-K, HBM-bound: weight-stationary streaming kernel
+        int ncu = 256, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int bn = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+        const int tiles_n = cdiv(N, bn), tiles_m = cdiv(M, 128);
+        const int per_cu = (K == 64 && bn <= 256) ? 2 : 1;
+        int workers = (ncu * per_cu) / tiles_n;
+        if (workers < 1) workers = 1;
+        if (workers > tiles_m) workers = tiles_m;
+        const int grid = tiles_n * workers;
+#define WS(T_, O_, BN_, KK_) gemm16_ws_kernel<T_, O_, BN_, KK_><<<grid, 512, 0, st>>>(g, workers)
+#define WS_BY_SHAPE(T_, O_)                                                   \
+        do {                                                                  \
+            if (K == 64) { if (bn == 256) WS(T_, O_, 256, 64); else if (bn == 128) WS(T_, O_, 128, 64); else WS(T_, O_, 64, 64); }    \
+            else         { if (bn == 256) WS(T_, O_, 256, 128); else if (bn == 128) WS(T_, O_, 128, 128); else WS(T_, O_, 64, 128); } \
+        } while (0)
+        if (precision == MI355_PREC_FP16) { if (out16) WS_BY_SHAPE(_Float16, true); else WS_BY_SHAPE(_Float16, false); }
+        else                              { if (out16) WS_BY_SHAPE(__bf16, true); else WS_BY_SHAPE(__bf16, false); }
+#undef WS_BY_SHAPE
+#undef WS
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     if (variant == 0)          // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups
         variant = (N <= 64) ? 9 : (N < 256 ? 1 : 7);   // per CU; narrow outputs use 256x64 / 128x128 tiles instead
     else if (variant == 8) variant = 0;     // 8 = plain 128x128 without priority hints (tuning experiments)

@@ -297,7 +297,10 @@ def test_cast16_is_round_to_nearest_even(prec, dt):
 
 
 @pytest.mark.parametrize("prec", [1, 2])
-@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (130, 72, 64), (257, 132, 192), (64, 2304, 768), (50, 64, 256)])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (130, 72, 64), (257, 132, 192), (64, 2304, 768), (50, 64, 256),
+                                   # short-K weight-stationary kernel (M >= 2048, K in {64,128}), incl. ragged M and N
+                                   (4096, 192, 64), (3000, 64, 64), (2049, 256, 64), (5000, 384, 128), (2500, 128, 128), (2100, 68, 128),
+                                   (2304, 520, 64)])
 def test_linear16_bit_identical_to_fp32_entry(M, N, K, prec):
     """Same rounding point, same accumulation order: the 16-bit-operand GEMM must reproduce mi355_linear_fwd exactly."""
     torch.manual_seed(M + N + K)
