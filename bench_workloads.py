@@ -104,4 +104,33 @@ def workload_da(B, dev):
     return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, gather=None, dtype="f16")
 
 
-WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}
+def _full_model(ctor, title, flop_per_image, cpu_fn, B, dev):
+    m = _seeded(ctor)
+    torch.manual_seed(4321)
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    sd = _sd(m)
+
+    def gather(logits, dist):
+        from mi355attn.dist import gather_batch
+        return gather_batch(logits)
+
+    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd))]
+    return dict(name="%s full fwd, %d images per GPU, logits all-gathered" % (title, B), blocks=blocks, gather=gather, dtype="f16")
+
+
+def workload_cswin(B, dev):
+    """CSWin_64_12211_tiny_224 (cswin.py:360-363): stem conv7/4 + [1, 2, 21, 1] blocks + three conv3/2 merges + head."""
+    from mi355attn.modules import CSWin_64_12211_tiny_224
+    flop = (2.0 * 3136 * 147 * 64 + 356.9e6 + 2.0 * 784 * 576 * 128 + 2 * 332.6e6 + 2.0 * 196 * 1152 * 256 + 21 * 328.9e6
+            + 2.0 * 49 * 2304 * 512 + 313.65e6 + 2.0 * 512 * 1000)
+    return _full_model(CSWin_64_12211_tiny_224, "CSWin-T/224", flop, lambda xs, sd: O.cswin_forward(xs, sd), B, dev)
+
+
+def workload_mixer_full(B, dev):
+    """MLP_Mixer(dim 512, depth 12, patch 16) (mlp_mixer.py:53-79)."""
+    from mi355attn.modules import MLP_Mixer
+    flop = 2.0 * 196 * 768 * 512 + 12 * 924.8e6 + 2.0 * 512 * 1000
+    return _full_model(MLP_Mixer, "MLP-Mixer(512, depth 12)", flop, lambda xs, sd: O.mixer_forward(xs, sd), B, dev)
+
+
+WORKLOADS = {"cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

@@ -164,10 +164,24 @@ int    mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const flo
 /* ViT PatchEmbedding + token assembly (ViT.py:101-105,183-185):
  *   tokens[b, p, :] = patch_p(img_b) . Wp^T + bp + pos[p]   for p < P = (H/ps)*(W/ps);
  *   tokens[b, P, :] = cls + pos[P]                         (cls token LAST).
- *   img (B,Cin,H,W), Wp (E, Cin*ps*ps), bp (E), cls (E), pos (P+1,E), tokens (B,P+1,E). */
+ *   img (B,Cin,H,W), Wp (E, Cin*ps*ps), bp (E), cls (E), pos (P+1,E), tokens (B,P+1,E).
+ *   cls == pos == NULL: plain patch embedding, tokens (B,P,E)  (mlp_mixer.py:60-63). */
 int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
                           float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
                           mi355_stream_t stream);
+
+/* ---- model-level glue (callers of the blocks) ------------------------------------------------------------ */
+
+/* Conv2d as implicit GEMM, token-major output (B, OH*OW, Cout) + bias; no im2col buffer.
+ *   in_layout 0: x NCHW (B,Cin,H,W), weight rows ordered (c,ky,kx)        -- CSWin stem conv 7x7 s4 p2 (cswin.py:247-251)
+ *   in_layout 1: x token-major (B,H*W,Cin), weight rows ordered (ky,kx,c)  -- CSWin Merge_Block conv 3x3 s2 p1 (cswin.py:218-233)
+ * weight is (Cout, ldw), ldw >= Cin*KH*KW, ldw % 4 == 0, zero padded beyond Cin*KH*KW. */
+int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int H, int W,
+                            int Cout, int KH, int KW, int stride, int pad, int ldw, int in_layout, int precision,
+                            mi355_stream_t stream);
+
+/* y[b,c] = mean over n of x[b*batch_stride + n*C + c]  (cswin.py:341, mlp_mixer.py:77, ViT.py:189-190). */
+int mi355_token_mean_fwd(const float* x, float* y, int B, int N, int C, long batch_stride, mi355_stream_t stream);
 
 /* ---- measurement helpers --------------------------------------------------------------------------- */
 /* float4 streaming copy of `bytes` (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py. */

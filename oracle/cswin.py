@@ -1,5 +1,6 @@
 """Oracle (test infrastructure): CSWin LePEAttention and CSWinBlock, with explicit window index math."""
 import torch
+import torch.nn.functional as TF
 from .transformer import layernorm, gelu, linear, sdpa_core, _t, _sub
 
 
@@ -102,3 +103,31 @@ def cswin_block_forward(x, p, reso, num_heads, split_size, last_stage=False, dty
     m = _sub(p, "mlp.")
     h = gelu(linear(u, _t(m["fc1.weight"], dtype), _t(m["fc1.bias"], dtype)))
     return x + linear(h, _t(m["fc2.weight"], dtype), _t(m["fc2.bias"], dtype))
+
+
+def cswin_forward(img, p, embed_dim=64, depth=(1, 2, 21, 1), split_size=(1, 2, 7, 7), num_heads=(2, 4, 8, 16), dtype=torch.float32):
+    """CSWinTransformer.forward -- vision_transformers/cswin.py:324-346 (ctor :238-298; tiny-224 factory :360-363).
+
+    stem = Conv2d(3, C, 7, stride 4, pad 2) -> tokens (b, h*w, c) -> LayerNorm (:247-251); per stage the CSWinBlocks; between
+    stages Merge_Block = tokens -> NCHW -> Conv2d(C, 2C, 3, stride 2, pad 1) -> tokens -> LayerNorm (:224-233); final LayerNorm,
+    mean over tokens, head.  Convolutions are the ATen conv2d the reference's nn.Conv2d runs.
+    """
+    x = _t(img, dtype)
+    B, _, H, _ = x.shape
+    x = TF.conv2d(x, _t(p["stage1_conv_embed.0.weight"], dtype), _t(p["stage1_conv_embed.0.bias"], dtype), stride=4, padding=2)
+    reso = x.shape[-1]
+    x = x.flatten(2).transpose(1, 2)
+    x = layernorm(x, _t(p["stage1_conv_embed.2.weight"], dtype), _t(p["stage1_conv_embed.2.bias"], dtype))
+    for si in range(4):
+        if si > 0:
+            m = _sub(p, f"merge{si}.")
+            C = x.shape[-1]
+            grid = x.transpose(1, 2).reshape(B, C, reso, reso)
+            grid = TF.conv2d(grid, _t(m["conv.weight"], dtype), _t(m["conv.bias"], dtype), stride=2, padding=1)
+            reso = grid.shape[-1]
+            x = layernorm(grid.flatten(2).transpose(1, 2), _t(m["norm.weight"], dtype), _t(m["norm.bias"], dtype))
+        for bi in range(depth[si]):
+            x = cswin_block_forward(x, _sub(p, f"stage{si + 1}.{bi}."), reso, num_heads[si], split_size[si], last_stage=(si == 3),
+                                    dtype=dtype)
+    x = layernorm(x, _t(p["norm.weight"], dtype), _t(p["norm.bias"], dtype))
+    return linear(x.mean(dim=1), _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))

@@ -126,3 +126,12 @@ def mixer_layer_forward(x, p, dtype=torch.float32):
     u = layernorm(x, _t(p["norm2.weight"], dtype), _t(p["norm2.bias"], dtype))
     h = gelu(linear(u, _t(p["channel_mlp.fc1.weight"], dtype), _t(p["channel_mlp.fc1.bias"], dtype)))
     return x + linear(h, _t(p["channel_mlp.fc2.weight"], dtype), _t(p["channel_mlp.fc2.bias"], dtype))
+
+
+def mixer_forward(img, p, depth=12, dtype=torch.float32):
+    """MLP_Mixer.forward -- mlps/mlp_mixer.py:74-79: patch embedding (Conv k=s=patch == per-patch GEMM), `depth` MixerLayers,
+    mean over tokens, head."""
+    x = vit_patch_embed_forward(img, p["patch_embedding.proj.weight"], p["patch_embedding.proj.bias"], dtype)
+    for i in range(depth):
+        x = mixer_layer_forward(x, _sub(p, f"blocks.{i}."), dtype)
+    return linear(x.mean(dim=1), _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))

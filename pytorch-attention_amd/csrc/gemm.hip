@@ -30,8 +30,10 @@ struct GemmArgs {
     int lda, ldb, ldc;
     long sA, sB, sC;                          // batch strides (elements); 0 = shared operand
     int act, bias_per_row;
-    // AMODE 1 (patch embedding): image geometry
+    // AMODE 1 (patch embedding) / 2, 3 (convolution as implicit GEMM): image geometry
     int Cin, H, W, ps, gw, P;
+    int Pout;                                 // output rows per image (P + 1 when a cls row follows the patches, else P)
+    int KH, KW, stride, pad, OW, Kreal;       // AMODE 2 / 3 (Kreal = Cin*KH*KW; K may be padded up to a multiple of 4)
 };
 
 __device__ __forceinline__ f4 ld4_guard(const float* p, bool ok) {
@@ -79,17 +81,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int lr = t >> 3, lk = (t & 7) * 4;                 // row-within-32 and k offset for K-contiguous operands
     const float* a_ptr[4];
     bool a_ok[4];
+    int a_iy[4] = {0, 0, 0, 0}, a_ix[4] = {0, 0, 0, 0};      // AMODE 2 / 3
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lr + 32 * i;
         a_ok[i] = m < g.M;
         if constexpr (AMODE == 0) {
             a_ptr[i] = Ab + (long)(a_ok[i] ? m : 0) * g.lda;
-        } else {                                             // row m = (image, patch); k = (c, ky, kx), kx contiguous
+        } else if constexpr (AMODE == 1) {                   // row m = (image, patch); k = (c, ky, kx), kx contiguous
             const int mm = a_ok[i] ? m : 0;
             const int img = mm / g.P, p = mm % g.P;
             const int py = p / g.gw, px = p % g.gw;
             a_ptr[i] = Ab + ((long)img * g.Cin * g.H + (long)py * g.ps) * g.W + (long)px * g.ps;
+        } else {                                             // convolution: row m = (image, oy, ox); top-left input coordinate
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / g.P, p = mm % g.P;
+            a_iy[i] = (p / g.OW) * g.stride - g.pad;
+            a_ix[i] = (p % g.OW) * g.stride - g.pad;
+            a_ptr[i] = Ab + (long)img * g.Cin * g.H * g.W;   // image base (NCHW and token-major NHWC have the same size)
         }
     }
     const float* b_ptr[4];
@@ -117,11 +126,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             const int k = k0 + lk;
             if constexpr (AMODE == 0) {
                 ra[i] = ld4_guard(a_ptr[i] + k, a_ok[i] && k < g.K);
-            } else {
+            } else if constexpr (AMODE == 1) {
                 const int pp = g.ps * g.ps;
                 const int c = k / pp, rem = k % pp;
                 const int ky = rem / g.ps, kx = rem % g.ps;
                 ra[i] = ld4_guard(a_ptr[i] + ((long)c * g.H + ky) * g.W + kx, a_ok[i] && k < g.K);
+            } else if constexpr (AMODE == 2) {               // NCHW input, k = (c, ky, kx): element-wise gather, zero padding
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kq = k + q, kk2 = g.KH * g.KW;
+                    const int c = kq / kk2, rem = kq % kk2;
+                    const int iy = a_iy[i] + rem / g.KW, ix = a_ix[i] + rem % g.KW;
+                    const bool ok = a_ok[i] && kq < g.Kreal && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    e[q] = ok ? a_ptr[i][((long)c * g.H + iy) * g.W + ix] : 0.f;
+                }
+                ra[i] = f4{e[0], e[1], e[2], e[3]};
+            } else {                                         // token-major (H*W, C) input, k = (ky, kx, c): 4 channels per load
+                const int tap = k / g.Cin, c = k % g.Cin;
+                const int iy = a_iy[i] + tap / g.KW, ix = a_ix[i] + tap % g.KW;
+                const bool ok = a_ok[i] && k < g.K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                ra[i] = ld4_guard(a_ptr[i] + ((long)iy * g.W + ix) * g.Cin + c, ok);
             }
         }
         if constexpr (BMODE == 0) {
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             if (m >= g.M || n >= g.N) continue;
             f4 v = *reinterpret_cast<const f4*>(slab + rl * EPITCH + cl);
             long orow = m;
-            if constexpr (AMODE == 1) orow = (long)(m / g.P) * (g.P + 1) + (m % g.P);
+            if constexpr (AMODE == 1) orow = (long)(m / g.P) * g.Pout + (m % g.P);
             const bool full = vec_ok && (n + 3 < g.N);
             float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 if (n + c >= g.N) break;
                 float z = vv[c];
                 if (g.bias) z += g.bias_per_row ? g.bias[m] : g.bias[n + c];
-                if constexpr (AMODE == 1) z += g.pos[(long)(m % g.P) * g.N + n + c];
+                if constexpr (AMODE == 1) { if (g.pos) z += g.pos[(long)(m % g.P) * g.N + n + c]; }
                 if (g.act == MI355_ACT_GELU) z = gelu_fast(z);
                 if (g.gamma) z *= g.gamma[n + c];
                 if (Rb) z += Rb[orow * g.ldc + n + c];
@@ -321,7 +346,8 @@ int mi355_token_mix_fwd(const float* W, const float* X, const float* bias, const
 
 int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos, float* tokens,
                           int B, int Cin, int H, int W, int ps, int E, int precision, mi355_stream_t stream) {
-    MI355_CHECK_ARG(img && Wp && bp && cls && pos && tokens);
+    MI355_CHECK_ARG(img && Wp && bp && tokens);
+    MI355_CHECK_ARG((cls == nullptr) == (pos == nullptr));     // both (ViT: cls row + position embedding) or neither (plain patches)
     MI355_CHECK_ARG(B > 0 && Cin > 0 && ps > 0 && E > 0 && H >= ps && W >= ps && H % ps == 0 && W % ps == 0);
     if ((ps & 3) || (W & 3) || !aligned16(img) || !aligned16(Wp))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_patch_embed_fwd: patch size and image width must be multiples of 4");
@@ -332,10 +358,40 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
     g.A = img; g.B = Wp; g.C = tokens; g.bias = bp; g.pos = pos;
     g.M = B * g.P; g.N = E; g.K = Cin * ps * ps; g.lda = 0; g.ldb = g.K; g.ldc = E;
     g.Cin = Cin; g.H = H; g.W = W; g.ps = ps;
+    g.Pout = cls ? g.P + 1 : g.P;
     int rc = launch<0, 1>(g, 1, precision, st);
     if (rc) return rc;
-    const long n = (long)B * E;
-    cls_row_kernel<<<cdiv(n, 256), 256, 0, st>>>(cls, pos, tokens, B, g.P, E);
+    if (cls) {
+        const long n = (long)B * E;
+        cls_row_kernel<<<cdiv(n, 256), 256, 0, st>>>(cls, pos, tokens, B, g.P, E);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+// Conv2d as implicit GEMM (no im2col buffer): rows = output pixels, K = Cin*KH*KW gathered in the A-operand load with zero padding.
+//   in_layout 0: x is NCHW (B,Cin,H,W),            weight rows in (c,ky,kx) order   -- CSWin stem (cswin.py:247-251)
+//   in_layout 1: x is token-major (B, H*W, Cin),   weight rows in (ky,kx,c) order   -- CSWin Merge_Block (:218-233)
+// weight is (Cout, ldw) with ldw >= Cin*KH*KW, ldw % 4 == 0 and ZERO padding beyond Cin*KH*KW.  y is token-major
+// (B, OH*OW, Cout) fp32, + bias.
+int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                            int KH, int KW, int stride, int pad, int ldw, int in_layout, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    MI355_CHECK_ARG(in_layout == 0 || in_layout == 1);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    MI355_CHECK_ARG(OH > 0 && OW > 0);
+    const int Kreal = Cin * KH * KW, K = (Kreal + 3) & ~3;
+    MI355_CHECK_ARG(ldw >= K && (ldw & 3) == 0);
+    if (!aligned16(x) || !aligned16(weight) || (in_layout == 1 && (Cin & 3)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_conv2d_tokens_fwd: 16-byte aligned buffers and, for token-major input, Cin %% 4 == 0 (Cin=%d)", Cin);
+    GemmArgs g{};
+    g.A = x; g.B = weight; g.C = y; g.bias = bias;
+    g.P = OH * OW; g.Pout = g.P; g.OW = OW; g.Kreal = Kreal;
+    g.M = B * g.P; g.N = Cout; g.K = K; g.lda = 0; g.ldb = ldw; g.ldc = Cout;
+    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = in_layout == 0 ? launch<0, 2>(g, 1, precision, st) : launch<0, 3>(g, 1, precision, st);
+    if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

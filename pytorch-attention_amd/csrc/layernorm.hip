@@ -138,3 +138,29 @@ int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias
 }
 
 }  // extern "C"
+
+// mean over the token axis: y[b, c] = (1/N) sum_n x[b*batch_stride + n*C + c]   (CSWin head cswin.py:341, Mixer head mlp_mixer.py:77,
+// ViT global_pool="avg" ViT.py:189-190 via an offset base pointer).  One workgroup per (image, 256-channel slab).
+namespace {
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, long batch_stride,
+                                                        int slabs) {
+    const int b = blockIdx.x / slabs, c = (blockIdx.x % slabs) * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* p = x + (long)b * batch_stride + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+        s0 += p[(long)n * C]; s1 += p[(long)(n + 1) * C]; s2 += p[(long)(n + 2) * C]; s3 += p[(long)(n + 3) * C];
+    }
+    for (; n < N; ++n) s0 += p[(long)n * C];
+    y[(long)b * C + c] = ((s0 + s1) + (s2 + s3)) / (float)N;
+}
+}  // namespace
+
+extern "C" int mi355_token_mean_fwd(const float* x, float* y, int B, int N, int C, long batch_stride, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && y && B > 0 && N > 0 && C > 0 && batch_stride >= (long)N * C);
+    const int slabs = cdiv(C, 256);
+    token_mean_kernel<<<B * slabs, 256, 0, static_cast<hipStream_t>(stream)>>>(x, y, N, C, batch_stride, slabs);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}

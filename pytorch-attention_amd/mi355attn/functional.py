@@ -343,15 +343,73 @@ def patch_embed(img, wp, bp, cls, pos, patch, precision=None):
     wp = require_device_f32(wp, "proj.weight")
     E = wp.shape[0]
     wp = wp.reshape(E, -1)
-    bp, cls, pos = (require_device_f32(t, n) for t, n in ((bp, "proj.bias"), (cls, "cls_token"), (pos, "pos")))
+    bp = require_device_f32(bp, "proj.bias")
+    cls, pos = _opt(cls, "cls_token"), _opt(pos, "pos")
     B, Cin, H, W = img.shape
     P = (H // patch) * (W // patch)
-    if pos.numel() != (P + 1) * E:
+    if (cls is None) != (pos is None):
+        raise ValueError("patch_embed: pass both cls and pos (ViT) or neither (plain patches)")
+    if pos is not None and pos.numel() != (P + 1) * E:
         raise ValueError("patch_embed: position embedding does not match the patch grid")
-    tokens = torch.empty(B, P + 1, E, dtype=torch.float32, device=img.device)
+    tokens = torch.empty(B, P + (1 if cls is not None else 0), E, dtype=torch.float32, device=img.device)
     check(lib().mi355_patch_embed_fwd(dptr(img), dptr(wp), dptr(bp), dptr(cls), dptr(pos), dptr(tokens), B, Cin, H, W,
                                       patch, E, _prec(precision), stream_ptr(img.device)), "mi355_patch_embed_fwd")
     return tokens
+
+
+_wrow_cache = {}
+
+
+def conv_weight_rows(param, in_layout):
+    """Weight of a Conv2d as the GEMM operand of mi355_conv2d_tokens_fwd: (Cout, ldw) rows, zero padded to ldw % 4 == 0,
+    K ordered (c,ky,kx) for NCHW input (in_layout 0) or (ky,kx,c) for token-major input (in_layout 1).  A parameter layout
+    transform done once per parameter version (like weight16)."""
+    key = (id(param), in_layout)
+    tag = (param._version, param.data_ptr(), tuple(param.shape))
+    hit = _wrow_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w = param.detach()
+    cout = w.shape[0]
+    rows = (w if in_layout == 0 else w.permute(0, 2, 3, 1)).reshape(cout, -1)
+    k = rows.shape[1]
+    ldw = (k + 3) // 4 * 4
+    out = torch.zeros(cout, ldw, dtype=torch.float32, device=w.device)
+    out[:, :k] = rows
+    _wrow_cache[key] = (tag, out)
+    return out
+
+
+def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, precision=None):
+    """Conv2d -> token-major (B, OH*OW, Cout).  x is NCHW (in_layout 0) or tokens (B, H*W, Cin) with hw=(H, W) (in_layout 1)."""
+    x = require_device_f32(x, "x")
+    if in_layout == 0:
+        B, Cin, H, W = x.shape
+    else:
+        B, L, Cin = x.shape
+        H, W = hw
+        if L != H * W:
+            raise ValueError("conv2d_tokens: token count does not match hw")
+    wrows = conv_weight_rows(weight, in_layout)
+    Cout = wrows.shape[0]
+    bias = _opt(bias, "bias")
+    OH = (H + 2 * pad - kernel) // stride + 1
+    OW = (W + 2 * pad - kernel) // stride + 1
+    y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=x.device)
+    check(lib().mi355_conv2d_tokens_fwd(dptr(x), dptr(wrows), dptr(bias), dptr(y), B, Cin, H, W, Cout, kernel, kernel, stride, pad,
+                                        wrows.shape[1], in_layout, _prec(precision), stream_ptr(x.device)),
+          "mi355_conv2d_tokens_fwd")
+    return y, (OH, OW)
+
+
+def token_mean(x, skip_first=0):
+    """Mean over the token axis of x (B,N,C), optionally skipping the first `skip_first` tokens."""
+    x = require_device_f32(x, "x")
+    B, N, C = x.shape
+    y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    base = ctypes.c_void_p(x.data_ptr() + skip_first * C * 4)
+    check(lib().mi355_token_mean_fwd(base, dptr(y), B, N - skip_first, C, N * C, stream_ptr(x.device)), "mi355_token_mean_fwd")
+    return y
 
 
 def stream_copy(src, dst):

@@ -1,5 +1,6 @@
 from .chan_attn import CBAM, ChannelAttention, DoubleAttention, ECALayer, SELayer, SpatialAttention  # noqa: F401
-from .cswin import CSWinBlock, LePEAttention  # noqa: F401
-from .mixer import MixerLayer  # noqa: F401
+from .cswin import (CSWin_64_12211_tiny_224, CSWin_64_24322_small_224, CSWinBlock, CSWinTransformer,  # noqa: F401
+                    LePEAttention, Merge_Block)
+from .mixer import MLP_Mixer, MixerLayer  # noqa: F401
 from .vit import Attention, PatchEmbedding, TransformerEncoder, VisionTransformer  # noqa: F401
 from .xcit import LPI, XCA, XCABlock  # noqa: F401

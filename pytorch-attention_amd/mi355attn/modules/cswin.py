@@ -115,3 +115,93 @@ class CSWinBlock(nn.Module):
             x = F.linear(att, self.proj.weight, self.proj.bias, resid=x, precision=self.precision)
             u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp(u, resid=x)
+
+
+class Merge_Block(nn.Module):
+    """cswin.py:218-233: conv 3x3 stride 2 between stages, as an implicit GEMM straight on the token-major activations."""
+
+    def __init__(self, dim, dim_out, norm_layer=nn.LayerNorm, precision=None):
+        super().__init__()
+        self.conv = nn.Conv2d(dim, dim_out, 3, 2, 1)
+        self.norm = norm_layer(dim_out)
+        self.precision = precision
+
+    def forward(self, x):
+        B, L, C = x.shape
+        H = W = int(round(L ** 0.5))
+        y, _ = F.conv2d_tokens(x, self.conv.weight, self.conv.bias, 3, 2, 1, in_layout=1, hw=(H, W), precision=self.precision)
+        return F.layernorm(y, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class CSWinTransformer(nn.Module):
+    """Full CSWin (cswin.py:235-346): stem conv 7x7/4 + LN, four stages of CSWinBlocks with Merge_Blocks between, LN, token mean,
+    head.  Same constructor, state_dict and init stream as the reference (activation checkpointing is a training feature: ignored)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=96, depth=[2, 2, 6, 2],
+                 split_size=[3, 5, 7], num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 hybrid_backbone=None, norm_layer=nn.LayerNorm, use_chk=False, precision=None):
+        super().__init__()
+        self.use_chk = use_chk
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.precision = precision
+        heads = num_heads
+        self.stage1_conv_embed = nn.Sequential(nn.Conv2d(in_chans, embed_dim, 7, 4, 2), nn.Identity(), nn.LayerNorm(embed_dim))
+
+        def stage(dim, n, head, reso, split, last=False):
+            return nn.ModuleList([CSWinBlock(dim=dim, num_heads=head, reso=reso, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                             qk_scale=qk_scale, split_size=split, drop=drop_rate, attn_drop=attn_drop_rate,
+                                             norm_layer=norm_layer, last_stage=last, precision=precision) for _ in range(n)])
+
+        d = embed_dim
+        self.stage1 = stage(d, depth[0], heads[0], img_size // 4, split_size[0])
+        self.merge1 = Merge_Block(d, d * 2, precision=precision)
+        d *= 2
+        self.stage2 = stage(d, depth[1], heads[1], img_size // 8, split_size[1])
+        self.merge2 = Merge_Block(d, d * 2, precision=precision)
+        d *= 2
+        self.stage3 = stage(d, depth[2], heads[2], img_size // 16, split_size[2])
+        self.merge3 = Merge_Block(d, d * 2, precision=precision)
+        d *= 2
+        self.stage4 = stage(d, depth[-1], heads[3], img_size // 32, split_size[-1], last=True)
+        self.norm = norm_layer(d)
+        self.head = nn.Linear(d, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, nn.BatchNorm2d)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward_features(self, x):
+        stem, ln = self.stage1_conv_embed[0], self.stage1_conv_embed[2]
+        x, _ = F.conv2d_tokens(x, stem.weight, stem.bias, 7, 4, 2, in_layout=0, precision=self.precision)
+        x = F.layernorm(x, ln.weight, ln.bias, ln.eps)
+        for blk in self.stage1:
+            x = blk(x)
+        for pre, blocks in ((self.merge1, self.stage2), (self.merge2, self.stage3), (self.merge3, self.stage4)):
+            x = pre(x)
+            for blk in blocks:
+                x = blk(x)
+        x = F.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return F.token_mean(x)
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        if isinstance(self.head, nn.Identity):
+            return x
+        return F.linear(x, self.head.weight, self.head.bias, precision=self.precision)
+
+
+def CSWin_64_12211_tiny_224(pretrained=False, **kwargs):
+    return CSWinTransformer(patch_size=4, embed_dim=64, depth=[1, 2, 21, 1], split_size=[1, 2, 7, 7], num_heads=[2, 4, 8, 16],
+                            mlp_ratio=4., **kwargs)
+
+
+def CSWin_64_24322_small_224(pretrained=False, **kwargs):
+    return CSWinTransformer(patch_size=4, embed_dim=64, depth=[2, 4, 32, 2], split_size=[1, 2, 7, 7], num_heads=[2, 4, 8, 16],
+                            mlp_ratio=4., **kwargs)

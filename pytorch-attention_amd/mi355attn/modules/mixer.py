@@ -44,3 +44,37 @@ class MixerLayer(nn.Module):
         else:
             u = F.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return c(u, resid=x)
+
+
+class PatchEmbedding(nn.Module):
+    """mlp_mixer.py:52-63 (the argument really is spelled `in_chanels` in the reference)."""
+
+    def __init__(self, image_size, patch_size, in_chanels=3, embedding_dim=768):
+        super().__init__()
+        assert image_size % patch_size == 0
+        self.patch_size = patch_size
+        self.num_patches = (image_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chanels, embedding_dim, kernel_size=patch_size, stride=patch_size)
+        self.precision = None
+
+    def forward(self, x):
+        return F.patch_embed(x, self.proj.weight, self.proj.bias, None, None, self.patch_size, self.precision)
+
+
+class MLP_Mixer(nn.Module):
+    """Full MLP-Mixer (mlp_mixer.py:65-79): patch GEMM -> `depth` MixerLayers -> token mean -> head."""
+
+    def __init__(self, dim=512, depth=12, image_size=224, patch_size=16, in_channels=3, drop=0, num_classes=1000, precision=None):
+        super().__init__()
+        self.patch_embedding = PatchEmbedding(image_size, patch_size, in_channels, dim)
+        self.patch_embedding.precision = precision
+        self.blocks = nn.Sequential(*[MixerLayer(dim, self.patch_embedding.num_patches, drop=drop, precision=precision)
+                                      for _ in range(depth)])
+        self.head = nn.Linear(dim, num_classes)
+        self.precision = precision
+
+    def forward(self, x):
+        x = self.patch_embedding(x)
+        for blk in self.blocks:
+            x = blk(x)
+        return F.linear(F.token_mean(x), self.head.weight, self.head.bias, precision=self.precision)

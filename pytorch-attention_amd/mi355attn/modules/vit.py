@@ -86,13 +86,7 @@ class PatchEmbedding(nn.Module):
         self.precision = None
 
     def forward(self, x):
-        E = self.proj.weight.shape[0]
-        B, _, H, W = x.shape
-        P = (H // self.patch_size) * (W // self.patch_size)
-        # stand-alone use: no cls/pos -> feed zeros and drop the extra token
-        zeros = torch.zeros(P + 1, E, dtype=torch.float32, device=x.device)
-        tok = F.patch_embed(x, self.proj.weight, self.proj.bias, zeros[0], zeros, self.patch_size, self.precision)
-        return tok[:, :P]
+        return F.patch_embed(x, self.proj.weight, self.proj.bias, None, None, self.patch_size, self.precision)
 
 
 class TransformerEncoder(nn.Module):
@@ -160,7 +154,7 @@ class VisionTransformer(nn.Module):
         if self.global_pool == "token":
             pooled = tok[:, 0]                                   # row-strided view, consumed in place by the GEMM
         elif self.global_pool == "avg":
-            pooled = tok[:, 1:].mean(dim=1)
+            pooled = F.token_mean(tok, skip_first=1)
         else:
             raise ValueError(self.global_pool)
         return F.linear(pooled, self.head.weight, self.head.bias, precision=self.precision)

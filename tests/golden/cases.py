@@ -63,6 +63,11 @@ CASES = [
     # ---- MLP-Mixer (a16) ---------------------------------------------------------------------------
     dict(id="mixer", mod="mlps.mlp_mixer", cls="MixerLayer", args=(512, 196), shape=(2, 196, 512),
          oracle=lambda x, sd, dt: O.mixer_layer_forward(x, sd, dt)),
+    # ---- full models around the blocks -------------------------------------------------
+    dict(id="cswin_tiny_full", mod="vision_transformers.cswin", cls="CSWin_64_12211_tiny_224", shape=(2, 3, 224, 224), slow=True,
+         oracle=lambda x, sd, dt: O.cswin_forward(x, sd, dtype=dt)),
+    dict(id="mixer_full", mod="mlps.mlp_mixer", cls="MLP_Mixer", shape=(2, 3, 224, 224), slow=True,
+         oracle=lambda x, sd, dt: O.mixer_forward(x, sd, 12, dt)),
 ]
 
 BY_ID = {c["id"]: c for c in CASES}

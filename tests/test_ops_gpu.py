@@ -113,6 +113,69 @@ def test_patch_embed(B, Cin, HW, ps, E, prec):
     assert_parity(tok, ref.float(), TOL[prec], "patch_embed")
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+def test_patch_embed_without_cls_and_pos(prec):
+    """MLP-Mixer's PatchEmbedding (mlps/mlp_mixer.py:11-23): same gather GEMM, no cls row, no position add."""
+    torch.manual_seed(5)
+    img = torch.randn(2, 3, 64, 64)
+    w, b = torch.randn(96, 3, 16, 16) / math.sqrt(768), torch.randn(96)
+    tok = F().patch_embed(img.cuda(), w.cuda(), b.cuda(), None, None, 16, precision=prec).cpu()
+    assert tok.shape == (2, 16, 96)
+    assert_parity(tok, O.vit_patch_embed_forward(img, w, b, torch.float64).float(), TOL[prec], "patch_embed[no cls]")
+
+
+CONVS = [  # B, Cin, H, W, Cout, k, stride, pad
+    (2, 3, 224, 224, 64, 7, 4, 2),        # CSWin stem (cswin.py:247): K = 147, padded to 148 weight columns
+    (2, 64, 56, 56, 128, 3, 2, 1),        # Merge_Block 1 (cswin.py:224-233)
+    (3, 256, 14, 14, 512, 3, 2, 1),       # Merge_Block 3: 14 -> 7
+    (1, 5, 9, 11, 20, 3, 1, 1),           # ragged: odd sizes, stride 1, Cin not a multiple of 4
+    (2, 8, 6, 6, 12, 3, 2, 0),            # no padding
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,pad", CONVS)
+def test_conv2d_tokens(B, Cin, H, W, Cout, k, stride, pad, layout, prec):
+    """Implicit-GEMM convolution against ATen conv2d in fp64; input NCHW (layout 0) or token-major (layout 1)."""
+    torch.manual_seed(Cin * 7 + k)
+    img = torch.randn(B, Cin, H, W)
+    w, b = torch.randn(Cout, Cin, k, k) / math.sqrt(Cin * k * k), torch.randn(Cout)
+    ref = torch.nn.functional.conv2d(img.double(), w.double(), b.double(), stride=stride, padding=pad)
+    OH, OW = ref.shape[-2:]
+    ref = ref.flatten(2).transpose(1, 2)
+    wp = torch.nn.Parameter(w.cuda())
+    if layout == 0:
+        y, hw = F().conv2d_tokens(img.cuda(), wp, b.cuda(), k, stride, pad, 0, precision=prec)
+    else:
+        tokens = img.flatten(2).transpose(1, 2).contiguous().cuda()
+        if Cin % 4:                                   # token-major gathers are 16-byte channel runs: documented restriction
+            with pytest.raises(mi355attn.Mi355Error, match="Cin % 4"):
+                F().conv2d_tokens(tokens, wp, b.cuda(), k, stride, pad, 1, hw=(H, W), precision=prec)
+            return
+        y, hw = F().conv2d_tokens(tokens, wp, b.cuda(), k, stride, pad, 1, hw=(H, W), precision=prec)
+    assert hw == (OH, OW) and y.shape == (B, OH * OW, Cout)
+    assert_parity(y.cpu(), ref.float(), TOL[prec], f"conv2d_tokens[layout {layout}]")
+
+
+def test_conv2d_tokens_border_is_zero_padding():
+    """All-ones input and weights, no bias: every output equals the count of in-bounds taps (exact small integers)."""
+    x = torch.ones(1, 4, 6, 6)
+    w = torch.nn.Parameter(torch.ones(8, 4, 3, 3).cuda())
+    ref = torch.nn.functional.conv2d(x, torch.ones(8, 4, 3, 3), None, stride=2, padding=1).flatten(2).transpose(1, 2)
+    for layout, inp, hw in ((0, x.cuda(), None), (1, x.flatten(2).transpose(1, 2).contiguous().cuda(), (6, 6))):
+        y, _ = F().conv2d_tokens(inp, w, None, 3, 2, 1, layout, hw=hw, precision=1)
+        assert torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,N,C,skip", [(2, 196, 512, 0), (3, 197, 768, 1), (1, 49, 512, 0), (2, 5, 36, 2), (1, 1, 4, 0), (2, 3136, 64, 0)])
+def test_token_mean(B, N, C, skip):
+    torch.manual_seed(N)
+    x = torch.randn(B, N, C)
+    y = F().token_mean(x.cuda(), skip_first=skip).cpu()
+    assert_parity(y, x[:, skip:].double().mean(dim=1).float(), 1e-6, "token_mean")
+
+
 # ---------------------------------------------------------------------------------------------- attention cores
 def _sdpa_ref(qkv, h, scale):
     B, N, C3 = qkv.shape
