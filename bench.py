@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--nt", type=int, default=None, help="channel-attention final pass: bit0 NT loads, bit1 NT stores")
     ap.add_argument("--reverse", type=int, default=None, help="channel-attention final pass walks the batch backwards")
     ap.add_argument("--precision", type=int, default=None, help="MFMA operand precision 0 strict / 1 fp16 / 2 bf16")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="mi355_set_option override (tuning experiments)")
     ap.add_argument("--only", default=None, help="keep only the blocks of the workload whose name contains this text (profiling aid)")
     args = ap.parse_args()
     _extra_workloads()
@@ -117,6 +118,9 @@ def main():
         mi355attn.set_option("nt", args.nt)
     if args.reverse is not None:
         mi355attn.set_option("reverse", args.reverse)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        mi355attn.set_option(key, int(val))
     if args.precision is not None:
         mi355attn.set_default_precision(args.precision)
 

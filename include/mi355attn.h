@@ -58,6 +58,11 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "fused"         0 = two streaming passes (default); 1 = experimental single-pass register-resident SE/ECA kernel for
  *                   large shapes (x read once; measured slower on MI355X -- inter-workgroup hand-off latency),
  *                   2 = single pass whenever the shape is supported, regardless of size (tests).
+ *   "se_single"     1 (default) = SE reads x once: 8 channel rows per workgroup stay in registers, the image's channel means are
+ *                   exchanged between its workgroups as 8-byte {mean, tag} granules (one write-through store each, polled with
+ *                   bounded sweeps); 0 = two passes (pool, then gate + scale).
+ *   "eca_single"    1 (default) = ECA reads x once: a workgroup keeps 8 channel rows in registers and re-sums the k-1 halo
+ *                   rows next to them (served by the same XCD's L2), no exchange between workgroups; 0 = two passes.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);

@@ -11,6 +11,9 @@ static std::atomic<long> g_reverse{0};
 static std::atomic<long> g_gemm_variant{0};   // tile/schedule variant of the 16-bit GEMM (gemm16.hip)
 static std::atomic<long> g_fused{0};     // experimental single-pass SE/ECA kernel (measured 4x slower than two passes: DESIGN.md 6.1)
 
+static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
+static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
+
 char* err_buf() { return g_err; }
 
 int fail(int code, const char* fmt, ...) {
@@ -24,6 +27,8 @@ long opt_chunk_images() { return g_chunk_images.load(std::memory_order_relaxed);
 long opt_nt() { return g_nt.load(std::memory_order_relaxed); }
 long opt_reverse() { return g_reverse.load(std::memory_order_relaxed); }
 long opt_fused() { return g_fused.load(std::memory_order_relaxed); }
+long opt_eca_single() { return g_eca_single.load(std::memory_order_relaxed); }
+long opt_se_single() { return g_se_single.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
@@ -58,6 +63,16 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_fused.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "eca_single") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_eca_single.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
+    if (std::strcmp(key, "se_single") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_se_single.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "reverse") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_reverse.store(value, std::memory_order_relaxed);
@@ -72,6 +87,8 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "reverse") == 0) return mi355::opt_reverse();
     if (key && std::strcmp(key, "fused") == 0) return mi355::opt_fused();
     if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
+    if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
+    if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
     return -1;
 }

@@ -447,7 +447,9 @@ extern "C" {
 
 // workspace: pooled means [B*C] (rounded to 16 B) | single-pass sync state (arrive[B], ticket, err)
 static inline size_t pooled_bytes(int B, int C) { return (((size_t)B * C * sizeof(float)) + 15) & ~(size_t)15; }
-size_t mi355_se_workspace_bytes(int B, int C, int, int) { return pooled_bytes(B, C) + mi355::fused_state_bytes(B); }
+size_t mi355_se_workspace_bytes(int B, int C, int, int) {
+    return pooled_bytes(B, C) + mi355::fused_state_bytes(B) + mi355::se_single_extra_bytes(B, C);
+}
 size_t mi355_eca_workspace_bytes(int B, int C, int, int) { return pooled_bytes(B, C) + mi355::fused_state_bytes(B); }
 
 static int se_eca_common(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr,
@@ -460,6 +462,12 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
     if (vec && mi355::opt_fused() && mi355::fused_applicable(B, C, H, W))      // x read once, y written once
         return mi355::se_eca_fused(mode, x, wa, wb, y, B, C, Cr, H, W, pooled, static_cast<char*>(ws) + pooled_bytes(B, C), st);
+    if (mode == 0 && vec && mi355::se_single_applicable(C, Cr, H, W)) {       // SE: x read once, means exchanged as tagged granules
+        char* state = static_cast<char*>(ws) + pooled_bytes(B, C);
+        return mi355::se_single(x, wa, wb, y, B, C, Cr, H, W, state, state + mi355::fused_state_bytes(B), st);
+    }
+    if (mode == 1 && vec && mi355::eca_single_applicable(C, Cr, H, W))         // ECA: x read once, no exchange between workgroups
+        return mi355::eca_single(x, wa, y, B, C, Cr, H, W, st);
     const Tune tu = resolve_tune(B, (long)C * HW * 4);
     for (int b0 = 0; b0 < B; b0 += tu.chunk) {
         const int nb = (B - b0 < tu.chunk) ? B - b0 : tu.chunk;

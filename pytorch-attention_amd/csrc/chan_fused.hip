@@ -137,6 +137,199 @@ __global__ __launch_bounds__(256) void se_eca_fused_kernel(const FusedArgs a) {
     }
 }
 
+// ---- ECA without any cross-workgroup exchange ------------------------------------------------------------------------------
+// The ECA gate of channel c only needs the means of channels c-pad..c+pad (eca.py:26-30, k taps, zero padding).  A workgroup
+// therefore keeps ECW = 8 channel rows in registers (one per wave) and additionally SUMS the 2*pad halo rows next to its slab
+// (streamed, not kept).  Slices are numbered so that the workgroups an XCD receives (blockIdx % 8) own consecutive channel
+// groups: the halo rows of one workgroup are the resident rows of its neighbours on the same XCD at the same moment, so the
+// second request for a row is served by that XCD's L2 and the fabric/HBM traffic stays at one read + one write of x.
+// Every mean -- own row or halo row -- is accumulated by ONE wave in the same lane/step order, so the value of mean(b,c) does
+// not depend on which workgroup computes it.
+constexpr int ECW = 8;
+
+template <int NV, bool NTL, bool NTS>
+__global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                          float* __restrict__ y, int C, int k, int HW, int n4, int gpi, int total,
+                                                          int per_xcd) {
+    __shared__ float s_mean[ECW + 8];                        // means of channels c0-pad .. c0+ECW+pad-1
+    const int s = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (s >= total) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int pad = (k - 1) >> 1;
+    const int b = s / gpi, c0 = (s - b * gpi) * ECW;
+    const float inv = 1.0f / (float)HW;
+    const float* img = x + (long)b * C * HW;
+
+    // own row -> registers
+    v4f r[NV];
+    const v4f* xr = reinterpret_cast<const v4f*>(img + (long)(c0 + wave) * HW);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n4) r[j] = NTL ? __builtin_nontemporal_load(&xr[i]) : xr[i];
+        else r[j] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    // halo row of this wave (if any): same lane/step order as an own row, streamed
+    int hc = -1, hslot = 0;
+    if (wave < 2 * pad) {
+        hc = (wave < pad) ? c0 - pad + wave : c0 + ECW + (wave - pad);
+        hslot = (wave < pad) ? wave : ECW + wave;
+    }
+    const bool halo_live = hc >= 0 && hc < C;                 // wave-uniform
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+    if (halo_live) {
+        const v4f* hr = reinterpret_cast<const v4f*>(img + (long)hc * HW);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < n4) {
+                const v4f v = hr[i];
+                h0 += v.x; h1 += v.y; h2 += v.z; h3 += v.w;
+            }
+        }
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
+    const float mean = wave_sum((s0 + s1) + (s2 + s3)) * inv;
+    if (lane == 0) s_mean[pad + wave] = mean;
+    if (wave < 2 * pad) {
+        const float hm = halo_live ? wave_sum((h0 + h1) + (h2 + h3)) * inv : 0.f;
+        if (lane == 0) s_mean[hslot] = hm;
+    }
+    __syncthreads();
+    float z = 0.f;
+    for (int j = 0; j < k; ++j) z += taps[j] * s_mean[wave + j];
+    const float g = sigmoidf_(z);
+    v4f* yr = reinterpret_cast<v4f*>(y + ((long)b * C + c0 + wave) * HW);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n4) {
+            if (NTS) __builtin_nontemporal_store(r[j] * g, &yr[i]);
+            else yr[i] = r[j] * g;
+        }
+    }
+}
+
+// ---- SE, x read once: register-resident rows + data-tagged granules --------------------------------------------------------------
+// Same geometry as the ECA kernel above (8 waves = 8 channel rows held in registers, two workgroups per CU), but the SE gate
+// needs the means of ALL channels of the image.  Each wave publishes its mean as ONE naturally aligned 8-byte {mean, tag}
+// granule with a single sc1 (write-through) store -- data and "ready" travel together, so there is no flag, no drain and no
+// arrival counter (MI355X_MICROARCH.md price list: handoff-1to1 / allgather rows).  Every workgroup of the image then sweeps
+// the image's C granules with sc1 loads (one per thread) until all tags match, computes the excitation MLP redundantly
+// (C*Cr MACs) and scales its rows from registers.  Slices are handed out in image order by a ticket that is prefetched one
+// slice ahead, so progress needs only C/8 running workgroups and never a particular placement.  The granule array is
+// zeroed by a memset node before the launch; the tag is a non-zero constant.  Polls are bounded (error word).
+constexpr u32 GRAN_TAG = 0x5EC0DE01u;
+typedef unsigned long long u64;
+
+struct SeSingleArgs {
+    const float* x; float* y; const float* w1; const float* w2;
+    u64* gran; u32* ticket; u32* err;
+    int C, Cr, HW, n4, gpi, total;
+};
+
+template <int NV, bool NTS, bool WLDS>
+__global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // p[C] | h[Cr] | (WLDS: W1[Cr*C] | W2[C*Cr])
+    __shared__ u32 s_tk[2];
+    float* s_p = smem;
+    float* s_h = smem + a.C;
+    float* s_w1 = s_h + a.Cr;
+    float* s_w2 = s_w1 + a.Cr * a.C;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float inv = 1.0f / (float)a.HW;
+    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+    if (WLDS) {                                                       // both weight matrices stay in LDS for every slice
+        const int nw = a.Cr * a.C;
+        for (int i = t; i < nw; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
+    }
+    int par = 0;
+    for (;;) {
+        __syncthreads();
+        const u32 tk = s_tk[par];
+        if (tk >= (u32)a.total) return;
+        const int b = tk / a.gpi, c0 = (tk - b * a.gpi) * ECW;
+        const long row = ((long)b * a.C + c0 + wave) * a.HW;
+        v4f r[NV];
+        const v4f* xr = reinterpret_cast<const v4f*>(a.x + row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            r[j] = (i < a.n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
+        const float mean = wave_sum((s0 + s1) + (s2 + s3)) * inv;
+        u64* gb = a.gran + (long)b * a.C;
+        if (lane == 0)
+            __hip_atomic_store(gb + c0 + wave, ((u64)GRAN_TAG << 32) | (u64)__float_as_uint(mean), AGENT_RLX);
+
+        // sweep the image's granules until every tag is in
+        u32 spins = 0;
+        bool mine_done = false;                                        // C <= 512: one granule per thread; larger C loops
+        for (;;) {
+            bool ok = true;
+            if (a.C <= 512) {
+                if (t < a.C && !mine_done) {
+                    const u64 g = __hip_atomic_load(gb + t, AGENT_RLX);
+                    if ((u32)(g >> 32) == GRAN_TAG) { s_p[t] = __uint_as_float((u32)g); mine_done = true; }
+                    else ok = false;
+                }
+            } else {
+                for (int cc = t; cc < a.C; cc += 512) {
+                    const u64 g = __hip_atomic_load(gb + cc, AGENT_RLX);
+                    if ((u32)(g >> 32) == GRAN_TAG) s_p[cc] = __uint_as_float((u32)g);
+                    else ok = false;
+                }
+            }
+            if (__syncthreads_and(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) {
+                if (t == 0) __hip_atomic_store(a.err, 1u, AGENT_RLX);
+                break;
+            }
+        }
+        // Next slice's ticket: only now, when this workgroup no longer waits for anybody -- a workgroup that held an unprocessed
+        // ticket of the image it is still waiting for would deadlock.  Its latency hides behind the MLP and the stores.
+        if (t == 0) s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+        // excitation: h = relu(W1 p) (16 lanes per hidden unit), g = sigmoid(W2[c,:] h) (one wave per channel)
+        const float* w1 = WLDS ? s_w1 : a.w1;
+        const float* w2 = WLDS ? s_w2 : a.w2;
+        const int part = t & 15, jl = t >> 4;
+        for (int j0 = 0; j0 < a.Cr; j0 += 32) {
+            const int j = j0 + jl;
+            float acc = 0.f;
+            if (j < a.Cr) {
+                const float* wrow = w1 + (long)j * a.C;
+                for (int cc = part; cc < a.C; cc += 16) acc += wrow[cc] * s_p[cc];
+            }
+            acc += __shfl_xor(acc, 8, WAVE);
+            acc += __shfl_xor(acc, 4, WAVE);
+            acc += __shfl_xor(acc, 2, WAVE);
+            acc += __shfl_xor(acc, 1, WAVE);
+            if (part == 0 && j < a.Cr) s_h[j] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        const float* w2r = w2 + (long)(c0 + wave) * a.Cr;
+        float z = 0.f;
+        for (int j = lane; j < a.Cr; j += 64) z += w2r[j] * s_h[j];
+        const float g = sigmoidf_(wave_sum(z));
+        v4f* yr = reinterpret_cast<v4f*>(a.y + row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < a.n4) {
+                if (NTS) __builtin_nontemporal_store(r[j] * g, &yr[i]);
+                else yr[i] = r[j] * g;
+            }
+        }
+        par ^= 1;
+    }
+}
+
 template <int MODE>
 hipError_t launch_fused(const FusedArgs& a, int nv, size_t smem, hipStream_t st) {
     int dev = 0, ncu = 256;
@@ -198,6 +391,90 @@ int se_eca_fused(int mode, const float* x, const float* wa, const float* wb, flo
     const int nv = (a.n4 + 63) / 64;
     e = (mode == 0) ? launch_fused<0>(a, nv, smem, st) : launch_fused<1>(a, nv, smem, st);
     if (e != hipSuccess) return fail(MI355_EHIP, "se_eca_fused: launch -> %s", hipGetErrorString(e));
+    return MI355_OK;
+}
+
+bool eca_single_applicable(int C, int k, int H, int W) {
+    const long HW = (long)H * W;
+    return opt_eca_single() && (HW % 4 == 0) && (HW / 4 <= 16 * 64) && (C % ECW == 0) && (k - 1 <= 8) && (k & 1);
+}
+
+int eca_single(const float* x, const float* taps, float* y, int B, int C, int k, int H, int W, hipStream_t st) {
+    const int HW = H * W, n4 = HW / 4, gpi = C / ECW;
+    const long total_l = (long)B * gpi;
+    if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "eca_single: too many slices");
+    const int total = (int)total_l, per_xcd = (total + 7) / 8, grid = per_xcd * 8;
+    const int nv = (n4 + 63) / 64;
+    const long nt = opt_nt();
+#define GO2(NV_, L_, S_) eca_halo_kernel<NV_, L_, S_><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd)
+#define GO(NV_)                                                                                   \
+    do {                                                                                          \
+        if ((nt & 1) && (nt & 2)) GO2(NV_, true, true);                                           \
+        else if (nt & 1) GO2(NV_, true, false);                                                   \
+        else if (nt & 2) GO2(NV_, false, true);                                                   \
+        else GO2(NV_, false, false);                                                              \
+    } while (0)
+    if (nv <= 1) GO(1);
+    else if (nv <= 2) GO(2);
+    else if (nv <= 4) GO(4);
+    else if (nv <= 8) GO(8);
+    else if (nv <= 13) GO(13);
+    else GO(16);
+#undef GO
+#undef GO2
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MI355_EHIP, "eca_single: launch -> %s", hipGetErrorString(e));
+    return MI355_OK;
+}
+
+// ---- SE single read (granule exchange) ------------------------------------------------------------------------------------
+size_t se_single_extra_bytes(int B, int C) { return (size_t)B * C * sizeof(u64); }
+
+bool se_single_applicable(int C, int Cr, int H, int W) {
+    const long HW = (long)H * W;
+    return opt_se_single() && (HW % 4 == 0) && (HW / 4 <= 16 * 64) && (C % ECW == 0) && ((size_t)(C + Cr) * 4 <= 48 * 1024);
+}
+
+// `state` = arrive[B] | ticket | err (fused_state_bytes), `gran` = B*C granules (se_single_extra_bytes)
+int se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,
+              void* gran, hipStream_t st) {
+    SeSingleArgs a{};
+    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2;
+    a.gran = static_cast<u64*>(gran);
+    a.ticket = static_cast<u32*>(state) + B;
+    a.err = a.ticket + 1;
+    a.C = C; a.Cr = Cr; a.HW = H * W; a.n4 = a.HW / 4; a.gpi = C / ECW;
+    const long total_l = (long)B * a.gpi;
+    if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "se_single: too many slices");
+    a.total = (int)total_l;
+    hipError_t e = hipMemsetAsync(a.ticket, 0, 2 * sizeof(u32), st);
+    if (e == hipSuccess) e = hipMemsetAsync(gran, 0, se_single_extra_bytes(B, C), st);
+    if (e != hipSuccess) return fail(MI355_EHIP, "se_single: memset -> %s", hipGetErrorString(e));
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    long grid = (long)ncu * 2;                            // two 512-thread workgroups per CU (<= 128 VGPRs)
+    if (grid > a.total) grid = a.total;
+    const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
+    const size_t smem = (size_t)(C + Cr + (wlds ? 2 * C * Cr : 0)) * sizeof(float);
+    const int nv = (a.n4 + 63) / 64;
+    const bool nts = (opt_nt() & 2) != 0;
+#define GO(NV_)                                                                                     \
+    do {                                                                                            \
+        if (nts && wlds)  se_single_kernel<NV_, true, true><<<(int)grid, 512, smem, st>>>(a);       \
+        else if (nts)     se_single_kernel<NV_, true, false><<<(int)grid, 512, smem, st>>>(a);      \
+        else if (wlds)    se_single_kernel<NV_, false, true><<<(int)grid, 512, smem, st>>>(a);      \
+        else              se_single_kernel<NV_, false, false><<<(int)grid, 512, smem, st>>>(a);     \
+    } while (0)
+    if (nv <= 1) GO(1);
+    else if (nv <= 2) GO(2);
+    else if (nv <= 4) GO(4);
+    else if (nv <= 8) GO(8);
+    else if (nv <= 13) GO(13);
+    else GO(16);
+#undef GO
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(MI355_EHIP, "se_single: launch -> %s", hipGetErrorString(e));
     return MI355_OK;
 }
 

@@ -18,6 +18,14 @@ long  opt_nt();
 long  opt_reverse();
 long  opt_fused();
 long  opt_gemm_variant();
+long  opt_eca_single();
+long  opt_se_single();
+size_t se_single_extra_bytes(int B, int C);
+bool  se_single_applicable(int C, int Cr, int H, int W);
+int   se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,
+                void* gran, hipStream_t st);
+bool  eca_single_applicable(int C, int k, int H, int W);
+int   eca_single(const float* x, const float* taps, float* y, int B, int C, int k, int H, int W, hipStream_t st);
 size_t fused_state_bytes(int B);
 bool  fused_applicable(int B, int C, int H, int W);
 int   se_eca_fused(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr, int H, int W,

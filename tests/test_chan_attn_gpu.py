@@ -65,15 +65,104 @@ def test_single_pass_kernel_matches_oracle_and_two_pass(shape, monkeypatch):
             y_se, y_eca = se.cuda()(xd).cpu(), eca.cuda()(xd).cpu()
             again = se(xd).cpu()
         mi355attn.set_option("fused", 0)
+        mi355attn.set_option("se_single", 0)
+        mi355attn.set_option("eca_single", 0)
         with torch.no_grad():
             y_se2, y_eca2 = se(xd).cpu(), eca(xd).cpu()
     finally:
         mi355attn.set_option("fused", old)
+        mi355attn.set_option("se_single", 1)
+        mi355attn.set_option("eca_single", 1)
     assert torch.equal(y_se, again), "single-pass kernel is not run-to-run deterministic"
     assert_parity(y_se, O.se_forward(x, se.fc[0].weight, se.fc[2].weight), 1e-5, f"se fused {shape}")
     assert_parity(y_eca, O.eca_forward(x, eca.conv.weight), 1e-5, f"eca fused {shape}")
     assert_parity(y_se, y_se2, 1e-6, "single pass vs two pass (SE)")
     assert_parity(y_eca, y_eca2, 1e-6, "single pass vs two pass (ECA)")
+
+
+ECA_SINGLE_SHAPES = [(2, 64, 32, 32), (3, 256, 56, 56), (1, 8, 4, 4), (2, 16, 2, 2), (2, 1024, 14, 14), (1, 24, 64, 64), (5, 40, 12, 12),
+                     (1, 4096, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", ECA_SINGLE_SHAPES)
+def test_eca_single_read_kernel(shape):
+    """ECA with x read once (halo rows re-summed per workgroup) vs the oracle and vs the two-pass path; k = 3, 5 and 7 (C = 4096),
+    first / last channel groups exercise the zero padding, every NV instantiation is hit."""
+    import mi355attn
+    B, C, H, W = shape
+    _, eca, _ = _mods(C, 4)
+    torch.manual_seed(11)
+    x = torch.randn(*shape)
+    xd = x.cuda()
+    old = mi355attn.get_option("eca_single")
+    try:
+        mi355attn.set_option("eca_single", 1)
+        with torch.no_grad():
+            y1 = eca.cuda()(xd).cpu()
+            y1b = eca(xd).cpu()
+        mi355attn.set_option("eca_single", 0)
+        with torch.no_grad():
+            y0 = eca(xd).cpu()
+    finally:
+        mi355attn.set_option("eca_single", old)
+    assert torch.equal(y1, y1b)
+    assert_parity(y1, O.eca_forward(x, eca.conv.weight.cpu()), 1e-5, f"eca single {shape}")
+    assert_parity(y1, y0, 1e-6, "eca single read vs two pass")
+
+
+@pytest.mark.parametrize("shape", ECA_SINGLE_SHAPES + [(70, 64, 28, 28), (3, 1024, 8, 8)])
+def test_se_single_read_kernel(shape, monkeypatch):
+    """SE with x read once (register-resident rows, {mean, tag} granule exchange between the workgroups of an image) vs the
+    oracle and vs the two-pass path; the bounded-poll error word is checked after every call."""
+    import mi355attn
+    monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+    B, C, H, W = shape
+    se, _, _ = _mods(C, 16 if C >= 32 else 4)
+    torch.manual_seed(13)
+    x = torch.randn(*shape)
+    xd = x.cuda()
+    try:
+        mi355attn.set_option("se_single", 1)
+        with torch.no_grad():
+            y1 = se.cuda()(xd).cpu()
+            y1b = se(xd).cpu()
+        mi355attn.set_option("se_single", 0)
+        with torch.no_grad():
+            y0 = se(xd).cpu()
+    finally:
+        mi355attn.set_option("se_single", 1)
+    assert torch.equal(y1, y1b)
+    assert_parity(y1, O.se_forward(x, se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, f"se single {shape}")
+    assert_parity(y1, y0, 1e-6, "se single read vs two pass")
+
+
+def test_se_single_granule_protocol_under_repetition(monkeypatch):
+    """300 back-to-back launches reusing one workspace (granules re-zeroed by the memset node each time): every run must equal
+    the first -- a stale or torn granule would change a gate -- and no poll may time out."""
+    monkeypatch.setenv("MI355_CHECK_SYNC", "0")
+    se, _, _ = _mods(256)
+    torch.manual_seed(8)
+    x = torch.randn(40, 256, 28, 28).cuda()
+    with torch.no_grad():
+        first = se.cuda()(x).clone()
+        for _ in range(300):
+            y = se(x)
+        monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+        last = se(x)
+    assert torch.equal(y, first) and torch.equal(last, first)
+    assert_parity(first.cpu(), O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, "se single repeat")
+
+
+def test_eca_single_is_independent_of_batch_grouping():
+    """mean(b,c) is accumulated in one fixed order whichever workgroup needs it, so an image's result does not depend on the batch
+    it is part of (slice numbering / XCD placement change with B)."""
+    _, eca, _ = _mods(256)
+    torch.manual_seed(12)
+    x = torch.randn(19, 256, 28, 28).cuda()
+    with torch.no_grad():
+        full = eca.cuda()(x)
+        part = eca(x[7:12].contiguous())
+    assert torch.equal(full[7:12], part)
 
 
 def test_single_pass_sync_protocol_under_repetition(monkeypatch):

@@ -150,7 +150,8 @@ def test_conv2d_tokens(B, Cin, H, W, Cout, k, stride, pad, layout, prec):
     else:
         tokens = img.flatten(2).transpose(1, 2).contiguous().cuda()
         if Cin % 4:                                   # token-major gathers are 16-byte channel runs: documented restriction
-            with pytest.raises(mi355attn.Mi355Error, match="Cin % 4"):
+            from mi355attn import Mi355Error
+            with pytest.raises(Mi355Error, match="Cin % 4"):
                 F().conv2d_tokens(tokens, wp, b.cuda(), k, stride, pad, 1, hw=(H, W), precision=prec)
             return
         y, hw = F().conv2d_tokens(tokens, wp, b.cuda(), k, stride, pad, 1, hw=(H, W), precision=prec)
