@@ -61,6 +61,9 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "se_single"     1 (default) = SE reads x once: 8 channel rows per workgroup stay in registers, the image's channel means are
  *                   exchanged between its workgroups as 8-byte {mean, tag} granules (one write-through store each, polled with
  *                   bounded sweeps); 0 = two passes (pool, then gate + scale).
+ *   "cbam_single"   1 (default) = full CBAM (stage 0) reads x once: a workgroup keeps a band of rows of all channels in registers;
+ *                   per-channel pools, image-level (avg, max) and the halo rows of the per-pixel statistics travel between the
+ *                   bands of an image as 16-byte self-validating granules; 0 = three passes (pool, statistics, apply).
  *   "eca_single"    1 (default) = ECA reads x once: a workgroup keeps 8 channel rows in registers and re-sums the k-1 halo
  *                   rows next to them (served by the same XCD's L2), no exchange between workgroups; 0 = two passes.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).

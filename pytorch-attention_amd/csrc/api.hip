@@ -13,6 +13,7 @@ static std::atomic<long> g_fused{0};     // experimental single-pass SE/ECA kern
 
 static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
 static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
+static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in registers, three granule hops per band (cbam_single.hip)
 
 char* err_buf() { return g_err; }
 
@@ -29,6 +30,7 @@ long opt_reverse() { return g_reverse.load(std::memory_order_relaxed); }
 long opt_fused() { return g_fused.load(std::memory_order_relaxed); }
 long opt_eca_single() { return g_eca_single.load(std::memory_order_relaxed); }
 long opt_se_single() { return g_se_single.load(std::memory_order_relaxed); }
+long opt_cbam_single() { return g_cbam_single.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
@@ -73,6 +75,11 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_se_single.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "cbam_single") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_cbam_single.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "reverse") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_reverse.store(value, std::memory_order_relaxed);
@@ -89,6 +96,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
     if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
+    if (key && std::strcmp(key, "cbam_single") == 0) return mi355::opt_cbam_single();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
     return -1;
 }

@@ -513,8 +513,11 @@ int mi355_eca_fwd(const float* x, const float* wconv, float* y, int B, int C, in
 
 // workspace: avg[B*C] | max[B*C] | smap[B*2*HW]   (each region rounded to 16 B)
 static inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
-size_t mi355_cbam_workspace_bytes(int B, int C, int H, int W) {
+static inline size_t cbam_multipass_bytes(int B, int C, int H, int W) {
     return 2 * r16((size_t)B * C * 4) + r16((size_t)B * 2 * H * W * 4);
+}
+size_t mi355_cbam_workspace_bytes(int B, int C, int H, int W) {
+    return cbam_multipass_bytes(B, C, H, W) + mi355::cbam_single_extra_bytes(B, C, H, W);
 }
 
 int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr,
@@ -527,6 +530,8 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
     if (do_s) MI355_CHECK_ARG(wconv && ks > 0 && (ks & 1));
     MI355_CHECK_ARG(ws_bytes >= mi355_cbam_workspace_bytes(B, C, H, W));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stage == 0 && aligned16(x) && aligned16(y) && mi355::cbam_single_applicable(C, Cr, H, W, ks))      // x read once
+        return mi355::cbam_single(x, w1, w2, wconv, y, B, C, Cr, H, W, ks, static_cast<char*>(ws) + cbam_multipass_bytes(B, C, H, W), st);
     if (!do_c) Cr = 0;
     if (!do_s) ks = 1;
     const int HW = H * W;

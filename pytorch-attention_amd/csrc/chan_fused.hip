@@ -406,13 +406,12 @@ int eca_single(const float* x, const float* taps, float* y, int B, int C, int k,
     const int total = (int)total_l, per_xcd = (total + 7) / 8, grid = per_xcd * 8;
     const int nv = (n4 + 63) / 64;
     const long nt = opt_nt();
-#define GO2(NV_, L_, S_) eca_halo_kernel<NV_, L_, S_><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd)
-#define GO(NV_)                                                                                   \
-    do {                                                                                          \
-        if ((nt & 1) && (nt & 2)) GO2(NV_, true, true);                                           \
-        else if (nt & 1) GO2(NV_, true, false);                                                   \
-        else if (nt & 2) GO2(NV_, false, true);                                                   \
-        else GO2(NV_, false, false);                                                              \
+    // loads are always plain: the halo rows are the neighbours' resident rows and should stay in the XCD's L2 (measured on MI355X
+    // at the C2 shape: 0.307 ms plain vs 0.358 ms with non-temporal loads); "nt" bit1 still selects non-temporal stores.
+#define GO(NV_)                                                                                                        \
+    do {                                                                                                               \
+        if (nt & 2) eca_halo_kernel<NV_, false, true><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd);  \
+        else        eca_halo_kernel<NV_, false, false><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd); \
     } while (0)
     if (nv <= 1) GO(1);
     else if (nv <= 2) GO(2);
@@ -421,7 +420,6 @@ int eca_single(const float* x, const float* taps, float* y, int B, int C, int k,
     else if (nv <= 13) GO(13);
     else GO(16);
 #undef GO
-#undef GO2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MI355_EHIP, "eca_single: launch -> %s", hipGetErrorString(e));
     return MI355_OK;

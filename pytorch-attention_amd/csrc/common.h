@@ -20,6 +20,11 @@ long  opt_fused();
 long  opt_gemm_variant();
 long  opt_eca_single();
 long  opt_se_single();
+long  opt_cbam_single();
+size_t cbam_single_extra_bytes(int B, int C, int H, int W);
+bool  cbam_single_applicable(int C, int Cr, int H, int W, int ks);
+int   cbam_single(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr, int H, int W,
+                  int ks, void* extra, hipStream_t st);
 size_t se_single_extra_bytes(int B, int C);
 bool  se_single_applicable(int C, int Cr, int H, int W);
 int   se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,

@@ -103,9 +103,18 @@ def cbam_forward(x, w1=None, w2=None, wconv=None, stage=0):
     y = torch.empty_like(x)
     n = lib().mi355_cbam_workspace_bytes(B, C, H, W)
     ws = workspace(n, x.device)
+    import os
+    debug = os.environ.get("MI355_CHECK_SYNC") == "1" and stage == 0       # error word of the single-read kernel: last 16 bytes
+    if debug:
+        ws[n - 16:n].zero_()
     check(lib().mi355_cbam_fwd(dptr(x), dptr(w1 if stage != 2 else None), dptr(w2 if stage != 2 else None),
                                dptr(wconv if stage != 1 else None), dptr(y), B, C, Cr, ks, H, W, stage,
                                dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_cbam_fwd")
+    if debug:
+        torch.cuda.synchronize()
+        err = int(ws[n - 12:n - 8].view(torch.int32).item())
+        if err:
+            raise _ffi.Mi355Error(f"mi355_cbam_fwd: inter-workgroup wait timed out (error word {err})")
     return y
 
 

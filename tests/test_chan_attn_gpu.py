@@ -153,6 +153,54 @@ def test_se_single_granule_protocol_under_repetition(monkeypatch):
     assert_parity(first.cpu(), O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, "se single repeat")
 
 
+CBAM_SINGLE_SHAPES = [(2, 64, 32, 32), (3, 256, 56, 56), (1, 8, 4, 4), (2, 16, 2, 2), (2, 256, 14, 14), (2, 24, 112, 112), (5, 40, 12, 12),
+                      (1, 512, 8, 8), (40, 64, 28, 28), (2, 100, 10, 10), (1, 32, 64, 128), (3, 48, 16, 20)]
+
+
+@pytest.mark.parametrize("shape", CBAM_SINGLE_SHAPES)
+def test_cbam_single_read_kernel(shape, monkeypatch):
+    """CBAM with x read once (row bands of all channels in registers, three granule hops between the bands of an image) vs the
+    oracle and vs the three-pass path.  Shapes cover both segment widths, all NV instantiations, channel counts that do not
+    fill the last register slot, one band per image, many bands per image and kernel sizes 7 and 3."""
+    import mi355attn
+    monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+    B, C, H, W = shape
+    ks = 7 if min(H, W) >= 4 else 3
+    _, _, cbam = _mods(C, 16 if C >= 32 else 4, ks)
+    torch.manual_seed(17)
+    x = torch.randn(*shape)
+    xd = x.cuda()
+    try:
+        mi355attn.set_option("cbam_single", 1)
+        with torch.no_grad():
+            y1 = cbam.cuda()(xd).cpu()
+            y1b = cbam(xd).cpu()
+        mi355attn.set_option("cbam_single", 0)
+        with torch.no_grad():
+            y0 = cbam(xd).cpu()
+    finally:
+        mi355attn.set_option("cbam_single", 1)
+    sd = {k: v.cpu() for k, v in cbam.state_dict().items()}
+    assert torch.equal(y1, y1b)
+    assert_parity(y1, O.cbam_forward(x, sd["ca.fc.0.weight"], sd["ca.fc.2.weight"], sd["sa.conv.weight"]), 1e-5, f"cbam single {shape}")
+    assert_parity(y1, y0, 2e-6, "cbam single read vs three pass")
+
+
+def test_cbam_single_granule_protocol_under_repetition(monkeypatch):
+    """200 back-to-back launches on one workspace: every run equals the first, no poll times out."""
+    monkeypatch.setenv("MI355_CHECK_SYNC", "0")
+    _, _, cbam = _mods(256)
+    torch.manual_seed(8)
+    x = torch.randn(24, 256, 28, 28).cuda()
+    with torch.no_grad():
+        first = cbam.cuda()(x).clone()
+        for _ in range(200):
+            y = cbam(x)
+        monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+        last = cbam(x)
+    assert torch.equal(y, first) and torch.equal(last, first)
+
+
 def test_eca_single_is_independent_of_batch_grouping():
     """mean(b,c) is accumulated in one fixed order whichever workgroup needs it, so an image's result does not depend on the batch
     it is part of (slice numbering / XCD placement change with B)."""
