@@ -66,10 +66,18 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   bands of an image as 16-byte self-validating granules; 0 = three passes (pool, statistics, apply).
  *   "eca_single"    1 (default) = ECA reads x once: a workgroup keeps 8 channel rows in registers and re-sums the k-1 halo
  *                   rows next to them (served by the same XCD's L2), no exchange between workgroups; 0 = two passes.
+ *   "ws_persistent" 0 (default) = the single-read kernels zero their exchange area in the workspace on every call; 1 = the caller
+ *                   promises that a workspace handed to mi355_se_fwd / mi355_cbam_fwd is DEDICATED to that op and shape: nobody
+ *                   else writes it between calls and it is not freed and re-allocated behind the library's back (call
+ *                   mi355_workspace_forget before freeing it).  The library then remembers the buffer, stamps every launch with
+ *                   a fresh tag and skips the memset (43 MB per call at the C2 shape of CBAM).
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
 long        mi355_get_option(const char* key);
+/* Drop what the library remembers about workspaces inside [ws, ws + ws_bytes) ("ws_persistent"): call before freeing or
+ * repurposing such a buffer.  The next call that uses the memory zeroes its exchange area again. */
+int         mi355_workspace_forget(const void* ws, size_t ws_bytes);
 
 /* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
 

@@ -2,6 +2,8 @@
 #include "common.h"
 #include <atomic>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace mi355 {
 static thread_local char g_err[512] = "";
@@ -14,6 +16,7 @@ static std::atomic<long> g_fused{0};     // experimental single-pass SE/ECA kern
 static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
 static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
 static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in registers, three granule hops per band (cbam_single.hip)
+static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
 
 char* err_buf() { return g_err; }
 
@@ -31,6 +34,50 @@ long opt_fused() { return g_fused.load(std::memory_order_relaxed); }
 long opt_eca_single() { return g_eca_single.load(std::memory_order_relaxed); }
 long opt_se_single() { return g_se_single.load(std::memory_order_relaxed); }
 long opt_cbam_single() { return g_cbam_single.load(std::memory_order_relaxed); }
+long opt_ws_persistent() { return g_ws_persistent.load(std::memory_order_relaxed); }
+
+// ---- epochs of the granule-exchange workspaces (chan_fused.hip, cbam_single.hip) ---------------------------------------------
+// A granule is valid when it carries the tag of the CURRENT launch.  With a fresh tag per launch a slot written by any earlier
+// launch -- completed or not -- can never look valid, so the region only has to be zeroed when its history is unknown: first
+// use of the pointer, a different layout key, ticket counter about to wrap, or "ws_persistent" off (the default: a C caller
+// that frees / reuses workspace memory between calls must not opt in).  The ticket word keeps counting across launches;
+// each launch subtracts the base it was handed.
+namespace {
+struct WsEntry { unsigned long long key; unsigned ticket_end; };
+std::mutex g_ws_mu;
+std::unordered_map<const void*, WsEntry> g_ws;
+std::atomic<unsigned> g_epoch{0x5EC0DE00u};
+}  // namespace
+
+WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws) {
+    WsEpoch r{};
+    unsigned tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    if (tag == 0u) tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;     // 0 is what a zeroed slot holds
+    r.tag = tag;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(region);
+    const bool known = opt_ws_persistent() && it != g_ws.end() && it->second.key == key &&
+                       it->second.ticket_end < 0x7FFFFFFFu - draws && tag > 0x1000u /* tags wrapped: start over */;
+    r.fresh = !known;
+    r.ticket_base = known ? it->second.ticket_end : 0u;
+    if (opt_ws_persistent()) g_ws[region] = WsEntry{key, r.ticket_base + draws};
+    else if (it != g_ws.end()) g_ws.erase(it);             // zeroed on every call from now on: what was remembered is void
+    return r;
+}
+void ws_forget(const void* region) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    g_ws.erase(region);
+}
+void ws_forget_range(const void* base, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    const char* lo = static_cast<const char*>(base);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        const char* p = static_cast<const char*>(it->first);
+        if (p >= lo && p < lo + bytes) it = g_ws.erase(it);
+        else ++it;
+    }
+}
+
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
@@ -80,12 +127,23 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_cbam_single.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "ws_persistent") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_ws_persistent.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "reverse") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_reverse.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
     return mi355::fail(MI355_EINVAL, "mi355_set_option: unknown key '%s'", key);
+}
+
+int mi355_workspace_forget(const void* ws, size_t ws_bytes) {
+    MI355_CHECK_ARG(ws != nullptr);
+    mi355::ws_forget_range(ws, ws_bytes);
+    return MI355_OK;
 }
 
 long mi355_get_option(const char* key) {
@@ -96,6 +154,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
     if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
+    if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();
     if (key && std::strcmp(key, "cbam_single") == 0) return mi355::opt_cbam_single();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
     return -1;

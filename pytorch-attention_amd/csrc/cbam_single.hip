@@ -14,8 +14,9 @@
 // Every sum is accumulated in a fixed order (butterfly inside the segment, bands in band order, channel groups in group
 // order), so results are run-to-run identical and independent of placement.  Slices (image, band) are handed out in image
 // order by a ticket; a workgroup only takes its next ticket once it no longer waits for anybody, so progress needs only
-// NB (bands per image) running workgroups, never a particular placement.  Granules are zeroed by memset nodes before the
-// launch; polls are bounded and raise the workspace error word instead of hanging.
+// NB (bands per image) running workgroups, never a particular placement.  The tag is unique per launch (api.hip ws_epoch), so
+// slots written by earlier launches never look valid and the region is only zeroed when its history is unknown; polls are
+// bounded and raise the workspace error word instead of hanging.
 #include "common.h"
 
 namespace {
@@ -25,7 +26,6 @@ typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr u32 TAG = 0xCBA5EED1u;
 constexpr u32 SPIN_LIMIT = 1u << 21;
 
 // Everything goes through raw buffer instructions: one wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset + a
@@ -38,11 +38,11 @@ constexpr u32 OOB = 0x80000000u;                                    // >= any nu
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, u32 bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void gran_put(rsrc_t g, u32 idx, float v0, float v1) {
+__device__ __forceinline__ void gran_put(rsrc_t g, u32 idx, float v0, float v1, u32 TAG) {
     const u32x4 v = {__float_as_uint(v0), TAG, __float_as_uint(v1), TAG};
     __builtin_amdgcn_raw_buffer_store_b128(v, g, idx * 16u, 0, AUX_SC1);      // one write-through 16-byte store
 }
-__device__ __forceinline__ bool gran_get(rsrc_t g, u32 idx, float& v0, float& v1) {
+__device__ __forceinline__ bool gran_get(rsrc_t g, u32 idx, float& v0, float& v1, u32 TAG) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(g, idx * 16u, 0, AUX_SC1);
     v0 = __uint_as_float(v.x);
     v1 = __uint_as_float(v.z);
@@ -77,6 +77,7 @@ struct CbamSingleArgs {
     const float* x; float* y; const float* w1; const float* w2; const float* wconv;
     u32x4* g1; u32x4* g2; u32x4* g3; u32* ticket; u32* err;
     int C, Cr, H, W, ks, R, Q, NB, cpb, total, nts, wlds;
+    u32 tag, tbase;                                                   // granule tag and ticket base of this launch (ws_epoch)
 #ifdef CBAM_TIMING
     unsigned long long* dbg;                                          // [gridDim][16 slices][10 stamps] of wall_clock64 (tools/cbam_timing.hip)
 #endif
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
 
     const int t = threadIdx.x, q = t & (SEG - 1), cl = t / SEG;
     const bool qa = q < a.Q;
-    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
     for (int i = t; i < 2 * ks * ks; i += 512) s_wc[i] = a.wconv[i];
     if (a.wlds)
         for (int i = t; i < Cr * C; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
             float s = (r[j].x + r[j].y) + (r[j].z + r[j].w);
             float m = qa ? fmaxf(fmaxf(r[j].x, r[j].y), fmaxf(r[j].z, r[j].w)) : -INFINITY;
             seg_reduce<SEG>(s, m, t & 63);
-            if (q == 0 && c < C) gran_put(rg1, (u32)(band * C + c), s, m);
+            if (q == 0 && c < C) gran_put(rg1, (u32)(band * C + c), s, m, a.tag);
         }
         STAMP(1);                                                                    // loads landed, band partials published
         // ---- hop 1, consume: this band adds up channels ck0 .. ck0+nch-1 over all bands, publishes (avg, max) as hop 2 ------
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
             for (int i = t; i < n1; i += 512) {
                 const int bb = i / nch, cc = i - bb * nch;
                 float v0, v1;
-                if (gran_get(rg1, (u32)(bb * C + ck0 + cc), v0, v1)) { s_l2s[bb * a.cpb + cc] = v0; s_l2m[bb * a.cpb + cc] = v1; }
+                if (gran_get(rg1, (u32)(bb * C + ck0 + cc), v0, v1, a.tag)) { s_l2s[bb * a.cpb + cc] = v0; s_l2m[bb * a.cpb + cc] = v1; }
                 else ok = false;
             }
             if (__syncthreads_and(ok)) break;
@@ -187,14 +188,14 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         if (t < nch) {
             float s = 0.f, m = -INFINITY;
             for (int bb = 0; bb < a.NB; ++bb) { s += s_l2s[bb * a.cpb + t]; m = fmaxf(m, s_l2m[bb * a.cpb + t]); }
-            gran_put(rg2, (u32)(ck0 + t), s / (float)HW, m);
+            gran_put(rg2, (u32)(ck0 + t), s / (float)HW, m, a.tag);
         }
         // ---- hop 2, consume: (avg, max) of every channel of the image ---------------------------------------------------------
         for (;;) {
             bool ok = true;
             for (int c = t; c < C; c += 512) {
                 float v0, v1;
-                if (gran_get(rg2, (u32)c, v0, v1)) { s_a[c] = v0; s_m[c] = v1; }
+                if (gran_get(rg2, (u32)c, v0, v1, a.tag)) { s_a[c] = v0; s_m[c] = v1; }
                 else ok = false;
             }
             if (__syncthreads_and(ok)) break;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
             const int ty = t / W, tx = t - ty * W;
             s_t[(0 * TH + ty + pad) * TW + tx + pad] = s;
             s_t[(1 * TH + ty + pad) * TW + tx + pad] = m;
-            gran_put(rg3, (u32)(r0 * W + t), s, m);                                  // hop 3, publish
+            gran_put(rg3, (u32)(r0 * W + t), s, m, a.tag);                                  // hop 3, publish
         }
         STAMP(5);                                                                    // statistics published
         // ---- hop 3, consume: halo rows of the neighbouring bands ------------------------------------------------------------------
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
                     const int hr = i / W, tx = i - hr * W;
                     const int gy = (hr < up) ? r0 - up + hr : r0 + a.R + (hr - up);
                     float v0, v1;
-                    if (gran_get(rg3, (u32)(gy * W + tx), v0, v1)) {
+                    if (gran_get(rg3, (u32)(gy * W + tx), v0, v1, a.tag)) {
                         const int ty = gy - r0 + pad;
                         s_t[(0 * TH + ty) * TW + tx + pad] = v0;
                         s_t[(1 * TH + ty) * TW + tx + pad] = v1;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         // nobody is waited for any more: take the next ticket (hidden behind the conv and the stores)
         u32 next_tk = 0;
         if (t == 0) {
-            next_tk = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);               // consumed after the stores below
+            next_tk = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;     // consumed after the stores below
             if (timeout) __hip_atomic_store(a.err, 1u, AGENT_RLX);
         }
         // ---- spatial gate of the band: sigmoid(conv_ks x ks([mean, max]))  (2 -> 1, zero pad, cross-correlation) ----------------
@@ -425,8 +426,6 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     const bool full = (C == g.CL * g.NV);
     a.wlds = (g.smem_base + g.smem_w <= 60 * 1024) ? 1 : 0;
     const size_t smem = g.smem_base + (a.wlds ? g.smem_w : 0);
-    hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);
-    if (e != hipSuccess) return fail(MI355_EHIP, "cbam_single: memset -> %s", hipGetErrorString(e));
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -436,6 +435,14 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     grid = (long)ncu * g_cbam_grid_mult;
 #endif
     if (grid > a.total) grid = a.total;
+    // every workgroup draws one ticket per slice plus one that tells it to stop: total + grid draws per launch
+    const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ 0xCBA0000000000000ull;
+    const WsEpoch ep = ws_epoch(extra, key, (unsigned)(a.total + grid));
+    a.tag = ep.tag; a.tbase = ep.ticket_base;
+    if (ep.fresh) {
+        hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);
+        if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: memset -> %s", hipGetErrorString(e)); }
+    }
 #define GO(SEG_, NV_)                                                                      \
     do {                                                                                   \
         if (full) cbam_single_kernel<SEG_, NV_, true><<<(int)grid, 512, smem, st>>>(a);    \
@@ -451,8 +458,8 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
         else GO(16, 16);
     }
 #undef GO
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(MI355_EHIP, "cbam_single: launch -> %s", hipGetErrorString(e));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: launch -> %s", hipGetErrorString(e)); }
     return MI355_OK;
 }
 

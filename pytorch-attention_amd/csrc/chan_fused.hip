@@ -219,15 +219,15 @@ __global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restric
 // arrival counter (MI355X_MICROARCH.md price list: handoff-1to1 / allgather rows).  Every workgroup of the image then sweeps
 // the image's C granules with sc1 loads (one per thread) until all tags match, computes the excitation MLP redundantly
 // (C*Cr MACs) and scales its rows from registers.  Slices are handed out in image order by a ticket that is prefetched one
-// slice ahead, so progress needs only C/8 running workgroups and never a particular placement.  The granule array is
-// zeroed by a memset node before the launch; the tag is a non-zero constant.  Polls are bounded (error word).
-constexpr u32 GRAN_TAG = 0x5EC0DE01u;
+// slice ahead, so progress needs only C/8 running workgroups and never a particular placement.  The tag is unique per launch
+// (api.hip ws_epoch): the granule array is only zeroed when the history of the workspace is unknown.  Polls are bounded.
 typedef unsigned long long u64;
 
 struct SeSingleArgs {
     const float* x; float* y; const float* w1; const float* w2;
     u64* gran; u32* ticket; u32* err;
     int C, Cr, HW, n4, gpi, total;
+    u32 tag, tbase;                    // granule tag and ticket base of this launch (api.hip ws_epoch)
 };
 
 template <int NV, bool NTS, bool WLDS>
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a)
     float* s_w2 = s_w1 + a.Cr * a.C;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float inv = 1.0f / (float)a.HW;
-    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+    const u32 GRAN_TAG = a.tag;
+    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
     if (WLDS) {                                                       // both weight matrices stay in LDS for every slice
         const int nw = a.Cr * a.C;
         for (int i = t; i < nw; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a)
         }
         // Next slice's ticket: only now, when this workgroup no longer waits for anybody -- a workgroup that held an unprocessed
         // ticket of the image it is still waiting for would deadlock.  Its latency hides behind the MLP and the stores.
-        if (t == 0) s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+        if (t == 0) s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
         // excitation: h = relu(W1 p) (16 lanes per hidden unit), g = sigmoid(W2[c,:] h) (one wave per channel)
         const float* w1 = WLDS ? s_w1 : a.w1;
         const float* w2 = WLDS ? s_w2 : a.w2;
@@ -385,6 +386,7 @@ int se_eca_fused(int mode, const float* x, const float* wa, const float* wb, flo
     a.ticket = a.arrive + B;
     a.err = a.ticket + 1;
     a.B = B; a.C = C; a.Cr = Cr; a.HW = H * W; a.n4 = a.HW / 4; a.spi = C / CPW; a.total = B * a.spi;
+    ws_forget(state);                                      // this path re-zeroes the ticket word the single-read SE kernel keeps counting on
     hipError_t e = hipMemsetAsync(state, 0, ((size_t)B + 2) * sizeof(u32), st);
     if (e != hipSuccess) return fail(MI355_EHIP, "se_eca_fused: memset -> %s", hipGetErrorString(e));
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + CPW) * sizeof(float);
@@ -445,14 +447,20 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     const long total_l = (long)B * a.gpi;
     if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "se_single: too many slices");
     a.total = (int)total_l;
-    hipError_t e = hipMemsetAsync(a.ticket, 0, 2 * sizeof(u32), st);
-    if (e == hipSuccess) e = hipMemsetAsync(gran, 0, se_single_extra_bytes(B, C), st);
-    if (e != hipSuccess) return fail(MI355_EHIP, "se_single: memset -> %s", hipGetErrorString(e));
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     long grid = (long)ncu * 2;                            // two 512-thread workgroups per CU (<= 128 VGPRs)
     if (grid > a.total) grid = a.total;
+    const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ 0x5E00000000000000ull;
+    const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid));     // one draw per slice + one stop draw per workgroup
+    a.tag = ep.tag; a.tbase = ep.ticket_base;
+    hipError_t e = hipSuccess;
+    if (ep.fresh) {
+        e = hipMemsetAsync(a.ticket, 0, 2 * sizeof(u32), st);
+        if (e == hipSuccess) e = hipMemsetAsync(gran, 0, se_single_extra_bytes(B, C), st);
+        if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: memset -> %s", hipGetErrorString(e)); }
+    }
     const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
     const size_t smem = (size_t)(C + Cr + (wlds ? 2 * C * Cr : 0)) * sizeof(float);
     const int nv = (a.n4 + 63) / 64;
@@ -472,7 +480,7 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     else GO(16);
 #undef GO
     e = hipGetLastError();
-    if (e != hipSuccess) return fail(MI355_EHIP, "se_single: launch -> %s", hipGetErrorString(e));
+    if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: launch -> %s", hipGetErrorString(e)); }
     return MI355_OK;
 }
 

@@ -20,6 +20,11 @@ long  opt_fused();
 long  opt_gemm_variant();
 long  opt_eca_single();
 long  opt_se_single();
+long  opt_ws_persistent();
+struct WsEpoch { unsigned tag; unsigned ticket_base; bool fresh; };
+WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws);   // api.hip: tag + ticket base of this launch
+void  ws_forget(const void* region);
+void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
 size_t cbam_single_extra_bytes(int B, int C, int H, int W);
 bool  cbam_single_applicable(int C, int Cr, int H, int W, int ks);

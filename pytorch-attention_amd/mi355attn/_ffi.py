@@ -8,6 +8,7 @@ implementation (see DESIGN.md "boundary").
 as /opt/rocm's), so loading torch first makes our library bind to the runtime torch already initialised --
 one HIP runtime per process, shared streams and device pointers.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -33,6 +34,7 @@ SIGNATURES = {
     "mi355_last_error": (ctypes.c_char_p, []),
     "mi355_set_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
     "mi355_get_option": (ctypes.c_long, [ctypes.c_char_p]),
+    "mi355_workspace_forget": (c_int, [c_vp, ctypes.c_size_t]),
     "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_se_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "mi355_eca_workspace_bytes": (c_size, [c_int] * 4),
@@ -88,6 +90,8 @@ def lib():
         v = handle.mi355_version()
         if v != ABI_VERSION:
             raise Mi355Error(f"libmi355attn ABI version {v} != binding version {ABI_VERSION}; rebuild")
+        # the single-read SE / CBAM ops get dedicated workspaces from workspace_dedicated() below, so the promise holds
+        handle.mi355_set_option(b"ws_persistent", 1)
         _lib = handle
     return _lib
 
@@ -132,6 +136,30 @@ def workspace(nbytes, device):
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
+    return t
+
+
+_ws_dedicated = collections.OrderedDict()
+_WS_DEDICATED_MAX = 12
+
+
+def workspace_dedicated(op_key, nbytes, device):
+    """Workspace owned by ONE op + shape (single-read SE / CBAM): nothing else ever writes it, which is what lets the library
+    skip re-zeroing the granule exchange area on every call ("ws_persistent", include/mi355attn.h).  A small LRU; an evicted
+    buffer is reported to the library before it is released."""
+    key = (op_key, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    t = _ws_dedicated.get(key)
+    if t is None or t.numel() < nbytes:
+        if t is not None:
+            lib().mi355_workspace_forget(ctypes.c_void_p(t.data_ptr()), t.numel())
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_dedicated[key] = t
+        while len(_ws_dedicated) > _WS_DEDICATED_MAX:
+            _, old = _ws_dedicated.popitem(last=False)
+            lib().mi355_workspace_forget(ctypes.c_void_p(old.data_ptr()), old.numel())
+    else:
+        _ws_dedicated.move_to_end(key)
     return t
 
 

@@ -62,7 +62,7 @@ def se_forward(x, w1, w2):
         raise ValueError(f"SE weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not match C={C}")
     y = torch.empty_like(x)
     n = lib().mi355_se_workspace_bytes(B, C, H, W)
-    ws = workspace(n, x.device)
+    ws = _ffi.workspace_dedicated(("se", B, C, H, W), n, x.device)
     check(lib().mi355_se_fwd(dptr(x), dptr(w1), dptr(w2), dptr(y), B, C, Cr, H, W, dptr(ws), ws.numel(),
                              stream_ptr(x.device)), "mi355_se_fwd")
     _check_sync_state(ws, B, C, "mi355_se_fwd")
@@ -102,11 +102,11 @@ def cbam_forward(x, w1=None, w2=None, wconv=None, stage=0):
             raise ValueError(f"CBAM spatial conv weight must be (1,2,k,k), got {tuple(wconv.shape)}")
     y = torch.empty_like(x)
     n = lib().mi355_cbam_workspace_bytes(B, C, H, W)
-    ws = workspace(n, x.device)
+    ws = _ffi.workspace_dedicated(("cbam", B, C, H, W), n, x.device) if stage == 0 else workspace(n, x.device)
     import os
-    debug = os.environ.get("MI355_CHECK_SYNC") == "1" and stage == 0       # error word of the single-read kernel: last 16 bytes
+    debug = os.environ.get("MI355_CHECK_SYNC") == "1" and stage == 0       # error word of the single-read kernel: ws[n-12:n-8]
     if debug:
-        ws[n - 16:n].zero_()
+        ws[n - 12:n - 8].zero_()                                           # (never the ticket word next to it: it counts across calls)
     check(lib().mi355_cbam_fwd(dptr(x), dptr(w1 if stage != 2 else None), dptr(w2 if stage != 2 else None),
                                dptr(wconv if stage != 1 else None), dptr(y), B, C, Cr, ks, H, W, stage,
                                dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_cbam_fwd")

@@ -201,6 +201,34 @@ def test_cbam_single_granule_protocol_under_repetition(monkeypatch):
     assert torch.equal(y, first) and torch.equal(last, first)
 
 
+def test_persistent_workspace_epochs(monkeypatch):
+    """With "ws_persistent" (what the Python binding runs with) the exchange area is zeroed once and every launch carries a fresh
+    tag.  Interleave shapes and ops that share nothing but the process-wide epoch counter, switch the option off and on again,
+    and detour through the kernels that reset the shared ticket word: every result must stay bit-identical to the first."""
+    import mi355attn
+    monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+    assert mi355attn.get_option("ws_persistent") == 1
+    se_a, _, cbam_a = _mods(64)
+    se_b, _, cbam_b = _mods(256)
+    torch.manual_seed(21)
+    xa, xb = torch.randn(6, 64, 28, 28).cuda(), torch.randn(3, 256, 14, 14).cuda()
+    mods = [(se_a.cuda(), xa), (cbam_a.cuda(), xa), (se_b.cuda(), xb), (cbam_b.cuda(), xb)]
+    with torch.no_grad():
+        first = [m(x).clone() for m, x in mods]
+        for rnd in range(12):
+            if rnd == 4:
+                mi355attn.set_option("ws_persistent", 0)
+            if rnd == 7:
+                mi355attn.set_option("ws_persistent", 1)
+            if rnd == 9:                                   # old flag-protocol kernel on the same dedicated workspace
+                mi355attn.set_option("fused", 2)
+                se_a(xa)
+                mi355attn.set_option("fused", 0)
+            for (m, x), f in zip(mods, first):
+                assert torch.equal(m(x), f), f"round {rnd}"
+    mi355attn.set_option("ws_persistent", 1)
+
+
 def test_eca_single_is_independent_of_batch_grouping():
     """mean(b,c) is accumulated in one fixed order whichever workgroup needs it, so an image's result does not depend on the batch
     it is part of (slice numbering / XCD placement change with B)."""
