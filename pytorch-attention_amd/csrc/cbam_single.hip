@@ -92,9 +92,9 @@ struct CbamSingleArgs {
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int SEG, int NV, bool FULL>
-__global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArgs a) {
-    constexpr int CL = 512 / SEG;                                     // channel groups (segments) per workgroup
+template <int NT, int SEG, int NV, bool FULL>
+__global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs a) {
+    constexpr int CL = NT / SEG;                                     // channel groups (segments) per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_tk[2];
     const int C = a.C, Cr = a.Cr, W = a.W, H = a.H, ks = a.ks, pad = (ks - 1) >> 1;
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
     const int t = threadIdx.x, q = t & (SEG - 1), cl = t / SEG;
     const bool qa = q < a.Q;
     if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
-    for (int i = t; i < 2 * ks * ks; i += 512) s_wc[i] = a.wconv[i];
+    for (int i = t; i < 2 * ks * ks; i += NT) s_wc[i] = a.wconv[i];
     if (a.wlds)
-        for (int i = t; i < Cr * C; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
+        for (int i = t; i < Cr * C; i += NT) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
     const float* w1 = a.wlds ? s_w1 : a.w1;
     const float* w2 = a.wlds ? s_w2 : a.w2;
     int par = 0;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         const rsrc_t rg2 = make_rsrc(a.g2 + (long)b * C, (u32)C * 16u);
         const rsrc_t rg3 = make_rsrc(a.g3 + (long)b * HW, (u32)HW * 16u);
         // zero the statistics tile while the loads fly
-        for (int i = t; i < 2 * TH * TW; i += 512) s_t[i] = 0.f;
+        for (int i = t; i < 2 * TH * TW; i += NT) s_t[i] = 0.f;
 
         // ---- hop 1, publish: (sum, max) of this band for every channel ------------------------------------------------------
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         const int n1 = a.NB * nch;
         for (;;) {
             bool ok = true;
-            for (int i = t; i < n1; i += 512) {
+            for (int i = t; i < n1; i += NT) {
                 const int bb = i / nch, cc = i - bb * nch;
                 float v0, v1;
                 if (gran_get(rg1, (u32)(bb * C + ck0 + cc), v0, v1, a.tag)) { s_l2s[bb * a.cpb + cc] = v0; s_l2m[bb * a.cpb + cc] = v1; }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         // ---- hop 2, consume: (avg, max) of every channel of the image ---------------------------------------------------------
         for (;;) {
             bool ok = true;
-            for (int c = t; c < C; c += 512) {
+            for (int c = t; c < C; c += NT) {
                 float v0, v1;
                 if (gran_get(rg2, (u32)c, v0, v1, a.tag)) { s_a[c] = v0; s_m[c] = v1; }
                 else ok = false;
@@ -205,11 +205,11 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
         STAMP(3);                                                                    // hop 2 in
         // ---- channel gates: gc = sigmoid(W2 (relu(W1 avg) + relu(W1 max)))  (cbam.py:31-35) ---------------------------------
         {
-            // threads 0-255: W1 avg, threads 256-511: W1 max; 16 lanes per hidden unit, 16 units per round
-            const int half = t >> 8, tt = t & 255, part = tt & 15, jl = tt >> 4;
+            // first half of the threads: W1 avg, second half: W1 max; 16 lanes per hidden unit, NT/32 units per round
+            const int half = t / (NT / 2), tt = t & (NT / 2 - 1), part = tt & 15, jl = tt >> 4;
             const float* vec = half ? s_m : s_a;
             float* s_hh = s_h + half * Crp;                           // relu(W1 avg) | relu(W1 max)
-            for (int j0 = 0; j0 < Cr; j0 += 16) {
+            for (int j0 = 0; j0 < Cr; j0 += NT / 32) {
                 const int j = j0 + jl;
                 float h0 = 0.f, h1 = 0.f;
                 if (j < Cr) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
                 if (part == 0 && j < Cr) s_hh[j] = fmaxf(h, 0.f);
             }
             __syncthreads();
-            for (int c = t; c < C; c += 512) {
+            for (int c = t; c < C; c += NT) {
                 const float* w2r = w2 + (long)c * Cr;
                 float z0 = 0.f, z1 = 0.f;
                 int j = 0;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
             const int n3 = (up + dn) * W;
             for (;;) {
                 bool ok = true;
-                for (int i = t; i < n3; i += 512) {
+                for (int i = t; i < n3; i += NT) {
                     const int hr = i / W, tx = i - hr * W;
                     const int gy = (hr < up) ? r0 - up + hr : r0 + a.R + (hr - up);
                     float v0, v1;
@@ -350,29 +350,30 @@ __global__ __launch_bounds__(512, 4) void cbam_single_kernel(const CbamSingleArg
 }
 
 struct Geo {
-    int R, Q, NB, SEG, CL, NV, cpb;
+    int NT, R, Q, NB, SEG, CL, NV, cpb;
     size_t smem_base, smem_w;
 };
 
-// Rows per band: the most pixels per band with R | H, (R*W) % 4 == 0 and R*W <= 128; 0 when no such R exists.
-int band_rows(int H, int W) {
+// Rows per band: the most pixels per band with R | H, (R*W) % 4 == 0 and R*W <= NT/4 (four conv lanes per pixel); 0 if none.
+int band_rows(int H, int W, int nt) {
     int best = 0;
     for (int R = 1; R <= H; ++R) {
-        if (H % R || (R * W) % 4 || R * W > 128) continue;
+        if (H % R || (R * W) % 4 || R * W > nt / 4) continue;
         best = R;
     }
     return best;
 }
 
-bool geometry(int C, int Cr, int H, int W, int ks, Geo& g) {
+bool geometry(int nt, int C, int Cr, int H, int W, int ks, Geo& g) {
     if (!(ks & 1) || ks > 15) return false;
-    const int best = band_rows(H, W);
+    const int best = band_rows(H, W, nt);
     if (!best) return false;
+    g.NT = nt;
     g.R = best;
     g.Q = best * W / 4;
     g.NB = H / best;
     g.SEG = g.Q > 16 ? 32 : 16;
-    g.CL = 512 / g.SEG;
+    g.CL = nt / g.SEG;
     const int nv = (C + g.CL - 1) / g.CL;
     if (nv > 16) return false;
     g.NV = nv <= 4 ? 4 : (nv <= 8 ? 8 : 16);
@@ -387,30 +388,38 @@ bool geometry(int C, int Cr, int H, int W, int ks, Geo& g) {
     return g.smem_base <= 40 * 1024;
 }
 
+// 512-thread workgroups (2 per CU, bands of <= 128 pixels) or 256-thread workgroups (4 per CU, <= 64 pixels): same bytes in
+// registers per CU, the second gives four independent load / exchange / store chains per CU instead of two.
+bool pick_geometry(int C, int Cr, int H, int W, int ks, Geo& g) {
+    const long pref = mi355::opt_cbam_threads();
+    if (pref == 256) return geometry(256, C, Cr, H, W, ks, g) || geometry(512, C, Cr, H, W, ks, g);
+    return geometry(512, C, Cr, H, W, ks, g) || geometry(256, C, Cr, H, W, ks, g);
+}
+
 }  // namespace
 
 namespace mi355 {
 #ifdef CBAM_TIMING
 unsigned long long* g_cbam_dbg = nullptr;
-int g_cbam_grid_mult = 2;
 #endif
 
 // extra workspace of the single-read CBAM: g1 | g2 | g3 granules | ticket, err, pad (0 when no band geometry exists)
 size_t cbam_single_extra_bytes(int B, int C, int H, int W) {
-    const int R = band_rows(H, W);
+    int R = band_rows(H, W, 256);                                     // the finer banding needs the larger hop-1 array
+    if (!R) R = band_rows(H, W, 512);
     if (!R) return 0;
     return ((size_t)B * (H / R) * C + (size_t)B * C + (size_t)B * H * W) * 16 + 16;
 }
 
 bool cbam_single_applicable(int C, int Cr, int H, int W, int ks) {
     Geo g;
-    return opt_cbam_single() && geometry(C, Cr, H, W, ks, g);
+    return opt_cbam_single() && pick_geometry(C, Cr, H, W, ks, g);
 }
 
 int cbam_single(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr, int H, int W,
                 int ks, void* extra, hipStream_t st) {
     Geo g;
-    if (!geometry(C, Cr, H, W, ks, g)) return fail(MI355_EUNSUPPORTED, "cbam_single: unsupported shape");
+    if (!pick_geometry(C, Cr, H, W, ks, g)) return fail(MI355_EUNSUPPORTED, "cbam_single: unsupported shape");
     CbamSingleArgs a{};
     a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.wconv = wconv;
     a.g1 = static_cast<u32x4*>(extra);
@@ -424,29 +433,34 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     a.total = (int)total_l;
     a.nts = (opt_nt() & 2) ? 1 : 0;
     const bool full = (C == g.CL * g.NV);
-    a.wlds = (g.smem_base + g.smem_w <= 60 * 1024) ? 1 : 0;
+    const int per_cu = g.NT == 512 ? 2 : 4;
+    a.wlds = (g.smem_base + g.smem_w <= (size_t)(120 * 1024) / per_cu) ? 1 : 0;
     const size_t smem = g.smem_base + (a.wlds ? g.smem_w : 0);
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    long grid = (long)ncu * 2;                                        // two 512-thread workgroups per CU (<= 128 VGPRs, <= 60 KB LDS)
+    long grid = (long)ncu * per_cu;                                   // 16 waves per CU at <= 128 VGPRs, <= 120 KB LDS per CU
 #ifdef CBAM_TIMING
     a.dbg = g_cbam_dbg;
-    grid = (long)ncu * g_cbam_grid_mult;
 #endif
     if (grid > a.total) grid = a.total;
     // every workgroup draws one ticket per slice plus one that tells it to stop: total + grid draws per launch
-    const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ 0xCBA0000000000000ull;
+    const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ ((unsigned long long)g.NT << 40) ^ 0xCBA0000000000000ull;
     const WsEpoch ep = ws_epoch(extra, key, (unsigned)(a.total + grid));
     a.tag = ep.tag; a.tbase = ep.ticket_base;
     if (ep.fresh) {
         hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);
         if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: memset -> %s", hipGetErrorString(e)); }
     }
-#define GO(SEG_, NV_)                                                                      \
-    do {                                                                                   \
-        if (full) cbam_single_kernel<SEG_, NV_, true><<<(int)grid, 512, smem, st>>>(a);    \
-        else      cbam_single_kernel<SEG_, NV_, false><<<(int)grid, 512, smem, st>>>(a);   \
+#define GO(SEG_, NV_)                                                                                  \
+    do {                                                                                               \
+        if (g.NT == 512) {                                                                             \
+            if (full) cbam_single_kernel<512, SEG_, NV_, true><<<(int)grid, 512, smem, st>>>(a);       \
+            else      cbam_single_kernel<512, SEG_, NV_, false><<<(int)grid, 512, smem, st>>>(a);      \
+        } else {                                                                                       \
+            if (full) cbam_single_kernel<256, SEG_, NV_, true><<<(int)grid, 256, smem, st>>>(a);       \
+            else      cbam_single_kernel<256, SEG_, NV_, false><<<(int)grid, 256, smem, st>>>(a);      \
+        }                                                                                              \
     } while (0)
     if (g.SEG == 32) {
         if (g.NV == 4) GO(32, 4);

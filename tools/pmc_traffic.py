@@ -18,6 +18,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 BLOCK_OF = [  # (regex on the kernel name, block, share of that kernel's launches belonging to the block)
+    (r"se_single_kernel", "SELayer(256)", 1.0),
+    (r"eca_halo_kernel", "ECALayer(256)", 1.0),
+    (r"cbam_single_kernel", "CBAM(256)", 1.0),
     (r"gate_scale_kernel<0", "SELayer(256)", 1.0),
     (r"gate_scale_kernel<1", "ECALayer(256)", 1.0),
     (r"pool_rows_kernel<false", "SELayer(256)", 0.5),
