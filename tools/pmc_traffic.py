@@ -26,7 +26,7 @@ BLOCK_OF = [  # (regex on the kernel name, block, share of that kernel's launche
     (r"pool_rows_kernel<false", "SELayer(256)", 0.5),
     (r"pool_rows_kernel<false", "ECALayer(256)", 0.5),
     (r"pool_rows_kernel<true", "CBAM(256)", 1.0),
-    (r"cbam_", "CBAM(256)", 1.0),
+    (r"cbam_(spatial|apply)", "CBAM(256)", 1.0),
 ]
 
 
