@@ -133,4 +133,12 @@ def workload_mixer_full(B, dev):
     return _full_model(MLP_Mixer, "MLP-Mixer(512, depth 12)", flop, lambda xs, sd: O.mixer_forward(xs, sd), B, dev)
 
 
-WORKLOADS = {"cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}
+def workload_xcit(B, dev):
+    """xcit_nano_12_p16 (xcit.py:416-420): conv patch embedding + Fourier positions, 12 XCABlocks (dim 128, 4 heads), 2 class-attention
+    blocks, head.  FLOPs per image: convs 97.5e6 + 12 x 81.2e6 (qkv, covariance core, proj, LPI, MLP) + 2 x 13.5e6 + head."""
+    from mi355attn.modules import xcit_nano_12_p16
+    flop = 97.5e6 + 12 * 81.2e6 + 2 * 13.5e6 + 2.0 * 128 * 1000
+    return _full_model(xcit_nano_12_p16, "XCiT-nano-12/16", flop, lambda xs, sd: O.xcit_forward(xs, sd), B, dev)
+
+
+WORKLOADS = {"xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

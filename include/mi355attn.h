@@ -188,16 +188,33 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
 
 /* ---- model-level glue (callers of the blocks) ------------------------------------------------------------ */
 
-/* Conv2d as implicit GEMM, token-major output (B, OH*OW, Cout) + bias; no im2col buffer.
- *   in_layout 0: x NCHW (B,Cin,H,W), weight rows ordered (c,ky,kx)        -- CSWin stem conv 7x7 s4 p2 (cswin.py:247-251)
- *   in_layout 1: x token-major (B,H*W,Cin), weight rows ordered (ky,kx,c)  -- CSWin Merge_Block conv 3x3 s2 p1 (cswin.py:218-233)
- * weight is (Cout, ldw), ldw >= Cin*KH*KW, ldw % 4 == 0, zero padded beyond Cin*KH*KW. */
-int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int H, int W,
-                            int Cout, int KH, int KW, int stride, int pad, int ldw, int in_layout, int precision,
-                            mi355_stream_t stream);
+/* Conv2d as implicit GEMM, token-major output: y (B, OH*OW, Cout) = act(conv(x) + bias + pos); no im2col buffer.
+ *   in_layout 0: x NCHW (B,Cin,H,W), weight rows ordered (c,ky,kx)        -- CSWin stem conv 7x7 s4 p2 (cswin.py:247-251),
+ *                                                                            first conv of XCiT ConvPatchEmbed (xcit.py:88-126)
+ *   in_layout 1: x token-major (B,H*W,Cin), weight rows ordered (ky,kx,c)  -- CSWin Merge_Block conv 3x3 s2 p1 (cswin.py:218-233),
+ *                                                                            the later ConvPatchEmbed convs
+ * weight is (Cout, ldw), ldw >= Cin*KH*KW, ldw % 4 == 0, zero padded beyond Cin*KH*KW.  bias (Cout) and pos (OH*OW, Cout: a
+ * per-output-token addend, e.g. the XCiT Fourier position encoding xcit.py:398-400) may be NULL; act = MI355_ACT_NONE|GELU.
+ * An eval-mode BatchNorm after the conv is folded into weight / bias by the caller. */
+int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, const float* pos, float* y, int B, int Cin,
+                            int H, int W, int Cout, int KH, int KW, int stride, int pad, int ldw, int in_layout, int act,
+                            int precision, mi355_stream_t stream);
 
 /* y[b,c] = mean over n of x[b*batch_stride + n*C + c]  (cswin.py:341, mlp_mixer.py:77, ViT.py:189-190). */
 int mi355_token_mean_fwd(const float* x, float* y, int B, int N, int C, long batch_stride, mi355_stream_t stream);
+
+/* Class attention core (CaiT / XCiT ClassAttention.forward xcit.py:174-188): one query per image and head attends over N keys,
+ *   out[b, i*d + j] = sum_n softmax_n(scale * sum_j' q[b, i*d + j'] k[b,n,i*d + j']) v[b,n,i*d + j],   exact fp32.
+ * q row b starts at q + b*ldq; key / value token (b,n) starts at k|v + (b*N + n)*ldkv (so the fused (B,N,3C) qkv tensor can be
+ * passed in place with k = qkv + C, v = qkv + 2C, ldkv = 3C).  out (B, h*d) dense.  d <= 64, N <= 4096. */
+int mi355_class_attn_fwd(const float* q, const float* k, const float* v, float* out, int B, int N, int num_heads, int head_dim,
+                         long ldq, long ldkv, float scale, mi355_stream_t stream);
+
+/* y[r, c] = alpha * x[r, c] + gamma[c] * u[r, c]  over rows x cols with row strides ldx / ldu / ldy (floats; ldx or ldu may be 0
+ * to broadcast one row).  u == NULL drops the second term, gamma == NULL means 1.  The token-axis glue of the XCiT class-attention
+ * stage (xcit.py:219-231, 402-403): residual with LayerScale, cls-row scatter / gather, token concatenation. */
+int mi355_axpby_fwd(const float* x, const float* u, const float* gamma, float* y, long rows, int cols, long ldx, long ldu,
+                    long ldy, float alpha, mi355_stream_t stream);
 
 /* ---- measurement helpers --------------------------------------------------------------------------- */
 /* float4 streaming copy of `bytes` (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py. */

@@ -23,7 +23,8 @@ from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_ml
                           vit_encoder_forward, vit_patch_embed_forward, vit_forward,
                           mixer_layer_forward, sdpa_core, mixer_forward)
 from .cswin import lepe_attention_forward, cswin_block_forward, window_token_index, cswin_forward
-from .xcit import xca_forward, lpi_forward, xca_block_forward
+from .xcit import (xca_forward, lpi_forward, xca_block_forward, xcit_forward, conv_patch_embed_forward, fourier_position_rows,
+                   class_attention_block_forward)
 from .params import seeded_module_inputs, strip_prefix
 
 __all__ = [n for n in dir() if not n.startswith("_")]

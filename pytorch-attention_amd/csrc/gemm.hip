@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 if (n + c >= g.N) break;
                 float z = vv[c];
                 if (g.bias) z += g.bias_per_row ? g.bias[m] : g.bias[n + c];
-                if constexpr (AMODE == 1) { if (g.pos) z += g.pos[(long)(m % g.P) * g.N + n + c]; }
+                if constexpr (AMODE >= 1) { if (g.pos) z += g.pos[(long)(m % g.P) * g.N + n + c]; }
                 if (g.act == MI355_ACT_GELU) z = gelu_fast(z);
                 if (g.gamma) z *= g.gamma[n + c];
                 if (Rb) z += Rb[orow * g.ldc + n + c];
@@ -374,10 +374,12 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
 //   in_layout 1: x is token-major (B, H*W, Cin),   weight rows in (ky,kx,c) order   -- CSWin Merge_Block (:218-233)
 // weight is (Cout, ldw) with ldw >= Cin*KH*KW, ldw % 4 == 0 and ZERO padding beyond Cin*KH*KW.  y is token-major
 // (B, OH*OW, Cout) fp32, + bias.
-int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
-                            int KH, int KW, int stride, int pad, int ldw, int in_layout, int precision, mi355_stream_t stream) {
+int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bias, const float* pos, float* y, int B, int Cin, int H,
+                            int W, int Cout, int KH, int KW, int stride, int pad, int ldw, int in_layout, int act, int precision,
+                            mi355_stream_t stream) {
     MI355_CHECK_ARG(x && weight && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     MI355_CHECK_ARG(in_layout == 0 || in_layout == 1);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     MI355_CHECK_ARG(OH > 0 && OW > 0);
     const int Kreal = Cin * KH * KW, K = (Kreal + 3) & ~3;
@@ -385,7 +387,7 @@ int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bi
     if (!aligned16(x) || !aligned16(weight) || (in_layout == 1 && (Cin & 3)))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_conv2d_tokens_fwd: 16-byte aligned buffers and, for token-major input, Cin %% 4 == 0 (Cin=%d)", Cin);
     GemmArgs g{};
-    g.A = x; g.B = weight; g.C = y; g.bias = bias;
+    g.A = x; g.B = weight; g.C = y; g.bias = bias; g.pos = pos; g.act = act;
     g.P = OH * OW; g.Pout = g.P; g.OW = OW; g.Kreal = Kreal;
     g.M = B * g.P; g.N = Cout; g.K = K; g.lda = 0; g.ldb = ldw; g.ldc = Cout;
     g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;

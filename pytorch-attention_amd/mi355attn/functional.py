@@ -389,8 +389,31 @@ def conv_weight_rows(param, in_layout):
     return out
 
 
-def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, precision=None):
-    """Conv2d -> token-major (B, OH*OW, Cout).  x is NCHW (in_layout 0) or tokens (B, H*W, Cin) with hw=(H, W) (in_layout 1)."""
+def conv_bn_rows(conv_w, bn, in_layout):
+    """Conv weight with the eval-mode BatchNorm that follows it folded in (xcit.py:79-86 conv3x3 = Conv2d(bias=False) + BatchNorm2d):
+    w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps), as GEMM rows like conv_weight_rows.  Cached per version
+    of the five tensors involved."""
+    parts = (conv_w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = (id(conv_w), id(bn), in_layout, "bn")
+    tag = tuple((t._version, t.data_ptr()) for t in parts) + (bn.eps,)
+    hit = _wrow_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    w = conv_w.detach() * s[:, None, None, None]
+    bias = (bn.bias.detach() - bn.running_mean.detach() * s).contiguous()
+    cout = w.shape[0]
+    rows = (w if in_layout == 0 else w.permute(0, 2, 3, 1)).reshape(cout, -1)
+    k = rows.shape[1]
+    out = torch.zeros(cout, (k + 3) // 4 * 4, dtype=torch.float32, device=w.device)
+    out[:, :k] = rows
+    _wrow_cache[key] = (tag, (out, bias))
+    return out, bias
+
+
+def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, precision=None, act=ACT_NONE, pos=None, wrows=None):
+    """Conv2d -> token-major (B, OH*OW, Cout) = act(conv + bias + pos).  x is NCHW (in_layout 0) or tokens (B, H*W, Cin) with
+    hw=(H, W) (in_layout 1).  `wrows` passes prepared GEMM rows (conv_bn_rows) instead of a Conv2d weight."""
     x = require_device_f32(x, "x")
     if in_layout == 0:
         B, Cin, H, W = x.shape
@@ -399,16 +422,41 @@ def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, prec
         H, W = hw
         if L != H * W:
             raise ValueError("conv2d_tokens: token count does not match hw")
-    wrows = conv_weight_rows(weight, in_layout)
+    if wrows is None:
+        wrows = conv_weight_rows(weight, in_layout)
     Cout = wrows.shape[0]
     bias = _opt(bias, "bias")
     OH = (H + 2 * pad - kernel) // stride + 1
     OW = (W + 2 * pad - kernel) // stride + 1
+    if pos is not None:
+        pos = require_device_f32(pos, "pos")
+        if pos.numel() != OH * OW * Cout:
+            raise ValueError("conv2d_tokens: pos must hold one row per output token")
     y = torch.empty(B, OH * OW, Cout, dtype=torch.float32, device=x.device)
-    check(lib().mi355_conv2d_tokens_fwd(dptr(x), dptr(wrows), dptr(bias), dptr(y), B, Cin, H, W, Cout, kernel, kernel, stride, pad,
-                                        wrows.shape[1], in_layout, _prec(precision), stream_ptr(x.device)),
+    check(lib().mi355_conv2d_tokens_fwd(dptr(x), dptr(wrows), dptr(bias), dptr(pos), dptr(y), B, Cin, H, W, Cout, kernel, kernel,
+                                        stride, pad, wrows.shape[1], in_layout, act, _prec(precision), stream_ptr(x.device)),
           "mi355_conv2d_tokens_fwd")
     return y, (OH, OW)
+
+
+def class_attention(q, k, v, num_heads, scale, N, ldq, ldkv):
+    """One query per (image, head) over N keys; q/k/v are (possibly strided) views into fp32 device tensors."""
+    B = q.shape[0]
+    C = q.shape[-1]
+    out = torch.empty(B, C, dtype=torch.float32, device=q.device)
+    check(lib().mi355_class_attn_fwd(dptr(q), dptr(k), dptr(v), dptr(out), B, N, num_heads, C // num_heads, ldq, ldkv, float(scale),
+                                     stream_ptr(q.device)), "mi355_class_attn_fwd")
+    return out
+
+
+def axpby(x, y, rows, cols, ldx, ldy, alpha=1.0, u=None, ldu=0, gamma=None):
+    """y[r,c] = alpha*x[r,c] + gamma[c]*u[r,c] on strided row views (pointers = the tensors' data_ptr, strides in floats)."""
+    for t in (x, y, u, gamma):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise _ffi.Mi355Error("axpby: fp32 device tensors only (there is no CPU path)")
+    check(lib().mi355_axpby_fwd(dptr(x), dptr(u), dptr(gamma), dptr(y), rows, cols, ldx, ldu, ldy, float(alpha),
+                                stream_ptr(x.device)), "mi355_axpby_fwd")
+    return y
 
 
 def token_mean(x, skip_first=0):

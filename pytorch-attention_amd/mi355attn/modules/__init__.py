@@ -3,4 +3,5 @@ from .cswin import (CSWin_64_12211_tiny_224, CSWin_64_24322_small_224, CSWinBloc
                     LePEAttention, Merge_Block)
 from .mixer import MLP_Mixer, MixerLayer  # noqa: F401
 from .vit import Attention, PatchEmbedding, TransformerEncoder, VisionTransformer  # noqa: F401
-from .xcit import LPI, XCA, XCABlock  # noqa: F401
+from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed, PositionalEncodingFourier, XCABlock, XCiT,  # noqa: F401
+                   xcit_nano_12_p16)

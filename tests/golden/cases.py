@@ -68,7 +68,31 @@ CASES = [
          oracle=lambda x, sd, dt: O.cswin_forward(x, sd, dtype=dt)),
     dict(id="mixer_full", mod="mlps.mlp_mixer", cls="MLP_Mixer", shape=(2, 3, 224, 224), slow=True,
          oracle=lambda x, sd, dt: O.mixer_forward(x, sd, 12, dt)),
+    # XCiT: the class-attention stage alone (cls token = token 0 of the input) and the only factory the reference ships.
+    # `prep` perturbs the BatchNorm statistics / affine terms so that the folded-BN patch embedding is actually exercised
+    # (module-default BatchNorm is the identity up to eps).
+    dict(id="xcit_cls_block", mod="vision_transformers.xcit", cls="ClassAttentionBlock", args=(128, 4),
+         kwargs=dict(qkv_bias=True, eta=1.0), shape=(2, 197, 128), fwd_args=(14, 14),
+         oracle=lambda x, sd, dt: O.class_attention_block_forward(x, sd, 4, dt)),
+    dict(id="xcit_nano_full", mod="vision_transformers.xcit", cls="xcit_nano_12_p16", shape=(2, 3, 224, 224), slow=True,
+         prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 4, 12, 2, dt)),
 ]
+
+
+def perturb_batchnorm(module):
+    """Deterministic non-trivial BatchNorm state (running stats and affine) for every BatchNorm2d of `module`."""
+    import torch
+    g = torch.Generator().manual_seed(777)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.copy_(0.2 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.num_features, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.num_features, generator=g))
+
+
+PREP = {"perturb_batchnorm": perturb_batchnorm}
 
 BY_ID = {c["id"]: c for c in CASES}
 
@@ -78,3 +102,12 @@ N_SAMPLES = 257            # strided sample positions recorded per case (prime -
 def sample_index(numel, n=N_SAMPLES):
     """Deterministic sample positions: i * (numel-1) // (n-1), i = 0..n-1 (first and last included)."""
     return [i * (numel - 1) // (n - 1) for i in range(n)]
+
+
+def build_case(c, cls):
+    """Module + input of a case under the seed protocol, with the case's optional state preparation applied."""
+    from oracle.params import seeded_module_inputs
+    m, x = seeded_module_inputs(lambda: cls(*c.get("args", ()), **c.get("kwargs", {})), c["shape"])
+    if c.get("prep"):
+        PREP[c["prep"]](m)
+    return m, x

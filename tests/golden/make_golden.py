@@ -27,8 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-from cases import CASES, sample_index  # noqa: E402
-from oracle.params import seeded_module_inputs  # noqa: E402
+from cases import CASES, build_case, sample_index  # noqa: E402
 
 
 def main():
@@ -44,7 +43,7 @@ def main():
     for c in CASES:
         mod = importlib.import_module(c["mod"])
         cls = getattr(mod, c["cls"])
-        m, x = seeded_module_inputs(lambda: cls(*c.get("args", ()), **c.get("kwargs", {})), c["shape"])
+        m, x = build_case(c, cls)
         with torch.no_grad():
             y = m(x, *c.get("fwd_args", ()))
         yf = y.reshape(-1)

@@ -12,9 +12,8 @@ import importlib
 import pytest
 import torch
 
-from cases import BY_ID, CASES, sample_index
+from cases import BY_ID, CASES, build_case, sample_index
 from conftest import assert_parity
-from oracle.params import seeded_module_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +23,7 @@ VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256"}
 def _run(c, precision=None):
     import mi355attn
     cls = getattr(importlib.import_module(c["mod"]), c["cls"])
-    m, x = seeded_module_inputs(lambda: cls(*c.get("args", ()), **c.get("kwargs", {})), c["shape"])
+    m, x = build_case(c, cls)
     ref = c["oracle"](x, m.state_dict(), torch.float32)
     old = mi355attn.default_precision()
     if precision is not None:

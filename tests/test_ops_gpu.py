@@ -177,6 +177,75 @@ def test_token_mean(B, N, C, skip):
     assert_parity(y, x[:, skip:].double().mean(dim=1).float(), 1e-6, "token_mean")
 
 
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv2d_tokens_epilogue_pos_and_gelu(act):
+    """act(conv + bias + pos): the position rows are indexed by output token, shared by all images (XCiT patch embedding)."""
+    torch.manual_seed(3)
+    B, Cin, H, W, Cout = 3, 8, 12, 10, 24
+    img = torch.randn(B, Cin, H, W)
+    w, b = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9), torch.randn(Cout)
+    ref = torch.nn.functional.conv2d(img.double(), w.double(), b.double(), stride=2, padding=1)
+    OH, OW = ref.shape[-2:]
+    pos = torch.randn(OH * OW, Cout)
+    ref = ref.flatten(2).transpose(1, 2) + pos.double()
+    if act:
+        ref = gelu64(ref)
+    tokens = img.flatten(2).transpose(1, 2).contiguous().cuda()
+    y, _ = F().conv2d_tokens(tokens, torch.nn.Parameter(w.cuda()), b.cuda(), 3, 2, 1, 1, hw=(H, W), precision=0, act=act, pos=pos.cuda())
+    assert_parity(y.cpu(), ref.float(), TOL[0], "conv2d_tokens[pos, act]")
+
+
+def test_conv_bn_folding_matches_eval_batchnorm():
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(6, 16, 3, stride=2, padding=1, bias=False)
+    bn = torch.nn.BatchNorm2d(16).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(1, 0.3); bn.bias.normal_(0, 0.3)
+    x = torch.randn(2, 6, 9, 9)
+    with torch.no_grad():
+        ref = bn(conv(x)).flatten(2).transpose(1, 2)
+    conv, bn = conv.cuda(), bn.cuda()
+    wrows, bias = F().conv_bn_rows(conv.weight, bn, 0)
+    y, _ = F().conv2d_tokens(x.cuda(), None, bias, 3, 2, 1, 0, precision=0, wrows=wrows)
+    assert_parity(y.cpu(), ref, TOL[0], "conv + folded BatchNorm")
+
+
+@pytest.mark.parametrize("B,N,h,d", [(3, 197, 4, 32), (2, 50, 8, 16), (1, 1, 2, 64), (2, 300, 3, 48), (5, 64, 4, 32)])
+def test_class_attention_core(B, N, h, d):
+    """One query per (image, head) against fp64; q/k/v are consumed in place from the fused (B,N,3C) projection."""
+    torch.manual_seed(N + d)
+    C = h * d
+    qkv = torch.randn(B, N, 3 * C)
+    scale = d ** -0.5
+    q = qkv[:, 0, :C].double().reshape(B, h, 1, d)
+    k = qkv[:, :, C:2 * C].double().reshape(B, N, h, d).permute(0, 2, 1, 3)
+    v = qkv[:, :, 2 * C:].double().reshape(B, N, h, d).permute(0, 2, 1, 3)
+    a = torch.softmax((q * k).sum(-1) * scale, dim=-1)
+    ref = (a.unsqueeze(2) @ v).transpose(1, 2).reshape(B, C)
+    dev = qkv.cuda()
+    out = F().class_attention(dev[:, 0, :C], dev[:, :, C:2 * C], dev[:, :, 2 * C:], h, scale, N, N * 3 * C, 3 * C)
+    assert_parity(out.cpu(), ref.float(), 2e-6, "class attention")
+
+
+def test_axpby_strided_rows():
+    """y = alpha*x + gamma*u on strided row views: cls-row gather / scatter, broadcast row, token-block copy, scalar tail."""
+    torch.manual_seed(9)
+    B, N, C = 3, 7, 20
+    x, u, g = torch.randn(B, N, C), torch.randn(B, C), torch.randn(C)
+    xd, ud, gd = x.cuda(), u.cuda(), g.cuda()
+    c1 = torch.empty(B, C, device="cuda")
+    F().axpby(xd, c1, B, C, N * C, C, alpha=0.5, u=ud, ldu=C, gamma=gd)                  # gather cls rows + scaled residual
+    assert_parity(c1.cpu(), 0.5 * x[:, 0] + g * u, 1e-6, "axpby gather")
+    out = torch.zeros(B, N + 1, C, device="cuda")
+    F().axpby(gd, out, B, C, 0, (N + 1) * C)                                               # broadcast one row into every image
+    F().axpby(xd, out[:, 1:], B, N * C, N * C, (N + 1) * C)                                # token blocks behind it
+    assert torch.equal(out.cpu(), torch.cat([g.expand(B, 1, C), x], dim=1))
+    odd = torch.randn(5, 9)
+    y = torch.empty(5, 9, device="cuda")
+    F().axpby(odd.cuda(), y, 5, 9, 9, 9, alpha=2.0)                                        # cols % 4 != 0: scalar path
+    assert torch.equal(y.cpu(), 2.0 * odd)
+
+
 # ---------------------------------------------------------------------------------------------- attention cores
 def _sdpa_ref(qkv, h, scale):
     B, N, C3 = qkv.shape

@@ -17,14 +17,13 @@ import numpy as np
 import pytest
 import torch
 
-from cases import BY_ID, CASES, sample_index
+from cases import BY_ID, CASES, build_case, sample_index
 from conftest import REFERENCE, ROOT, have_reference, rel_fro
-from oracle.params import seeded_module_inputs
 
 
 def _build(c):
     cls = getattr(importlib.import_module(c["mod"]), c["cls"])
-    return seeded_module_inputs(lambda: cls(*c.get("args", ()), **c.get("kwargs", {})), c["shape"])
+    return build_case(c, cls)
 
 
 CASE_IDS = [c["id"] for c in CASES]

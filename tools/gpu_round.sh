@@ -9,12 +9,12 @@ timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -6 > gpurun
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
 rm -f gpurun_out/bench_others.jsonl
 timeout 300 python bench.py --workload c3 --steps 10 --warmup 3 --cpu-sample 16 >> gpurun_out/bench_others.jsonl 2>> gpurun_out/bench_others.err
-for w in c4 c5 mixer da cswin mixer_full; do
+for w in c4 c5 mixer da cswin mixer_full xcit; do
   timeout 300 python bench.py --no-cpu --workload $w --steps 5 --warmup 2 >> gpurun_out/bench_others.jsonl 2>> gpurun_out/bench_others.err
 done
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-for w in c2 c3 c4 c5 cswin mixer_full; do
+for w in c2 c3 c4 c5 cswin mixer_full xcit; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o $w -- python $R/bench.py --no-cpu --workload $w --steps 3 --warmup 1 > $R/gpurun_out/prof_$w.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_c2 -o c2 -- python $R/bench.py --no-cpu --steps 3 --warmup 1 > $R/gpurun_out/pmc_fetch_c2.log 2>&1
