@@ -186,6 +186,17 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
                           float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
                           mi355_stream_t stream);
 
+/* General multi-head attention core (the plain softmax(QK^T*s)V pattern of setr.py:62-72, pvt.py:73-91,
+ * segformer.py:33-50, cmt.py:93-111, moat.py:74-84, bvit.py:66-76 ...): any N_q / N_kv, online softmax over 64-key tiles.
+ *   out[b, n, i*d + j] = sum_m softmax_m(scale * <q[b,n,i,:], k[b,m,i,:]> + bias[b?, i, n, m]) v[b,m,i,j]
+ * q (B,Nq,.) / k,v (B,Nkv,.) / out (B,Nq,.) are addressed as  ptr + (b*N + n)*ld + i*head_dim + j  (ld = row stride in elements,
+ * >= heads*head_dim), so they may be slices of one fused projection or separate tensors.  bias (heads, Nq, Nkv) fp32 or NULL;
+ * image b uses bias + b*bias_batch_stride (0 = shared).  io16 = 0: fp32 tensors; 1: tensors in the 16-bit operand type of
+ * `precision` (1 fp16, 2 bf16).  head_dim in {32, 64}. */
+int mi355_sdpa_general_fwd(const void* q, const void* k, const void* v, const float* bias, void* out, int B, int num_heads, int Nq,
+                           int Nkv, int head_dim, long ldq, long ldk, long ldv, long ldo, long bias_batch_stride, float scale,
+                           int io16, int precision, mi355_stream_t stream);
+
 /* ---- model-level glue (callers of the blocks) ------------------------------------------------------------ */
 
 /* Conv2d as implicit GEMM, token-major output: y (B, OH*OW, Cout) = act(conv(x) + bias + pos); no im2col buffer.

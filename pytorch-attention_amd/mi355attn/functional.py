@@ -439,6 +439,46 @@ def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, prec
     return y, (OH, OW)
 
 
+def _rows3(t, name):
+    """(B, N, C') device view with unit channel stride and a dense batch axis -> (tensor, row stride)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dim() != 3:
+        raise _ffi.Mi355Error(f"{name}: expected a (B, N, C) device tensor (there is no CPU path)")
+    if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
+def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None):
+    """softmax(q k^T * scale + bias) v for (B,Nq,C) queries and (B,Nkv,C) keys / values (views into fused projections welcome).
+    fp32 tensors -> fp32 result; fp16 / bf16 tensors (the operand type of `precision`) -> same type.  bias: (heads,Nq,Nkv) or
+    (B,heads,Nq,Nkv) fp32."""
+    p = _prec(precision)
+    q, ldq = _rows3(q, "q")
+    k, ldk = _rows3(k, "k")
+    v, ldv = _rows3(v, "v")
+    B, Nq, C = q.shape
+    Nkv = k.shape[1]
+    if k.shape != (B, Nkv, C) or v.shape != (B, Nkv, C) or C % num_heads:
+        raise ValueError("sdpa_general: q (B,Nq,C), k/v (B,Nkv,C) with C divisible by num_heads")
+    io16 = q.dtype != torch.float32
+    if io16 and (p == PREC_STRICT or q.dtype != dtype16(p)):
+        raise ValueError("sdpa_general: 16-bit tensors must be in the operand type of the precision mode")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("sdpa_general: q, k, v must share one element type")
+    bstride = 0
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+        if bias.dim() == 4 and bias.shape[0] == B and B > 1:
+            bstride = num_heads * Nq * Nkv
+        if bias.numel() != (B if bstride else 1) * num_heads * Nq * Nkv:
+            raise ValueError("sdpa_general: bias must be (heads,Nq,Nkv) or (B,heads,Nq,Nkv)")
+    out = torch.empty(B, Nq, C, dtype=q.dtype, device=q.device)
+    check(lib().mi355_sdpa_general_fwd(dptr(q), dptr(k), dptr(v), dptr(bias), dptr(out), B, num_heads, Nq, Nkv, C // num_heads,
+                                       ldq, ldk, ldv, C, bstride, float(scale), 1 if io16 else 0, p, stream_ptr(q.device)),
+          "mi355_sdpa_general_fwd")
+    return out
+
+
 def class_attention(q, k, v, num_heads, scale, N, ldq, ldkv):
     """One query per (image, head) over N keys; q/k/v are (possibly strided) views into fp32 device tensors."""
     B = q.shape[0]

@@ -265,6 +265,72 @@ def test_sdpa(B, N, h, d, prec):
     assert_parity(out, _sdpa_ref(qkv, h, d ** -0.5).float(), TOL[prec], f"sdpa{(B, N, h, d)} p{prec}")
 
 
+GENERAL = [  # B, Nq, Nkv, heads, d, bias
+    (2, 197, 197, 3, 64, False),      # ViT-like
+    (2, 784, 49, 2, 64, False),       # PVT / SegFormer: keys from a spatially reduced grid
+    (1, 1024, 1024, 2, 64, False),    # SETR at 512x512: 16 key tiles
+    (2, 50, 300, 4, 32, True),        # ragged: partial query block, partial last key tile, additive bias
+    (3, 1, 77, 2, 32, False),         # single query
+    (2, 196, 49, 4, 32, True),        # CMT: relative-position term, N_kv % 4 != 0 -> scalar bias loads
+    (1, 65, 64, 1, 64, True),         # exactly one key tile, N_kv % 4 == 0 -> vector bias loads
+]
+
+
+def _general_ref(q, k, v, h, scale, bias):
+    B, Nq, C = q.shape
+    d = C // h
+    qh = q.double().reshape(B, Nq, h, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, -1, h, d).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, -1, h, d).permute(0, 2, 1, 3)
+    att = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        att = att + bias.double()
+    return (torch.softmax(att, dim=-1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("B,Nq,Nkv,h,d,with_bias", GENERAL)
+def test_sdpa_general(B, Nq, Nkv, h, d, with_bias, prec):
+    """Streaming attention core vs fp64: N_q != N_kv, partial tiles, optional additive bias; q sliced out of a fused (B,N,3C)
+    projection when N_q == N_kv (strided rows), separate tensors otherwise."""
+    torch.manual_seed(Nq * 7 + Nkv)
+    C = h * d
+    scale = d ** -0.5
+    if Nq == Nkv:
+        qkv = torch.randn(B, Nq, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        dev = qkv.cuda()
+        qd, kd, vd = dev[..., :C], dev[..., C:2 * C], dev[..., 2 * C:]
+    else:
+        q, k, v = torch.randn(B, Nq, C), torch.randn(B, Nkv, C), torch.randn(B, Nkv, C)
+        qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    bias = torch.randn(h, Nq, Nkv) if with_bias else None
+    out = F().sdpa_general(qd, kd, vd, h, scale, bias=None if bias is None else bias.cuda(), precision=prec).cpu()
+    assert_parity(out, _general_ref(q, k, v, h, scale, bias).float(), TOL[prec], "sdpa_general")
+
+
+@pytest.mark.parametrize("prec,dt", [(1, torch.float16), (2, torch.bfloat16)])
+def test_sdpa_general_16bit_io_and_batched_bias(prec, dt):
+    torch.manual_seed(5)
+    B, Nq, Nkv, h, d = 2, 130, 200, 2, 64
+    C = h * d
+    q, k, v = (torch.randn(B, n, C).to(dt) for n in (Nq, Nkv, Nkv))
+    bias = torch.randn(B, h, Nq, Nkv)
+    out = F().sdpa_general(q.cuda(), k.cuda(), v.cuda(), h, 0.125, bias=bias.cuda(), precision=prec)
+    assert out.dtype == dt
+    ref = _general_ref(q.float(), k.float(), v.float(), h, 0.125, bias)
+    assert_parity(out.float().cpu(), ref.float(), TOL[prec], "sdpa_general[16-bit io]")
+
+
+def test_sdpa_general_matches_short_sequence_kernel():
+    """Same problem through the all-keys-in-LDS kernel (mi355_sdpa_fwd) and the streaming kernel: both within tolerance of each other."""
+    torch.manual_seed(6)
+    qkv = torch.randn(2, 197, 3 * 768).cuda()
+    a = F().sdpa(qkv, 12, 0.125, precision=0)
+    b = F().sdpa_general(qkv[..., :768], qkv[..., 768:1536], qkv[..., 1536:], 12, 0.125, precision=0)
+    assert_parity(b.cpu(), a.cpu(), 2e-5, "streaming vs resident")
+
+
 def test_sdpa_sharp_softmax_and_large_logits():
     """Rows whose max dwarfs the rest (one spiked key) and logits ~ +-60: the masked/shifted softmax must stay finite."""
     torch.manual_seed(1)
