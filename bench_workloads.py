@@ -141,4 +141,35 @@ def workload_xcit(B, dev):
     return _full_model(xcit_nano_12_p16, "XCiT-nano-12/16", flop, lambda xs, sd: O.xcit_forward(xs, sd), B, dev)
 
 
-WORKLOADS = {"xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}
+def workload_zoo(B, dev):
+    """SimAM, SRM, Gaussian GCT, LCT, GCT at the C2 shape: HBM-bound, algorithmic bytes = read x + write y."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+    from cases import perturb_all
+    from mi355attn.modules import GCT, LCT, SRM, GaussianGCT, simam_module
+    C, H = 256, 56
+    torch.manual_seed(4321)
+    x = torch.randn(B, C, H, H, device=dev)
+    nbytes = 2.0 * C * H * H * 4
+    blocks = []
+    for name, ctor in (("simam_module", lambda: simam_module()), ("SRM(256)", lambda: SRM(C)), ("GaussianGCT(256)", lambda: GaussianGCT(C)),
+                       ("LCT(256,16)", lambda: LCT(C, 16)), ("GCT(256,l2)", lambda: GCT(C))):
+        m = _seeded(ctor)
+        perturb_all(m)
+        sd = _sd(m)
+        if name.startswith("simam"):
+            cpu = lambda xs: O.simam_forward(xs)
+        elif name.startswith("SRM"):
+            cpu = (lambda s: (lambda xs: O.srm_forward(xs, s["cfc.weight"], s["bn.weight"], s["bn.bias"], s["bn.running_mean"], s["bn.running_var"])))(sd)
+        elif name.startswith("Gaussian"):
+            cpu = lambda xs: O.gct_gauss_forward(xs)
+        elif name.startswith("LCT"):
+            cpu = (lambda s: (lambda xs: O.lct_forward(xs, s["w"], s["b"], 16)))(sd)
+        else:
+            cpu = (lambda s: (lambda xs: O.gct_forward(xs, s["alpha"], s["gamma"], s["beta"])))(sd)
+        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="hbm", work=nbytes * B, cpu=cpu))
+    return dict(name="SimAM+SRM+GaussianGCT+LCT+GCT fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, gather=None, dtype="f32")
+
+
+WORKLOADS = {"zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

@@ -71,6 +71,7 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   else writes it between calls and it is not freed and re-allocated behind the library's back (call
  *                   mi355_workspace_forget before freeing it).  The library then remembers the buffer, stamps every launch with
  *                   a fresh tag and skips the memset (43 MB per call at the C2 shape of CBAM).
+ *   "zoo_single"    1 (default) = SimAM / SRM / GCT / LCT read x once when the shape allows; 0 = always two passes.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
@@ -108,6 +109,28 @@ int    mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, c
                              const float* wV, const float* bV, const float* wP, const float* bP, float* y,
                              int B, int C, int cm, int cn, int H, int W, int precision,
                              void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ---- the rest of the channel-attention zoo: per-channel statistic -> tiny transform -> broadcast scale ------------
+ * NCHW fp32, HBM-bound, x read once / y written once when HW % 4 == 0, HW <= 4096 and C % 8 == 0 (8 channel rows per workgroup stay
+ * in registers; GCT / LCT exchange one number per channel between the workgroups of an image exactly like mi355_se_fwd), two plain
+ * passes otherwise.  One workspace size serves all five: mi355_chan_stat_workspace_bytes(B, C).  "zoo_single" = 0 forces two passes.
+ *   simam      simam.py:32-41      y = x * sigmoid(d / (4 * (sum_hw d / (HW-1) + e_lambda)) + 0.5),  d = (x - mean_hw x)^2
+ *   srm        srm.py:23-34        g = sigmoid(BatchNorm1d_eval(cfc[c,0] * mean_hw x + cfc[c,1] * std_hw x)), std unbiased; cfc (C,2)
+ *   gct_gauss  gct.py:23-30        g = exp(-c/2 * yn^2), yn = (m - mean_c m) / sqrt(mean_c m^2 - (mean_c m)^2 + eps), m = mean_hw x
+ *   lct        lct.py:29-39        g = sigmoid(w[c] * yn + b[c]), yn as above but over the C/groups channels of the channel's group
+ *   gct        gate_channel_module.py:32-50   l2: e = sqrt(sum_hw x^2 + eps) * alpha, g = 1 + tanh(e * gamma / sqrt(mean_c e^2 + eps) + beta)
+ *                                             l1: e = sum_hw |x| * alpha (x itself when after_relu), g = 1 + tanh(e * gamma / (mean_c |e| + eps) + beta) */
+size_t mi355_chan_stat_workspace_bytes(int B, int C);
+int mi355_simam_fwd(const float* x, float* y, int B, int C, int H, int W, float e_lambda, void* ws, size_t ws_bytes, mi355_stream_t stream);
+int mi355_srm_fwd(const float* x, const float* cfc, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                  const float* bn_var, float bn_eps, float* y, int B, int C, int H, int W, void* ws, size_t ws_bytes,
+                  mi355_stream_t stream);
+int mi355_gct_gauss_fwd(const float* x, float* y, int B, int C, int H, int W, float c, float eps, void* ws, size_t ws_bytes,
+                        mi355_stream_t stream);
+int mi355_lct_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int groups, int H, int W, float eps,
+                  void* ws, size_t ws_bytes, mi355_stream_t stream);
+int mi355_gct_fwd(const float* x, const float* alpha, const float* gamma, const float* beta, float* y, int B, int C, int H, int W,
+                  float epsilon, int mode_l1, int after_relu, void* ws, size_t ws_bytes, mi355_stream_t stream);
 
 /* ---- dense building blocks used by the transformer blocks ---------------------------------------- */
 

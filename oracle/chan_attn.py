@@ -136,3 +136,65 @@ def double_attention_forward(x, wA, bA, wB, bB, wV, bV, wP, bP, dtype=torch.floa
     wp = _prep(wP, dtype).reshape(wP.shape[0], wP.shape[1])
     out = torch.einsum("om,bmn->bon", wp, Z) + _prep(bP, dtype)[None, :, None]
     return out.reshape(b, wp.shape[0], h, w)
+
+
+# ---- the rest of the channel-attention zoo -------------------------------------------------------------------
+def simam_forward(x, e_lambda=1e-4, dtype=torch.float32):
+    """simam_module.forward -- attention_mechanisms/simam.py:32-41: d = (x - mean_hw)^2; y = d / (4 (sum_hw d / (HW-1) + lambda)) + 0.5;
+    out = x * sigmoid(y)."""
+    x = x.detach().to("cpu", dtype)
+    n = x.shape[2] * x.shape[3] - 1
+    d = (x - x.mean(dim=(2, 3), keepdim=True)) ** 2
+    y = d / (4 * (d.sum(dim=(2, 3), keepdim=True) / n + e_lambda)) + 0.5
+    return x * torch.sigmoid(y)
+
+
+def srm_forward(x, cfc, bn_w, bn_b, bn_mean, bn_var, bn_eps=1e-5, dtype=torch.float32):
+    """SRM.forward -- attention_mechanisms/srm.py:23-34: u = [mean_hw, std_hw (unbiased)]; z_c = cfc[c,0,0]*mean + cfc[c,0,1]*std (depth-wise
+    Conv1d k=2 == per-channel dot product); BatchNorm1d in eval mode; g = sigmoid; out = x * g."""
+    x = x.detach().to("cpu", dtype)
+    b, c = x.shape[:2]
+    flat = x.reshape(b, c, -1)
+    mean = flat.mean(-1)
+    std = torch.sqrt(((flat - mean[..., None]) ** 2).sum(-1) / (flat.shape[-1] - 1))
+    w = cfc.detach().to("cpu", dtype).reshape(c, 2)
+    z = w[:, 0] * mean + w[:, 1] * std
+    t = lambda v: v.detach().to("cpu", dtype)
+    z = (z - t(bn_mean)) / torch.sqrt(t(bn_var) + bn_eps) * t(bn_w) + t(bn_b)
+    return x * torch.sigmoid(z)[:, :, None, None]
+
+
+def _channel_norm(y, eps):
+    """(y - mean) / sqrt(E[y^2] - mean^2 + eps) over the last axis (gct.py:25-28, lct.py:31-34)."""
+    mean = y.mean(dim=-1, keepdim=True)
+    var = (y ** 2).mean(dim=-1, keepdim=True) - mean ** 2
+    return (y - mean) / torch.sqrt(var + eps)
+
+
+def gct_gauss_forward(x, c=2, eps=1e-5, dtype=torch.float32):
+    """GCT.forward -- attention_mechanisms/gct.py:23-30: channel means normalised over the channel axis, gate exp(-(yn^2 / 2 * c))."""
+    x = x.detach().to("cpu", dtype)
+    yn = _channel_norm(x.mean(dim=(2, 3)), eps)
+    return x * torch.exp(-(yn ** 2 / 2 * c))[:, :, None, None]
+
+
+def lct_forward(x, w, b, groups, eps=1e-5, dtype=torch.float32):
+    """LCT.forward -- attention_mechanisms/lct.py:29-39: channel means normalised inside each of `groups` channel groups, affine, sigmoid."""
+    x = x.detach().to("cpu", dtype)
+    B, C = x.shape[:2]
+    yn = _channel_norm(x.mean(dim=(2, 3)).reshape(B, groups, -1), eps).reshape(B, C)
+    g = torch.sigmoid(w.detach().to("cpu", dtype) * yn + b.detach().to("cpu", dtype))
+    return x * g[:, :, None, None]
+
+
+def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False, dtype=torch.float32):
+    """GCT.forward -- attention_mechanisms/gate_channel_module.py:32-50 (l2: :34-36, l1: :38-44): gate = 1 + tanh(e * norm + beta)."""
+    x = x.detach().to("cpu", dtype)
+    al, ga, be = (p.detach().to("cpu", dtype).reshape(1, -1) for p in (alpha, gamma, beta))
+    if mode == "l2":
+        e = torch.sqrt((x ** 2).sum(dim=(2, 3)) + epsilon) * al
+        norm = ga / torch.sqrt((e ** 2).mean(dim=1, keepdim=True) + epsilon)
+    else:
+        e = (x if after_relu else x.abs()).sum(dim=(2, 3)) * al
+        norm = ga / (e.abs().mean(dim=1, keepdim=True) + epsilon)
+    return x * (1.0 + torch.tanh(e * norm + be))[:, :, None, None]

@@ -18,6 +18,7 @@
 // slots written by earlier launches never look valid and the region is only zeroed when its history is unknown; polls are
 // bounded and raise the workspace error word instead of hanging.
 #include "common.h"
+#include "bufops.h"
 
 namespace {
 
@@ -28,16 +29,6 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr u32 SPIN_LIMIT = 1u << 21;
 
-// Everything goes through raw buffer instructions: one wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset + a
-// wave-uniform SGPR offset.  Lanes / channels outside the band get an offset beyond num_records: their loads return 0 and their
-// stores are dropped by the hardware range check, so the streaming loops carry no predicates and one VGPR of address state.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int AUX_SC1 = 16, AUX_NT = 2;
-constexpr u32 OOB = 0x80000000u;                                    // >= any num_records used here (per-image extents < 2 GB)
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, u32 bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
 __device__ __forceinline__ void gran_put(rsrc_t g, u32 idx, float v0, float v1, u32 TAG) {
     const u32x4 v = {__float_as_uint(v0), TAG, __float_as_uint(v1), TAG};
     __builtin_amdgcn_raw_buffer_store_b128(v, g, idx * 16u, 0, AUX_SC1);      // one write-through 16-byte store

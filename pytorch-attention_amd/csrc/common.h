@@ -27,6 +27,8 @@ void  ws_forget(const void* region);
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
 long  opt_cbam_threads();
+long  opt_zoo_single();
+size_t zoo_workspace_bytes(int B, int C);
 size_t cbam_single_extra_bytes(int B, int C, int H, int W);
 bool  cbam_single_applicable(int C, int Cr, int H, int W, int ks);
 int   cbam_single(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr, int H, int W,

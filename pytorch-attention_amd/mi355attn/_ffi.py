@@ -59,6 +59,12 @@ SIGNATURES = {
     "mi355_cswin_lepe_attn16_fwd": (c_int, [c_vp] * 4 + [c_int] * 8 + [c_float, c_int, c_vp]),
     "mi355_conv2d_tokens_fwd": (c_int, [c_vp] * 5 + [c_int] * 13 + [c_vp]),
     "mi355_token_mean_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.c_long, c_vp]),
+    "mi355_chan_stat_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "mi355_simam_fwd": (c_int, [c_vp, c_vp] + [c_int] * 4 + [ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_srm_fwd": (c_int, [c_vp] * 6 + [ctypes.c_float, c_vp] + [c_int] * 4 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_gct_gauss_fwd": (c_int, [c_vp, c_vp] + [c_int] * 4 + [ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_lct_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_gct_fwd": (c_int, [c_vp] * 5 + [c_int] * 4 + [ctypes.c_float, c_int, c_int, c_vp, ctypes.c_size_t, c_vp]),
     "mi355_sdpa_general_fwd": (c_int, [c_vp] * 5 + [c_int] * 5 + [ctypes.c_long] * 5 + [ctypes.c_float, c_int, c_int, c_vp]),
     "mi355_class_attn_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
     "mi355_axpby_fwd": (c_int, [c_vp] * 4 + [ctypes.c_long, c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),

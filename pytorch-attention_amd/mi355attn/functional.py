@@ -118,6 +118,57 @@ def cbam_forward(x, w1=None, w2=None, wconv=None, stage=0):
     return y
 
 
+def _zoo(kind, x):
+    """Common prologue of the channel-statistics gates: dense fp32 device x, output, dedicated workspace (exchange area)."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    n = lib().mi355_chan_stat_workspace_bytes(B, C)
+    return x, torch.empty_like(x), _ffi.workspace_dedicated((kind, B, C, H, W), n, x.device), (B, C, H, W)
+
+
+def simam_forward(x, e_lambda=1e-4):
+    x, y, ws, (B, C, H, W) = _zoo("simam", x)
+    check(lib().mi355_simam_fwd(dptr(x), dptr(y), B, C, H, W, float(e_lambda), dptr(ws), ws.numel(), stream_ptr(x.device)),
+          "mi355_simam_fwd")
+    return y
+
+
+def srm_forward(x, cfc, bn_weight, bn_bias, bn_mean, bn_var, bn_eps):
+    x, y, ws, (B, C, H, W) = _zoo("srm", x)
+    cfc = require_device_f32(cfc, "cfc.weight").reshape(C, 2)
+    ps = [require_device_f32(t, n) for t, n in ((bn_weight, "bn.weight"), (bn_bias, "bn.bias"), (bn_mean, "bn.running_mean"),
+                                                (bn_var, "bn.running_var"))]
+    check(lib().mi355_srm_fwd(dptr(x), dptr(cfc), dptr(ps[0]), dptr(ps[1]), dptr(ps[2]), dptr(ps[3]), float(bn_eps), dptr(y),
+                              B, C, H, W, dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_srm_fwd")
+    return y
+
+
+def gct_gauss_forward(x, c=2, eps=1e-5):
+    x, y, ws, (B, C, H, W) = _zoo("gct_gauss", x)
+    check(lib().mi355_gct_gauss_fwd(dptr(x), dptr(y), B, C, H, W, float(c), float(eps), dptr(ws), ws.numel(), stream_ptr(x.device)),
+          "mi355_gct_gauss_fwd")
+    return y
+
+
+def lct_forward(x, w, b, groups, eps=1e-5):
+    x, y, ws, (B, C, H, W) = _zoo("lct", x)
+    w, b = require_device_f32(w, "w"), require_device_f32(b, "b")
+    check(lib().mi355_lct_fwd(dptr(x), dptr(w), dptr(b), dptr(y), B, C, int(groups), H, W, float(eps), dptr(ws), ws.numel(),
+                              stream_ptr(x.device)), "mi355_lct_fwd")
+    return y
+
+
+def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False):
+    if mode not in ("l2", "l1"):
+        raise ValueError("GCT mode must be 'l2' or 'l1'")
+    x, y, ws, (B, C, H, W) = _zoo("gct", x)
+    alpha, gamma, beta = (require_device_f32(t, n).reshape(-1) for t, n in ((alpha, "alpha"), (gamma, "gamma"), (beta, "beta")))
+    check(lib().mi355_gct_fwd(dptr(x), dptr(alpha), dptr(gamma), dptr(beta), dptr(y), B, C, H, W, float(epsilon),
+                              1 if mode == "l1" else 0, 1 if after_relu else 0, dptr(ws), ws.numel(), stream_ptr(x.device)),
+          "mi355_gct_fwd")
+    return y
+
+
 def double_attention_forward(x, wA, bA, wB, bB, wV, bV, wP, bP, precision=None):
     x = require_device_f32(x, "x")
     B, C, H, W = x.shape

@@ -5,3 +5,4 @@ from .mixer import MLP_Mixer, MixerLayer  # noqa: F401
 from .vit import Attention, PatchEmbedding, TransformerEncoder, VisionTransformer  # noqa: F401
 from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed, PositionalEncodingFourier, XCABlock, XCiT,  # noqa: F401
                    xcit_nano_12_p16)
+from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401

@@ -74,6 +74,32 @@ CASES = [
     dict(id="xcit_cls_block", mod="vision_transformers.xcit", cls="ClassAttentionBlock", args=(128, 4),
          kwargs=dict(qkv_bias=True, eta=1.0), shape=(2, 197, 128), fwd_args=(14, 14),
          oracle=lambda x, sd, dt: O.class_attention_block_forward(x, sd, 4, dt)),
+    # ---- more of the channel-attention zoo; `prep` gives the learnable gates non-trivial parameters ----------------
+    dict(id="simam64", mod="attention_mechanisms.simam", cls="simam_module", shape=(2, 64, 32, 32), small=True,
+         oracle=lambda x, sd, dt: O.simam_forward(x, 1e-4, dt)),
+    dict(id="srm64", mod="attention_mechanisms.srm", cls="SRM", args=(64,), shape=(2, 64, 32, 32), small=True, prep="perturb_all",
+         oracle=lambda x, sd, dt: O.srm_forward(x, sd["cfc.weight"], sd["bn.weight"], sd["bn.bias"], sd["bn.running_mean"],
+                                                sd["bn.running_var"], 1e-5, dt)),
+    dict(id="gctg64", mod="attention_mechanisms.gct", cls="GCT", args=(64,), shape=(2, 64, 32, 32), small=True,
+         oracle=lambda x, sd, dt: O.gct_gauss_forward(x, 2, 1e-5, dt)),
+    dict(id="lct64", mod="attention_mechanisms.lct", cls="LCT", args=(64, 8), shape=(2, 64, 32, 32), small=True, prep="perturb_all",
+         oracle=lambda x, sd, dt: O.lct_forward(x, sd["w"], sd["b"], 8, 1e-5, dt)),
+    dict(id="gct64", mod="attention_mechanisms.gate_channel_module", cls="GCT", args=(64,), shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], 1e-5, "l2", False, dt)),
+    dict(id="gct64_l1", mod="attention_mechanisms.gate_channel_module", cls="GCT", args=(64,), kwargs=dict(mode="l1"),
+         shape=(2, 64, 32, 32), prep="perturb_all",
+         oracle=lambda x, sd, dt: O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], 1e-5, "l1", False, dt)),
+    dict(id="simam256", mod="attention_mechanisms.simam", cls="simam_module", shape=(4, 256, 56, 56),
+         oracle=lambda x, sd, dt: O.simam_forward(x, 1e-4, dt)),
+    dict(id="srm256", mod="attention_mechanisms.srm", cls="SRM", args=(256,), shape=(4, 256, 56, 56), prep="perturb_all",
+         oracle=lambda x, sd, dt: O.srm_forward(x, sd["cfc.weight"], sd["bn.weight"], sd["bn.bias"], sd["bn.running_mean"],
+                                                sd["bn.running_var"], 1e-5, dt)),
+    dict(id="gctg256", mod="attention_mechanisms.gct", cls="GCT", args=(256,), shape=(4, 256, 56, 56),
+         oracle=lambda x, sd, dt: O.gct_gauss_forward(x, 2, 1e-5, dt)),
+    dict(id="lct256", mod="attention_mechanisms.lct", cls="LCT", args=(256, 16), shape=(4, 256, 56, 56), prep="perturb_all",
+         oracle=lambda x, sd, dt: O.lct_forward(x, sd["w"], sd["b"], 16, 1e-5, dt)),
+    dict(id="gct256", mod="attention_mechanisms.gate_channel_module", cls="GCT", args=(256,), shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], 1e-5, "l2", False, dt)),
     dict(id="xcit_nano_full", mod="vision_transformers.xcit", cls="xcit_nano_12_p16", shape=(2, 3, 224, 224), slow=True,
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 4, 12, 2, dt)),
 ]
@@ -92,7 +118,20 @@ def perturb_batchnorm(module):
                 m.bias.copy_(0.2 * torch.randn(m.num_features, generator=g))
 
 
-PREP = {"perturb_batchnorm": perturb_batchnorm}
+def perturb_all(module):
+    """Deterministic perturbation of every parameter and BatchNorm buffer (the zoo's gates are the identity at their default init)."""
+    import torch
+    g = torch.Generator().manual_seed(778)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(0.3 * torch.randn(p.shape, generator=g))
+        for m in module.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(0.2 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+
+
+PREP = {"perturb_batchnorm": perturb_batchnorm, "perturb_all": perturb_all}
 
 BY_ID = {c["id"]: c for c in CASES}
 

@@ -341,3 +341,77 @@ def test_full_size_properties(which):
         lo = torch.where(ok, ratio, torch.full_like(ratio, 2.0)).amin(dim=1)
         hi = torch.where(ok, ratio, torch.full_like(ratio, -1.0)).amax(dim=1)
         assert float((hi - lo).max()) < 1e-4 and float(lo.min()) > 0.0 and float(hi.max()) < 1.0
+
+
+# ---- SimAM / SRM / Gaussian GCT / LCT / GCT -------------------------------------------------------------------------
+def _zoo_mods(C, groups):
+    from mi355attn.modules import GCT, LCT, SRM, GaussianGCT, simam_module
+    from cases import perturb_all
+    torch.manual_seed(31)
+    mods = dict(simam=simam_module(), srm=SRM(C).eval(), gctg=GaussianGCT(C), lct=LCT(C, groups), gct=GCT(C), gct_l1=GCT(C, mode="l1"),
+                gct_l1r=GCT(C, mode="l1", after_relu=True))
+    for m in mods.values():
+        perturb_all(m)
+    return mods
+
+
+def _zoo_ref(name, m, x):
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    if name == "simam":
+        return O.simam_forward(x, m.e_lambda)
+    if name == "srm":
+        return O.srm_forward(x, sd["cfc.weight"], sd["bn.weight"], sd["bn.bias"], sd["bn.running_mean"], sd["bn.running_var"], m.bn.eps)
+    if name == "gctg":
+        return O.gct_gauss_forward(x, m.c, m.eps)
+    if name == "lct":
+        return O.lct_forward(x, sd["w"], sd["b"], m.groups, m.eps)
+    return O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], m.epsilon, m.mode, m.after_relu)
+
+
+ZOO_SHAPES = [(2, 64, 32, 32, 8), (3, 256, 56, 56, 16), (2, 48, 7, 9, 4), (1, 20, 5, 5, 5), (2, 16, 2, 2, 2), (1, 24, 64, 64, 3),
+              (5, 40, 12, 12, 8), (2, 12, 3, 1, 4), (1, 1024, 14, 14, 32)]
+
+
+@pytest.mark.parametrize("single", [1, 0])
+@pytest.mark.parametrize("shape", ZOO_SHAPES)
+def test_zoo_gates_vs_oracle(shape, single, monkeypatch):
+    """All five modules (GCT in its three variants) against the oracle: shapes that take the single-read register path, shapes that
+    cannot (HW % 4 != 0, C % 8 != 0) and the forced two-pass path; run-to-run identical."""
+    import mi355attn
+    monkeypatch.setenv("MI355_CHECK_SYNC", "1")
+    B, C, H, W, groups = shape
+    mods = _zoo_mods(C, groups)
+    torch.manual_seed(32)
+    x = torch.randn(B, C, H, W)
+    xd = x.cuda()
+    mi355attn.set_option("zoo_single", single)
+    try:
+        for name, m in mods.items():
+            with torch.no_grad():
+                y = m.cuda()(xd)
+                y2 = m(xd)
+            assert torch.equal(y, y2), name
+            assert_parity(y.cpu(), _zoo_ref(name, m, x), 2e-5, f"{name} {shape} single={single}")
+    finally:
+        mi355attn.set_option("zoo_single", 1)
+
+
+def test_zoo_single_and_two_pass_agree_and_repeat():
+    """Exchange protocol of the GCT / LCT kernels under repetition on one dedicated workspace, and agreement of the two paths."""
+    import mi355attn
+    mods = _zoo_mods(256, 16)
+    torch.manual_seed(33)
+    x = torch.randn(24, 256, 28, 28).cuda()
+    for name in ("gctg", "lct", "gct", "gct_l1"):
+        m = mods[name].cuda()
+        with torch.no_grad():
+            first = m(x).clone()
+            for _ in range(100):
+                y = m(x)
+            assert torch.equal(y, first), name
+            mi355attn.set_option("zoo_single", 0)
+            try:
+                two = m(x)
+            finally:
+                mi355attn.set_option("zoo_single", 1)
+        assert_parity(first.cpu(), two.cpu(), 2e-6, f"{name}: single read vs two passes")

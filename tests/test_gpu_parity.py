@@ -17,7 +17,8 @@ from conftest import assert_parity
 
 pytestmark = pytest.mark.gpu
 
-VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256"}
+VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256", "simam64", "srm64", "gctg64", "lct64", "gct64", "gct64_l1",
+               "simam256", "srm256", "gctg256", "lct256", "gct256"}
 
 
 def _run(c, precision=None):

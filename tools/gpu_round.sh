@@ -19,4 +19,5 @@ for w in c2 c3 c4 c5 cswin mixer_full xcit; do
 done
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_c2 -o c2 -- python $R/bench.py --no-cpu --steps 3 --warmup 1 > $R/gpurun_out/pmc_fetch_c2.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_c2 -o c2 -- python $R/bench.py --no-cpu --steps 3 --warmup 1 > $R/gpurun_out/pmc_write_c2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_mfma_c3 -o c3 -- python $R/bench.py --no-cpu --workload c3 --steps 3 --warmup 1 > $R/gpurun_out/pmc_mfma_c3.log 2>&1
 cd $R
