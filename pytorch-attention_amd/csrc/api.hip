@@ -19,6 +19,7 @@ static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in r
 static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
 static std::atomic<long> g_cbam_threads{512}; // workgroup size of the single-read CBAM: 512 (2 per CU) or 256 (4 per CU, finer bands)
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
+static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
 
 char* err_buf() { return g_err; }
 
@@ -82,6 +83,7 @@ void ws_forget_range(const void* base, size_t bytes) {
 
 long opt_cbam_threads() { return g_cbam_threads.load(std::memory_order_relaxed); }
 long opt_zoo_single() { return g_zoo_single.load(std::memory_order_relaxed); }
+long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
@@ -146,6 +148,11 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_zoo_single.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "se_occ") == 0) {
+        MI355_CHECK_ARG(value == 2 || value == 3);
+        mi355::g_se_occ.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "reverse") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_reverse.store(value, std::memory_order_relaxed);
@@ -168,6 +175,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
     if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
+    if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
     if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
     if (key && std::strcmp(key, "cbam_threads") == 0) return mi355::opt_cbam_threads();
     if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();

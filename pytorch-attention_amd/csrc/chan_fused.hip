@@ -22,6 +22,7 @@
 // register file can only keep ~4 slices (200 KB) per CU in flight: Little's law caps it near 1-2 TB/s.  Kept behind
 // mi355_set_option("fused", 1|2) as the measured negative result.
 #include "common.h"
+#include "bufops.h"
 
 namespace {
 
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(256) void se_eca_fused_kernel(const FusedArgs a) {
 // not depend on which workgroup computes it.
 constexpr int ECW = 8;
 
-template <int NV, bool NTL, bool NTS>
-__global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restrict__ x, const float* __restrict__ taps,
-                                                          float* __restrict__ y, int C, int k, int HW, int n4, int gpi, int total,
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NV, bool NTS>
+__global__ __launch_bounds__(512, 6) void eca_halo_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                          float* __restrict__ y, int C, int k, int HW, int gpi, int total,
                                                           int per_xcd) {
     __shared__ float s_mean[ECW + 8];                        // means of channels c0-pad .. c0+ECW+pad-1
     const int s = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -159,16 +162,14 @@ __global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restric
     const int b = s / gpi, c0 = (s - b * gpi) * ECW;
     const float inv = 1.0f / (float)HW;
     const float* img = x + (long)b * C * HW;
-
-    // own row -> registers
+    // rows through buffer descriptors: lanes beyond the row read zeros and their stores are dropped, so the streaming loops carry
+    // no predicates and one VGPR of address state (<= 80 VGPRs: three workgroups per CU)
+    const u32 cw = __builtin_amdgcn_readfirstlane((u32)(c0 + wave));
+    const rsrc_t rx = make_rsrc(img + (long)cw * HW, (u32)HW * 4u);
+    const u32 voff = (u32)lane * 16u;
     v4f r[NV];
-    const v4f* xr = reinterpret_cast<const v4f*>(img + (long)(c0 + wave) * HW);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < n4) r[j] = NTL ? __builtin_nontemporal_load(&xr[i]) : xr[i];
-        else r[j] = v4f{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < NV; ++j) r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (u32)j * 1024u, 0));
     // halo row of this wave (if any): same lane/step order as an own row, streamed
     int hc = -1, hslot = 0;
     if (wave < 2 * pad) {
@@ -178,14 +179,12 @@ __global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restric
     const bool halo_live = hc >= 0 && hc < C;                 // wave-uniform
     float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
     if (halo_live) {
-        const v4f* hr = reinterpret_cast<const v4f*>(img + (long)hc * HW);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            if (i < n4) {
-                const v4f v = hr[i];
-                h0 += v.x; h1 += v.y; h2 += v.z; h3 += v.w;
-            }
+        const u32 hcw = __builtin_amdgcn_readfirstlane((u32)hc);
+        const rsrc_t rh = make_rsrc(img + (long)hcw * HW, (u32)HW * 4u);
+#pragma unroll 4
+        for (int j = 0; j < NV; ++j) {                        // a real loop (4 loads in flight): the own row already fills the registers
+            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rh, voff, (u32)j * 1024u, 0));
+            h0 += v.x; h1 += v.y; h2 += v.z; h3 += v.w;
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -201,14 +200,14 @@ __global__ __launch_bounds__(512, 4) void eca_halo_kernel(const float* __restric
     float z = 0.f;
     for (int j = 0; j < k; ++j) z += taps[j] * s_mean[wave + j];
     const float g = sigmoidf_(z);
-    v4f* yr = reinterpret_cast<v4f*>(y + ((long)b * C + c0 + wave) * HW);
+    const rsrc_t ry = make_rsrc(y + ((long)b * C + cw) * HW, (u32)HW * 4u);
+    u32 ob = voff;                                            // the row step rides in the VGPR offset of the stores: cbam_single.hip
+    asm volatile("" : "+v"(ob));
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < n4) {
-            if (NTS) __builtin_nontemporal_store(r[j] * g, &yr[i]);
-            else yr[i] = r[j] * g;
-        }
+        const v4f o = r[j] * g;
+        if (NTS) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ob + (u32)j * 1024u, 0, AUX_NT);
+        else     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ob + (u32)j * 1024u, 0, 0);
     }
 }
 
@@ -230,8 +229,8 @@ struct SeSingleArgs {
     u32 tag, tbase;                    // granule tag and ticket base of this launch (api.hip ws_epoch)
 };
 
-template <int NV, bool NTS, bool WLDS>
-__global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a) {
+template <int NV, bool NTS, bool WLDS, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // p[C] | h[Cr] | (WLDS: W1[Cr*C] | W2[C*Cr])
     __shared__ u32 s_tk[2];
     float* s_p = smem;
@@ -252,14 +251,13 @@ __global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a)
         const u32 tk = s_tk[par];
         if (tk >= (u32)a.total) return;
         const int b = tk / a.gpi, c0 = (tk - b * a.gpi) * ECW;
-        const long row = ((long)b * a.C + c0 + wave) * a.HW;
+        const u32 rw = __builtin_amdgcn_readfirstlane((u32)(b * a.C + c0 + wave));
+        const long row = (long)rw * a.HW;
+        const rsrc_t rx = make_rsrc(a.x + row, (u32)a.HW * 4u), ry = make_rsrc(a.y + row, (u32)a.HW * 4u);
+        const u32 voff = (u32)lane * 16u;                              // lanes beyond the row: zeros in, stores dropped (range check)
         v4f r[NV];
-        const v4f* xr = reinterpret_cast<const v4f*>(a.x + row);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            r[j] = (i < a.n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < NV; ++j) r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (u32)j * 1024u, 0));
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
@@ -318,14 +316,13 @@ __global__ __launch_bounds__(512, 4) void se_single_kernel(const SeSingleArgs a)
         float z = 0.f;
         for (int j = lane; j < a.Cr; j += 64) z += w2r[j] * s_h[j];
         const float g = sigmoidf_(wave_sum(z));
-        v4f* yr = reinterpret_cast<v4f*>(a.y + row);
+        u32 ob = voff;                                                // row step in the VGPR offset of the stores: cbam_single.hip
+        asm volatile("" : "+v"(ob));
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            if (i < a.n4) {
-                if (NTS) __builtin_nontemporal_store(r[j] * g, &yr[i]);
-                else yr[i] = r[j] * g;
-            }
+            const v4f o = r[j] * g;
+            if (NTS) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ob + (u32)j * 1024u, 0, AUX_NT);
+            else     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ob + (u32)j * 1024u, 0, 0);
         }
         par ^= 1;
     }
@@ -412,8 +409,8 @@ int eca_single(const float* x, const float* taps, float* y, int B, int C, int k,
     // at the C2 shape: 0.307 ms plain vs 0.358 ms with non-temporal loads); "nt" bit1 still selects non-temporal stores.
 #define GO(NV_)                                                                                                        \
     do {                                                                                                               \
-        if (nt & 2) eca_halo_kernel<NV_, false, true><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd);  \
-        else        eca_halo_kernel<NV_, false, false><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, n4, gpi, total, per_xcd); \
+        if (nt & 2) eca_halo_kernel<NV_, true><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, gpi, total, per_xcd);   \
+        else        eca_halo_kernel<NV_, false><<<grid, 512, 0, st>>>(x, taps, y, C, k, HW, gpi, total, per_xcd);  \
     } while (0)
     if (nv <= 1) GO(1);
     else if (nv <= 2) GO(2);
@@ -450,7 +447,9 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    long grid = (long)ncu * 2;                            // two 512-thread workgroups per CU (<= 128 VGPRs)
+    const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
+    const int occ = (opt_se_occ() == 3 && (!wlds || (size_t)(C + Cr + 2 * C * Cr) * 4 <= 50 * 1024)) ? 3 : 2;
+    long grid = (long)ncu * occ;                          // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
     if (grid > a.total) grid = a.total;
     const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ 0x5E00000000000000ull;
     const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid));     // one draw per slice + one stop draw per workgroup
@@ -461,16 +460,18 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
         if (e == hipSuccess) e = hipMemsetAsync(gran, 0, se_single_extra_bytes(B, C), st);
         if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: memset -> %s", hipGetErrorString(e)); }
     }
-    const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
     const size_t smem = (size_t)(C + Cr + (wlds ? 2 * C * Cr : 0)) * sizeof(float);
     const int nv = (a.n4 + 63) / 64;
     const bool nts = (opt_nt() & 2) != 0;
 #define GO(NV_)                                                                                     \
     do {                                                                                            \
-        if (nts && wlds)  se_single_kernel<NV_, true, true><<<(int)grid, 512, smem, st>>>(a);       \
-        else if (nts)     se_single_kernel<NV_, true, false><<<(int)grid, 512, smem, st>>>(a);      \
-        else if (wlds)    se_single_kernel<NV_, false, true><<<(int)grid, 512, smem, st>>>(a);      \
-        else              se_single_kernel<NV_, false, false><<<(int)grid, 512, smem, st>>>(a);     \
+        if (occ == 3) {                                                                             \
+            if (wlds) se_single_kernel<NV_, true, true, 3><<<(int)grid, 512, smem, st>>>(a);        \
+            else      se_single_kernel<NV_, true, false, 3><<<(int)grid, 512, smem, st>>>(a);       \
+        } else if (nts && wlds)  se_single_kernel<NV_, true, true, 2><<<(int)grid, 512, smem, st>>>(a);   \
+        else if (nts)     se_single_kernel<NV_, true, false, 2><<<(int)grid, 512, smem, st>>>(a);   \
+        else if (wlds)    se_single_kernel<NV_, false, true, 2><<<(int)grid, 512, smem, st>>>(a);   \
+        else              se_single_kernel<NV_, false, false, 2><<<(int)grid, 512, smem, st>>>(a);  \
     } while (0)
     if (nv <= 1) GO(1);
     else if (nv <= 2) GO(2);

@@ -104,7 +104,7 @@ __device__ __forceinline__ void group_reduce(const float* s_p, int c, int cpg, f
 }
 
 template <int MODE, int NV, bool NTS>
-__global__ __launch_bounds__(512, 4) void stat_single_kernel(const StatArgs a) {
+__global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_kernel(const StatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_p[];       // exchange modes: the image's C published values
     __shared__ float s_red[32];
     __shared__ u32 s_tk[2];
@@ -288,7 +288,7 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
         int dev = 0, ncu = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        long grid = (long)ncu * (XCH ? 2 : 3);                    // the exchange-free kernels fit three workgroups per CU (<= 80 VGPRs)
+        long grid = (long)ncu * (MODE == M_SIMAM ? 2 : 3);        // three workgroups per CU (<= 80 VGPRs); SimAM's per-element gate needs 120
         if (grid > a.total) grid = a.total;
         if (XCH) {
             if (ws_bytes < mi355::zoo_workspace_bytes(B, C)) return mi355::fail(MI355_EINVAL, "channel-statistics gate: workspace too small");

@@ -20,6 +20,7 @@ long  opt_fused();
 long  opt_gemm_variant();
 long  opt_eca_single();
 long  opt_se_single();
+long  opt_se_occ();
 long  opt_ws_persistent();
 struct WsEpoch { unsigned tag; unsigned ticket_base; bool fresh; };
 WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws);   // api.hip: tag + ticket base of this launch
