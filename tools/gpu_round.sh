@@ -9,7 +9,7 @@ timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -6 > gpurun
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
 rm -f gpurun_out/bench_others.jsonl
 timeout 300 python bench.py --workload c3 --steps 10 --warmup 3 --cpu-sample 16 >> gpurun_out/bench_others.jsonl 2>> gpurun_out/bench_others.err
-for w in c4 c5 mixer da cswin mixer_full xcit; do
+for w in c4 c5 mixer da cswin mixer_full xcit zoo; do
   timeout 300 python bench.py --no-cpu --workload $w --steps 5 --warmup 2 >> gpurun_out/bench_others.jsonl 2>> gpurun_out/bench_others.err
 done
 R=${GRAFT_REPO_ROOT:-$PWD}
