@@ -244,6 +244,13 @@ int mi355_token_mean_fwd(const float* x, float* y, int B, int N, int C, long bat
 int mi355_class_attn_fwd(const float* q, const float* k, const float* v, float* out, int B, int N, int num_heads, int head_dim,
                          long ldq, long ldkv, float scale, mi355_stream_t stream);
 
+/* Depth-wise patch convolution on a token grid: x (B, H*W, C) -> y (B, (H/sr)*(W/sr), C), kernel == stride == sr, groups == C,
+ *   y[b, oy*OW + ox, c] = bias[c] + sum_{ky,kx} weight[c, ky*sr + kx] * x[b, (oy*sr + ky)*W + ox*sr + kx, c]
+ * (the spatial reduction in front of K / V in PVT / CMT, pvt.py:66-70; an eval-mode BatchNorm is folded into weight / bias by the
+ * caller).  bias may be NULL.  C % 4 == 0, H % sr == 0, W % sr == 0. */
+int mi355_dwconv_patch_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int H, int W, int C,
+                                  int sr, mi355_stream_t stream);
+
 /* y[r, c] = alpha * x[r, c] + gamma[c] * u[r, c]  over rows x cols with row strides ldx / ldu / ldy (floats; ldx or ldu may be 0
  * to broadcast one row).  u == NULL drops the second term, gamma == NULL means 1.  The token-axis glue of the XCiT class-attention
  * stage (xcit.py:219-231, 402-403): residual with LayerScale, cls-row scatter / gather, token concatenation. */

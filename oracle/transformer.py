@@ -135,3 +135,53 @@ def mixer_forward(img, p, depth=12, dtype=torch.float32):
     for i in range(depth):
         x = mixer_layer_forward(x, _sub(p, f"blocks.{i}."), dtype)
     return linear(x.mean(dim=1), _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))
+
+
+def mhsa_forward(x, p, num_heads, H=None, W=None, sr_ratio=1, relative_pos=None, layout="qkv", dtype=torch.float32, bn_eps=1e-5):
+    """The plain multi-head attention of the reference's other ViT files.
+
+    layout "qkv"    : fused qkv Linear                                   -- setr.py:62-72, moat.py:74-84
+    layout "q,k,v"  : separate Linears; K/V source reduced by a depth-wise conv (k = s = sr_ratio, bias) + BatchNorm2d(eval)
+                      when sr_ratio > 1; optional additive relative_pos    -- pvt.py:73-91, cmt.py:93-111
+    layout "q,kv"   : q Linear + fused kv Linear; K/V source reduced by a dense conv (k = s = sr_ratio, bias)   -- segformer.py:33-50
+    """
+    import torch.nn.functional as TF
+    x = _t(x, dtype)
+    B, N, C = x.shape
+    d = C // num_heads
+
+    def opt(k):
+        return _t(p[k], dtype) if k in p else None
+
+    src = x
+    if sr_ratio > 1:
+        grid = x.transpose(1, 2).reshape(B, C, H, W)
+        if layout == "q,k,v":
+            grid = TF.conv2d(grid, _t(p["sr.0.weight"], dtype), opt("sr.0.bias"), stride=sr_ratio, groups=C)
+            mean, var = _t(p["sr.1.running_mean"], dtype), _t(p["sr.1.running_var"], dtype)
+            grid = (grid - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + bn_eps)
+            grid = grid * _t(p["sr.1.weight"], dtype)[None, :, None, None] + _t(p["sr.1.bias"], dtype)[None, :, None, None]
+        else:
+            grid = TF.conv2d(grid, _t(p["sr.weight"], dtype), opt("sr.bias"), stride=sr_ratio)
+        src = grid.reshape(B, C, -1).transpose(1, 2)
+    if layout == "qkv":
+        qkv = linear(x, _t(p["qkv.weight"], dtype), opt("qkv.bias"))
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    elif layout == "q,k,v":
+        q = linear(x, _t(p["q.weight"], dtype), opt("q.bias"))
+        k = linear(src, _t(p["k.weight"], dtype), opt("k.bias"))
+        v = linear(src, _t(p["v.weight"], dtype), opt("v.bias"))
+    else:
+        q = linear(x, _t(p["q.weight"], dtype), opt("q.bias"))
+        kv = linear(src, _t(p["kv.weight"], dtype), opt("kv.bias"))
+        k, v = kv[..., :C], kv[..., C:]
+    out = torch.empty(B, N, C, dtype=dtype)
+    for i in range(num_heads):
+        sl = slice(i * d, (i + 1) * d)
+        s = (q[..., sl] @ k[..., sl].transpose(-1, -2)) * d ** -0.5
+        if relative_pos is not None:
+            s = s + _t(relative_pos, dtype)[i]
+        s = s - s.amax(dim=-1, keepdim=True)
+        e = torch.exp(s)
+        out[..., sl] = (e / e.sum(dim=-1, keepdim=True)) @ v[..., sl]
+    return linear(out, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))

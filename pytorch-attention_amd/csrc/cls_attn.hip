@@ -83,9 +83,49 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
     }
 }
 
+// Depth-wise "patch" convolution on a token grid (kernel == stride == sr, groups == C): the spatial reduction in front of K / V in
+// PVT / CMT (pvt.py:66-70).  One thread per (output token, 4 channels); taps read channel-contiguous float4's.
+__global__ __launch_bounds__(256) void dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int B, int H, int W, int C, int sr) {
+    const int c4 = C >> 2, OH = H / sr, OW = W / sr;
+    const long total = (long)B * OH * OW * c4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % c4) * 4;
+        long r = e / c4;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        v4f acc = bias ? *reinterpret_cast<const v4f*>(bias + c) : v4f{0.f, 0.f, 0.f, 0.f};
+        const float* xb = x + ((long)b * H * W) * C + c;
+        for (int ky = 0; ky < sr; ++ky)
+            for (int kx = 0; kx < sr; ++kx) {
+                const v4f v = *reinterpret_cast<const v4f*>(xb + ((long)(oy * sr + ky) * W + ox * sr + kx) * C);
+                const int tap = ky * sr + kx, kk = sr * sr;
+                acc.x += w[(long)c * kk + tap] * v.x;
+                acc.y += w[(long)(c + 1) * kk + tap] * v.y;
+                acc.z += w[(long)(c + 2) * kk + tap] * v.z;
+                acc.w += w[(long)(c + 3) * kk + tap] * v.w;
+            }
+        *reinterpret_cast<v4f*>(y + (((long)b * OH + oy) * OW + ox) * C + c) = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mi355_dwconv_patch_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int H, int W, int C, int sr,
+                                  mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y && B > 0 && H > 0 && W > 0 && C > 0 && sr > 0);
+    if ((C & 3) || (H % sr) || (W % sr) || !aligned16(x) || !aligned16(y) || (bias && !aligned16(bias)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_dwconv_patch_tokens_fwd: C %% 4 == 0, H and W divisible by sr, 16-byte aligned buffers");
+    const long work = (long)B * (H / sr) * (W / sr) * (C / 4);
+    long blocks = (work + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    dw_patch_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, weight, bias, y, B, H, W, C, sr);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
 
 int mi355_class_attn_fwd(const float* q, const float* k, const float* v, float* out, int B, int N, int num_heads, int head_dim,
                          long ldq, long ldkv, float scale, mi355_stream_t stream) {

@@ -530,6 +530,35 @@ def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None):
     return out
 
 
+def dwconv_patch_tokens(x, conv_w, conv_b, bn, H, W, sr):
+    """Depth-wise conv (kernel == stride == sr, optional bias) + optional eval BatchNorm2d on a token grid:
+    (B, H*W, C) -> (B, (H/sr)*(W/sr), C).  Conv bias and BatchNorm are folded into one weight / bias pair, cached per version."""
+    x = require_device_f32(x, "x")
+    B, L, C = x.shape
+    if L != H * W:
+        raise ValueError("dwconv_patch_tokens: token count does not match (H, W)")
+    key = (id(conv_w), id(bn), "dwp")
+    parts = [conv_w] + ([] if conv_b is None else [conv_b]) + ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
+    tag = tuple((t._version, t.data_ptr()) for t in parts)
+    hit = _wrow_cache.get(key)
+    if hit is None or hit[0] != tag:
+        w = conv_w.detach().reshape(C, sr * sr)
+        cb = None if conv_b is None else conv_b.detach()
+        if bn is None:
+            wf, bf = w.contiguous(), cb
+        else:
+            s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+            shift = bn.running_mean.detach() if cb is None else bn.running_mean.detach() - cb
+            wf, bf = (w * s[:, None]).contiguous(), (bn.bias.detach() - shift * s).contiguous()
+        hit = (tag, (wf, bf))
+        _wrow_cache[key] = hit
+    wf, bf = hit[1]
+    y = torch.empty(B, (H // sr) * (W // sr), C, dtype=torch.float32, device=x.device)
+    check(lib().mi355_dwconv_patch_tokens_fwd(dptr(x), dptr(wf), dptr(bf), dptr(y), B, H, W, C, sr, stream_ptr(x.device)),
+          "mi355_dwconv_patch_tokens_fwd")
+    return y
+
+
 def class_attention(q, k, v, num_heads, scale, N, ldq, ldkv):
     """One query per (image, head) over N keys; q/k/v are (possibly strided) views into fp32 device tensors."""
     B = q.shape[0]

@@ -6,3 +6,4 @@ from .vit import Attention, PatchEmbedding, TransformerEncoder, VisionTransforme
 from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed, PositionalEncodingFourier, XCABlock, XCiT,  # noqa: F401
                    xcit_nano_12_p16)
 from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401
+from .mhsa import SRAttention, SRAttentionRelPos, SRConvAttention  # noqa: F401

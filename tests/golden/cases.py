@@ -100,9 +100,35 @@ CASES = [
          oracle=lambda x, sd, dt: O.lct_forward(x, sd["w"], sd["b"], 16, 1e-5, dt)),
     dict(id="gct256", mod="attention_mechanisms.gate_channel_module", cls="GCT", args=(256,), shape=(4, 256, 56, 56),
          prep="perturb_all", oracle=lambda x, sd, dt: O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], 1e-5, "l2", False, dt)),
+    # ---- plain multi-head attention of other ViT files on the streaming core (module level) ----------------------------
+    dict(id="setr_attn", mod="vision_transformers.setr", cls="Attention", args=(256, 4), kwargs=dict(qkv_bias=True), shape=(2, 1024, 256),
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 4, layout="qkv", dtype=dt)),
+    dict(id="moat_attn", mod="vision_transformers.moat", cls="Attention", args=(128, 4), shape=(2, 196, 128),
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 4, layout="qkv", dtype=dt)),
+    dict(id="pvt_attn_s1", mod="vision_transformers.pvt", cls="Attention", args=(64,), kwargs=dict(num_heads=1, qkv_bias=True, sr_ratio=8),
+         shape=(2, 3136, 64), fwd_args=(56, 56), prep="perturb_batchnorm",
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 1, 56, 56, 8, layout="q,k,v", dtype=dt)),
+    dict(id="pvt_attn_s3", mod="vision_transformers.pvt", cls="Attention", args=(320,), kwargs=dict(num_heads=5, qkv_bias=True, sr_ratio=2),
+         shape=(2, 196, 320), fwd_args=(14, 14), prep="perturb_batchnorm",
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 5, 14, 14, 2, layout="q,k,v", dtype=dt)),
+    dict(id="cmt_attn", mod="vision_transformers.cmt", cls="Attention", args=(128,), kwargs=dict(num_heads=2, qkv_bias=True, sr_ratio=2),
+         shape=(2, 784, 128), fwd_args=(28, 28, "relpos:2,784,196"), prep="perturb_batchnorm",
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 2, 28, 28, 2, relative_pos=make_arg("relpos:2,784,196"), layout="q,k,v", dtype=dt)),
+    dict(id="segformer_attn", mod="vision_transformers.segformer", cls="Attention", args=(64,), kwargs=dict(num_heads=1, qkv_bias=True, sr_ratio=8),
+         shape=(2, 3136, 64), fwd_args=(56, 56),
+         oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 1, 56, 56, 8, layout="q,kv", dtype=dt)),
     dict(id="xcit_nano_full", mod="vision_transformers.xcit", cls="xcit_nano_12_p16", shape=(2, 3, 224, 224), slow=True,
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 4, 12, 2, dt)),
 ]
+
+
+def make_arg(a):
+    """Forward arguments that are tensors are written as "relpos:<heads>,<Nq>,<Nkv>" and materialised deterministically here."""
+    if isinstance(a, str) and a.startswith("relpos:"):
+        import torch
+        shape = tuple(int(v) for v in a.split(":")[1].split(","))
+        return 0.5 * torch.randn(shape, generator=torch.Generator().manual_seed(991))
+    return a
 
 
 def perturb_batchnorm(module):

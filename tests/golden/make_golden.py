@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-from cases import CASES, build_case, sample_index  # noqa: E402
+from cases import CASES, build_case, make_arg, sample_index  # noqa: E402
 
 
 def main():
@@ -45,7 +45,7 @@ def main():
         cls = getattr(mod, c["cls"])
         m, x = build_case(c, cls)
         with torch.no_grad():
-            y = m(x, *c.get("fwd_args", ()))
+            y = m(x, *[make_arg(a) for a in c.get("fwd_args", ())])
         yf = y.reshape(-1)
         n = yf.numel()
         rec = {

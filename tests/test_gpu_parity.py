@@ -12,7 +12,7 @@ import importlib
 import pytest
 import torch
 
-from cases import BY_ID, CASES, build_case, sample_index
+from cases import BY_ID, CASES, build_case, make_arg, sample_index
 from conftest import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,8 @@ def _run(c, precision=None):
     try:
         dev = m.to("cuda")
         with torch.no_grad():
-            y = dev(x.to("cuda"), *c.get("fwd_args", ()))
+            args = [make_arg(a) for a in c.get("fwd_args", ())]
+            y = dev(x.to("cuda"), *[a.cuda() if isinstance(a, torch.Tensor) else a for a in args])
         torch.cuda.synchronize()
     finally:
         mi355attn.set_default_precision(old)

@@ -227,6 +227,22 @@ def test_class_attention_core(B, N, h, d):
     assert_parity(out.cpu(), ref.float(), 2e-6, "class attention")
 
 
+@pytest.mark.parametrize("B,H,W,C,sr,with_bias", [(2, 56, 56, 64, 8, True), (3, 14, 14, 320, 2, True), (1, 8, 12, 20, 4, False), (2, 6, 6, 8, 1, True)])
+def test_dwconv_patch_tokens(B, H, W, C, sr, with_bias):
+    """Depth-wise kernel == stride conv (+ bias) + eval BatchNorm on the token grid against ATen in fp64."""
+    torch.manual_seed(C + sr)
+    conv = torch.nn.Conv2d(C, C, sr, stride=sr, groups=C, bias=with_bias)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(1, 0.3); bn.bias.normal_(0, 0.3)
+    x = torch.randn(B, H * W, C)
+    with torch.no_grad():
+        ref = bn.double()(conv.double()(x.double().transpose(1, 2).reshape(B, C, H, W))).reshape(B, C, -1).transpose(1, 2)
+    conv, bn = conv.float().cuda(), bn.float().cuda()
+    y = F().dwconv_patch_tokens(x.cuda(), conv.weight, conv.bias, bn, H, W, sr)
+    assert_parity(y.cpu(), ref.float(), 2e-6, "dwconv_patch_tokens")
+
+
 def test_axpby_strided_rows():
     """y = alpha*x + gamma*u on strided row views: cls-row gather / scatter, broadcast row, token-block copy, scalar tail."""
     torch.manual_seed(9)
