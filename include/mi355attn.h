@@ -72,6 +72,9 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   mi355_workspace_forget before freeing it).  The library then remembers the buffer, stamps every launch with
  *                   a fresh tag and skips the memset (43 MB per call at the C2 shape of CBAM).
  *   "zoo_single"    1 (default) = SimAM / SRM / GCT / LCT read x once when the shape allows; 0 = always two passes.
+ *                   Under hipGraph stream capture the granule-exchange kernels are not used at all (a recorded launch replays with the
+ *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
+ *                   kernels instead, so captured graphs are replay-safe by construction.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);

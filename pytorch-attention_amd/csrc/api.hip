@@ -52,8 +52,30 @@ std::unordered_map<const void*, WsEntry> g_ws;
 std::atomic<unsigned> g_epoch{0x5EC0DE00u};
 }  // namespace
 
-WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws) {
+// A launch recorded by hipGraph capture replays with the SAME kernel arguments, so it cannot carry a per-launch tag or a ticket base
+// remembered on the host, and a captured memset -> kernel pair was observed to misbehave on replay (MI355X, ROCm 7.2: replays after an
+// intervening eager launch returned stale output; tests/test_chan_attn_gpu.py::test_exchange_kernels_under_graph_capture).  The
+// exchange kernels therefore step aside under capture: their callers take the multi-pass paths, which only use kernel-to-kernel
+// dependencies through memory.  ws_epoch still answers safely (constant tag, zero base, nothing remembered) if it is ever asked.
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hipStream_t st) {
     WsEpoch r{};
+    if (stream_is_capturing(st)) {
+        r.tag = 0x6A9F0001u;
+        r.fresh = true;
+        r.ticket_base = 0u;
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        g_ws.erase(region);
+        return r;
+    }
     unsigned tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
     if (tag == 0u) tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;     // 0 is what a zeroed slot holds
     r.tag = tag;

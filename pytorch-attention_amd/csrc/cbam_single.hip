@@ -437,7 +437,7 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     if (grid > a.total) grid = a.total;
     // every workgroup draws one ticket per slice plus one that tells it to stop: total + grid draws per launch
     const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ ((unsigned long long)g.NT << 40) ^ 0xCBA0000000000000ull;
-    const WsEpoch ep = ws_epoch(extra, key, (unsigned)(a.total + grid));
+    const WsEpoch ep = ws_epoch(extra, key, (unsigned)(a.total + grid), st);
     a.tag = ep.tag; a.tbase = ep.ticket_base;
     if (ep.fresh) {
         hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);

@@ -452,7 +452,7 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     long grid = (long)ncu * occ;                          // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
     if (grid > a.total) grid = a.total;
     const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ 0x5E00000000000000ull;
-    const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid));     // one draw per slice + one stop draw per workgroup
+    const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid), st);     // one draw per slice + one stop draw per workgroup
     a.tag = ep.tag; a.tbase = ep.ticket_base;
     hipError_t e = hipSuccess;
     if (ep.fresh) {

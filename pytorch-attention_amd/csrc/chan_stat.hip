@@ -277,9 +277,9 @@ template <int MODE>
 int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
     const int B = a.B, C = a.C;
     a.HW = H * W;
-    const bool single = mi355::opt_zoo_single() && (a.HW % 4 == 0) && (a.HW / 4 <= 16 * 64) && (C % ECW == 0) && aligned16(a.x) &&
-                        aligned16(a.y) && (size_t)C * 4 <= 48 * 1024 && (MODE != M_LCT || a.i0 <= C);
     constexpr bool XCH = MODE >= M_GCTG;
+    const bool single = !(XCH && mi355::stream_is_capturing(st)) && mi355::opt_zoo_single() && (a.HW % 4 == 0) && (a.HW / 4 <= 16 * 64) && (C % ECW == 0) && aligned16(a.x) &&
+                        aligned16(a.y) && (size_t)C * 4 <= 48 * 1024 && (MODE != M_LCT || a.i0 <= C);
     if (single) {
         a.n4 = a.HW / 4; a.gpi = C / ECW;
         const long total_l = (long)B * a.gpi;
@@ -297,7 +297,7 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
             a.err = a.ticket + 1;
             a.gran = reinterpret_cast<u64*>(base + 16);
             const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ ((unsigned long long)MODE << 56);
-            const mi355::WsEpoch ep = mi355::ws_epoch(ws, key, (unsigned)(a.total + grid));
+            const mi355::WsEpoch ep = mi355::ws_epoch(ws, key, (unsigned)(a.total + grid), st);
             a.tag = ep.tag; a.tbase = ep.ticket_base;
             if (ep.fresh) {
                 hipError_t e = hipMemsetAsync(ws, 0, 16 + (size_t)B * C * 8, st);

@@ -23,8 +23,9 @@ long  opt_se_single();
 long  opt_se_occ();
 long  opt_ws_persistent();
 struct WsEpoch { unsigned tag; unsigned ticket_base; bool fresh; };
-WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws);   // api.hip: tag + ticket base of this launch
+WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hipStream_t st);   // api.hip: tag + ticket base of this launch
 void  ws_forget(const void* region);
+bool  stream_is_capturing(hipStream_t st);      // hipGraph capture in progress on this stream
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
 long  opt_cbam_threads();

@@ -415,3 +415,37 @@ def test_zoo_single_and_two_pass_agree_and_repeat():
             finally:
                 mi355attn.set_option("zoo_single", 1)
         assert_parity(first.cpu(), two.cpu(), 2e-6, f"{name}: single read vs two passes")
+
+
+def test_exchange_kernels_under_graph_capture():
+    """A captured launch replays with the same kernel arguments, so the granule-exchange kernels (per-launch tags, host-side ticket
+    bases) step aside under hipGraph capture and the multi-pass paths are recorded instead.  Capture SE + CBAM + GCT + ECA, replay with
+    new inputs, interleave eager calls of the same modules (which do use the exchange kernels)."""
+    from mi355attn.modules import GCT
+    se, _, cbam = _mods(64)
+    gct = GCT(64)
+    with torch.no_grad():
+        gct.gamma.add_(0.5)
+    _, eca, _ = _mods(64)
+    mods = [se.cuda(), cbam.cuda(), gct.cuda(), eca.cuda()]
+    torch.manual_seed(41)
+    static_x = torch.randn(6, 64, 28, 28, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        for m in mods:                                    # warm-up on the capture stream (allocations, dedicated workspaces)
+            m(static_x)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        outs = [m(static_x) for m in mods]
+    for rep in range(3):
+        x = torch.randn(6, 64, 28, 28, device="cuda")
+        static_x.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        with torch.no_grad():
+            want = [m(x) for m in mods]                   # eager calls in between: per-launch tags, remembered workspaces
+        for a, b, m in zip(got, want, mods):
+            assert_parity(a.cpu(), b.cpu(), 2e-6, f"replay {rep} {type(m).__name__}")
