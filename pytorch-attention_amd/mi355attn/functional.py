@@ -5,6 +5,7 @@ per-stream workspace) with torch -- device memory and streams are torch's job, t
 library's -- and raises ``Mi355Error`` on any non-zero return code.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -274,21 +275,33 @@ def cast16(x, precision=None):
     return y
 
 
-_w16_cache = {}
+_derived = {}
+
+
+def _derived_get(anchors, subkey, tag, build):
+    """Cache of tensors derived from parameters (16-bit copies, re-laid-out or BatchNorm-folded conv weights).
+
+    `anchors` are the owning objects (parameters / modules).  An entry is keyed by their ids but only honoured while every anchor
+    is still THE SAME LIVE OBJECT (weak references: CPython recycles ids, the caching allocator recycles addresses, and a fresh
+    parameter starts at version 0 again -- an id/address/version tag alone can resurrect the weights of a deleted model), and it is
+    dropped as soon as one of them is collected, so the derived copies do not outlive their model.  `tag` captures in-place updates
+    (version counters) and moves (data pointers)."""
+    key = tuple(id(a) for a in anchors) + (subkey,)
+    hit = _derived.get(key)
+    if hit is not None and hit[1] == tag and all(r() is a for r, a in zip(hit[0], anchors)):
+        return hit[2]
+    val = build()
+    refs = tuple(weakref.ref(a, lambda _r, k=key: _derived.pop(k, None)) for a in anchors)
+    _derived[key] = (refs, tag, val)
+    return val
 
 
 def weight16(param, precision=None):
     """16-bit copy of a weight, converted once and reused until the parameter is modified (in-place version bump),
-    moved or re-precisioned."""
+    moved, re-precisioned or collected."""
     p = _prec(precision)
-    key = id(param)
-    tag = (param._version, param.data_ptr(), p, tuple(param.shape))
-    hit = _w16_cache.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
-    w16 = cast16(param.detach(), p)
-    _w16_cache[key] = (tag, w16)
-    return w16
+    tag = (param._version, param.data_ptr(), tuple(param.shape))
+    return _derived_get((param,), ("w16", p), tag, lambda: cast16(param.detach(), p))
 
 
 def layernorm16(x, weight, bias, eps=1e-5, precision=None):
@@ -417,49 +430,38 @@ def patch_embed(img, wp, bp, cls, pos, patch, precision=None):
     return tokens
 
 
-_wrow_cache = {}
+def _gemm_rows(w, in_layout):
+    cout = w.shape[0]
+    rows = (w if in_layout == 0 else w.permute(0, 2, 3, 1)).reshape(cout, -1)
+    k = rows.shape[1]
+    out = torch.zeros(cout, (k + 3) // 4 * 4, dtype=torch.float32, device=w.device)
+    out[:, :k] = rows
+    return out
 
 
 def conv_weight_rows(param, in_layout):
     """Weight of a Conv2d as the GEMM operand of mi355_conv2d_tokens_fwd: (Cout, ldw) rows, zero padded to ldw % 4 == 0,
     K ordered (c,ky,kx) for NCHW input (in_layout 0) or (ky,kx,c) for token-major input (in_layout 1).  A parameter layout
     transform done once per parameter version (like weight16)."""
-    key = (id(param), in_layout)
     tag = (param._version, param.data_ptr(), tuple(param.shape))
-    hit = _wrow_cache.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
-    w = param.detach()
-    cout = w.shape[0]
-    rows = (w if in_layout == 0 else w.permute(0, 2, 3, 1)).reshape(cout, -1)
-    k = rows.shape[1]
-    ldw = (k + 3) // 4 * 4
-    out = torch.zeros(cout, ldw, dtype=torch.float32, device=w.device)
-    out[:, :k] = rows
-    _wrow_cache[key] = (tag, out)
-    return out
+    return _derived_get((param,), ("rows", in_layout), tag, lambda: _gemm_rows(param.detach(), in_layout))
+
+
+def _bn_tag(bn):
+    return tuple((t._version, t.data_ptr()) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (bn.eps,)
 
 
 def conv_bn_rows(conv_w, bn, in_layout):
     """Conv weight with the eval-mode BatchNorm that follows it folded in (xcit.py:79-86 conv3x3 = Conv2d(bias=False) + BatchNorm2d):
     w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps), as GEMM rows like conv_weight_rows.  Cached per version
     of the five tensors involved."""
-    parts = (conv_w, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = (id(conv_w), id(bn), in_layout, "bn")
-    tag = tuple((t._version, t.data_ptr()) for t in parts) + (bn.eps,)
-    hit = _wrow_cache.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
-    s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
-    w = conv_w.detach() * s[:, None, None, None]
-    bias = (bn.bias.detach() - bn.running_mean.detach() * s).contiguous()
-    cout = w.shape[0]
-    rows = (w if in_layout == 0 else w.permute(0, 2, 3, 1)).reshape(cout, -1)
-    k = rows.shape[1]
-    out = torch.zeros(cout, (k + 3) // 4 * 4, dtype=torch.float32, device=w.device)
-    out[:, :k] = rows
-    _wrow_cache[key] = (tag, (out, bias))
-    return out, bias
+    def build():
+        s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        bias = (bn.bias.detach() - bn.running_mean.detach() * s).contiguous()
+        return _gemm_rows(conv_w.detach() * s[:, None, None, None], in_layout), bias
+
+    tag = ((conv_w._version, conv_w.data_ptr(), tuple(conv_w.shape)),) + _bn_tag(bn)
+    return _derived_get((conv_w, bn), ("bnrows", in_layout), tag, build)
 
 
 def conv2d_tokens(x, weight, bias, kernel, stride, pad, in_layout, hw=None, precision=None, act=ACT_NONE, pos=None, wrows=None):
@@ -537,22 +539,19 @@ def dwconv_patch_tokens(x, conv_w, conv_b, bn, H, W, sr):
     B, L, C = x.shape
     if L != H * W:
         raise ValueError("dwconv_patch_tokens: token count does not match (H, W)")
-    key = (id(conv_w), id(bn), "dwp")
-    parts = [conv_w] + ([] if conv_b is None else [conv_b]) + ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
-    tag = tuple((t._version, t.data_ptr()) for t in parts)
-    hit = _wrow_cache.get(key)
-    if hit is None or hit[0] != tag:
+    def build():
         w = conv_w.detach().reshape(C, sr * sr)
         cb = None if conv_b is None else conv_b.detach()
         if bn is None:
-            wf, bf = w.contiguous(), cb
-        else:
-            s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
-            shift = bn.running_mean.detach() if cb is None else bn.running_mean.detach() - cb
-            wf, bf = (w * s[:, None]).contiguous(), (bn.bias.detach() - shift * s).contiguous()
-        hit = (tag, (wf, bf))
-        _wrow_cache[key] = hit
-    wf, bf = hit[1]
+            return w.contiguous(), cb
+        s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        shift = bn.running_mean.detach() if cb is None else bn.running_mean.detach() - cb
+        return (w * s[:, None]).contiguous(), (bn.bias.detach() - shift * s).contiguous()
+
+    tag = ((conv_w._version, conv_w.data_ptr(), tuple(conv_w.shape)),) + \
+          (() if conv_b is None else ((conv_b._version, conv_b.data_ptr()),)) + (() if bn is None else _bn_tag(bn))
+    anchors = (conv_w,) + (() if conv_b is None else (conv_b,)) + (() if bn is None else (bn,))
+    wf, bf = _derived_get(anchors, ("dwpatch", sr), tag, build)
     y = torch.empty(B, (H // sr) * (W // sr), C, dtype=torch.float32, device=x.device)
     check(lib().mi355_dwconv_patch_tokens_fwd(dptr(x), dptr(wf), dptr(bf), dptr(y), B, H, W, C, sr, stream_ptr(x.device)),
           "mi355_dwconv_patch_tokens_fwd")

@@ -577,3 +577,20 @@ def test_weight16_cache_tracks_inplace_updates():
     b = f.weight16(w, 1)
     assert b is not a and torch.equal(b, w.detach().half())
     assert f.weight16(w, 2).dtype == torch.bfloat16
+
+
+def test_derived_weight_cache_is_tied_to_the_live_parameter():
+    """A deleted model must not leave 16-bit / re-laid-out weights behind for a new parameter that happens to get the same id, address
+    and version counter: the cache entry dies with its parameter (weak reference) and the copies follow the new values."""
+    import gc
+    from mi355attn import functional as Fm
+    torch.manual_seed(0)
+    seen = 0
+    for trial in range(20):
+        w = torch.nn.Parameter(torch.randn(64, 64, device="cuda") * (trial + 1))
+        w16 = Fm.weight16(w, 1)
+        assert torch.equal(w16.float(), w.detach().half().float())
+        seen = max(seen, len(Fm._derived))
+        del w, w16
+        gc.collect()
+    assert len(Fm._derived) <= seen and all(all(r() is not None for r in e[0]) for e in Fm._derived.values())
