@@ -173,6 +173,18 @@ int mi355_cswin_lepe_attn16_fwd(const void* qkv16, const float* getv_w, const fl
                                 int B, int reso, int Ctot, int c0, int Cb, int heads, int Hsp, int Wsp,
                                 float scale, int precision, mi355_stream_t stream);
 
+/* Fused LayerNorm + MLP + residual for narrow token streams (C = 64 / hidden 256: CSWin stage 1; C = 128 / hidden 512: CSWin stage 2,
+ * XCiT-nano; cswin.py:194-196 with Mlp :29-44, xcit.py:293 with Mlp :21-38):
+ *   y = x + gamma * (W2 gelu(W1' xn + b1') + b2),   xn = (x - mean) / sqrt(var + eps) over the C channels (layernorm != 0) or x.
+ * The hidden activations stay in registers (no (M x hidden) tensor in HBM).  The LayerNorm affine part must be folded into the first
+ * Linear by the caller: W1' = W1 diag(ln_weight), b1' = b1 + W1 ln_bias.  w1_16 (hidden, C) and w2_16 (C, hidden) are 16-bit in the
+ * operand type of `precision` (1 fp16, 2 bf16); for C = 128, w2_16 is arranged slice-major: (hidden/32, C, 32) with
+ * w2_16[s][c][j] = W2[c][32 s + j] (the kernel streams 32-unit slices of both matrices through LDS).  x, y (M, C), b1', b2, gamma
+ * fp32; b2 / gamma may be NULL.  Other shapes:
+ * MI355_EUNSUPPORTED (callers use mi355_layernorm16_fwd + mi355_linear16_fwd x 2). */
+int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const float* b1, const void* w2_16, const float* b2, const float* gamma,
+                        float* y, long M, int C, int hidden, int layernorm, float eps, int precision, mi355_stream_t stream);
+
 /* ---- attention cores ------------------------------------------------------------------------------ */
 
 /* ViT Attention core (ViT.py:82-86): qkv (B,N,3,h,d) fp32 as produced by the qkv Linear; out (B,N,h*d).

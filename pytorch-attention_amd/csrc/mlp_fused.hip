@@ -1,0 +1,377 @@
+// mlp_fused.hip -- y = x + gamma * (W2 gelu(W1 LN(x) + b1) + b2) in ONE kernel for narrow token streams (C = 64, hidden = 256:
+// CSWin stage 1, cswin.py:194-196 with Mlp :29-44), gfx950.
+//
+// At C = 64 the two Linears of the MLP are HBM-bound as separate kernels: the (M x 4C) hidden tensor is written and read back
+// (822 MB at the C4 shape, against 410 MB for x and y together) and the first one spends its time in the GELU epilogue.  Here the
+// hidden activations never leave registers:
+//
+//   workgroup = 16 waves sharing one LDS copy of W1 (hidden x C) and W2 (C x hidden) in the MFMA operand format
+//   wave      = 32 tokens per step (two 16-token tiles); LayerNorm in registers (a token's C channels live in 4 lanes)
+//   per 32 hidden units:  H^T = W1 . Xn^T   (MFMA; a lane then holds 4 consecutive hidden units of one token)
+//                         + b1, GELU, re-packed IN-LANE as the A operand of the second product (same trick as P in attn.hip)
+//                         Y  += gelu(H) . W2^T   (MFMA)
+//   end:                  (+ b2) * gamma -> per-wave LDS slab -> + x (re-read, Infinity-Cache resident) -> 256-byte row stores
+// LayerNorm's affine part is folded into W1 / b1 by the caller (W1' = W1 diag(ln_w), b1' = b1 + W1 ln_b): the kernel only
+// normalises.  Weights are 16-bit (fp16 / bf16 per `precision`), accumulation fp32.
+#include "common.h"
+#include "mma.h"
+
+namespace {
+
+struct MlpArgs {
+    const float* x; float* y;
+    const void* w1; const void* w2;            // 16-bit: (HD, C) and (C, HD), row-major
+    const float* b1; const float* b2; const float* gamma;
+    long M;
+    float eps;
+    int do_ln;
+};
+
+template <int PREC, int C, int HD>
+__global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
+    using M_ = Mma<PREC>;
+    using v8 = typename M_::v8;
+    using v4 = typename M_::v4;
+    using el = typename M_::e;
+    constexpr int NWV = 16, TT = 2;                 // waves per workgroup, 16-token tiles per wave and step
+    constexpr int P1 = C + 8;                       // W1 row pitch (elements): rows = hidden units, k = channels
+    constexpr int P2 = HD + 4;                      // W2 row pitch: rows = output channels, k = hidden units
+    constexpr int SP = C + 4;                       // slab pitch (floats)
+    constexpr int KS = C / 32, NT = C / 16, NKB = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    el* s_w1 = reinterpret_cast<el*>(lds);
+    el* s_w2 = s_w1 + HD * P1;
+    float* s_b1 = reinterpret_cast<float*>(s_w2 + C * P2);
+    float* s_slab = s_b1 + HD;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    // ---- weights -> LDS once per workgroup (16-byte chunks) -----------------------------------------------------------------------
+    {
+        const el* w1 = static_cast<const el*>(a.w1);
+        const el* w2 = static_cast<const el*>(a.w2);
+        for (int i = t; i < HD * (C / 8); i += 1024) {
+            const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
+            *reinterpret_cast<v8*>(s_w1 + r * P1 + c8) = *reinterpret_cast<const v8*>(w1 + (long)r * C + c8);
+        }
+        for (int i = t; i < C * (HD / 4); i += 1024) {
+            const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
+            *reinterpret_cast<v4*>(s_w2 + r * P2 + c4) = *reinterpret_cast<const v4*>(w2 + (long)r * HD + c4);
+        }
+        for (int i = t; i < HD; i += 1024) s_b1[i] = a.b1[i];
+    }
+    __syncthreads();
+    float* slab = s_slab + wave * 16 * SP;
+    const float invC = 1.0f / (float)C;
+
+    const long nchunk = (a.M + 16 * TT - 1) / (16 * TT);
+    for (long ch = (long)blockIdx.x * NWV + wave; ch < nchunk; ch += (long)gridDim.x * NWV) {
+        const long tok0 = ch * (16 * TT);
+        // ---- tokens in B-operand layout: lane (l15, g) holds channels ks*32 + g*8 + [0,8) of token tok0 + tt*16 + l15 -------------
+        v8 xb[TT][KS];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const long tok = tok0 + tt * 16 + l15;
+            f4 lo[KS], hi[KS];
+            const float* xr = a.x + (tok < a.M ? tok : 0) * C + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lo[ks] = *reinterpret_cast<const f4*>(xr + ks * 32);
+                hi[ks] = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+            }
+            float mean = 0.f, rstd = 1.f;
+            if (a.do_ln) {
+                float s = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) s += ((lo[ks].x + lo[ks].y) + (lo[ks].z + lo[ks].w)) + ((hi[ks].x + hi[ks].y) + (hi[ks].z + hi[ks].w));
+                s += __shfl_xor(s, 16, WAVE);
+                s += __shfl_xor(s, 32, WAVE);
+                mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f4 d0 = lo[ks] - mean, d1 = hi[ks] - mean;
+                    q += ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) + ((d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w));
+                }
+                q += __shfl_xor(q, 16, WAVE);
+                q += __shfl_xor(q, 32, WAVE);
+                rstd = 1.0f / sqrtf(q * invC + a.eps);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4 h0 = M_::cvt((lo[ks] - mean) * rstd), h1 = M_::cvt((hi[ks] - mean) * rstd);
+                xb[tt][ks] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            }
+        }
+        // ---- hidden units in blocks of 32: H^T = W1 Xn^T -> gelu -> Y += gelu(H) W2^T ------------------------------------------------
+        f4 o[TT][NT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) o[tt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            f4 s[TT][2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f4 bias = *reinterpret_cast<const f4*>(s_b1 + kb * 32 + h2 * 16 + g * 4);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) s[tt][h2] = bias;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v8 wf = *reinterpret_cast<const v8*>(s_w1 + (kb * 32 + h2 * 16 + l15) * P1 + ks * 32 + g * 8);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) s[tt][h2] = M_::mma(wf, xb[tt][ks], s[tt][h2]);
+                }
+            }
+            v8 pf[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                f4 p0 = s[tt][0], p1 = s[tt][1];
+                p0 = f4{gelu_fast(p0.x), gelu_fast(p0.y), gelu_fast(p0.z), gelu_fast(p0.w)};
+                p1 = f4{gelu_fast(p1.x), gelu_fast(p1.y), gelu_fast(p1.z), gelu_fast(p1.w)};
+                const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
+                pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const el* wr = s_w2 + (nt * 16 + l15) * P2 + kb * 32 + g * 4;
+                const v4 a0 = *reinterpret_cast<const v4*>(wr), a1 = *reinterpret_cast<const v4*>(wr + 16);
+                const v8 vf = v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) o[tt][nt] = M_::mma(pf[tt], vf, o[tt][nt]);
+            }
+        }
+        // ---- epilogue per token tile: (+ b2) * gamma -> slab -> + x -> row stores ------------------------------------------------------
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cidx = nt * 16 + l15;
+                const float b2 = a.b2 ? a.b2[cidx] : 0.f, gm = a.gamma ? a.gamma[cidx] : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(g * 4 + r) * SP + cidx] = (o[tt][nt][r] + b2) * gm;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const long tok = tok0 + tt * 16 + l15;
+            if (tok < a.M) {
+                const float* xr = a.x + tok * C + g * 8;
+                float* yr = a.y + tok * C + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f4 r0 = *reinterpret_cast<const f4*>(slab + l15 * SP + ks * 32 + g * 8);
+                    const f4 r1 = *reinterpret_cast<const f4*>(slab + l15 * SP + ks * 32 + g * 8 + 4);
+                    const f4 x0 = *reinterpret_cast<const f4*>(xr + ks * 32), x1 = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+                    *reinterpret_cast<f4*>(yr + ks * 32) = x0 + r0;
+                    *reinterpret_cast<f4*>(yr + ks * 32 + 4) = x1 + r1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+// ---- C = 128 (hidden 512: CSWin stage 2, XCiT-nano): the weights (256 KB) do not fit in LDS, so all 16 waves walk the hidden
+// blocks in lockstep and the 32-unit slices of W1 (rows) and W2 (columns, pre-arranged slice-major by the caller) stream through a
+// double-buffered 16 KB LDS stage: loads of slice kb+1 are in flight during the MFMAs of slice kb, two barriers per slice.  One
+// 16-token tile per wave (the 128-wide accumulator leaves no room for two).
+template <int PREC, int C, int HD>
+__global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs a) {
+    using M_ = Mma<PREC>;
+    using v8 = typename M_::v8;
+    using v4 = typename M_::v4;
+    using el = typename M_::e;
+    constexpr int NWV = 16;
+    constexpr int P1 = C + 8, P2 = 32 + 4, SPH = 64 + 4;       // W1 slice [32][P1], W2 slice [C][P2], slab [16][SPH] (64 channels at a time)
+    constexpr int KS = C / 32, NT = C / 16, NKB = HD / 32;
+    constexpr int W1S = 32 * P1, W2S = C * P2, STAGE = W1S + W2S;
+    static_assert(32 * C / 8 == 512 && C * 32 / 8 == 512, "one 16-byte load per thread and slice");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    el* s_stage = reinterpret_cast<el*>(lds);                   // two stages
+    float* s_slab = reinterpret_cast<float*>(s_stage + 2 * STAGE);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    float* slab = s_slab + wave * 16 * SPH;
+    const float invC = 1.0f / (float)C;
+    const el* w1 = static_cast<const el*>(a.w1);
+    const el* w2c = static_cast<const el*>(a.w2);               // (HD/32, C, 32) slice-major
+    // this thread's element of every slice: threads 0-511 carry W1 rows, 512-1023 carry W2
+    const bool is_w1 = t < 512;
+    const int ti = t & 511;
+    const int srow = is_w1 ? ti / (C / 8) : ti / 4, scol = is_w1 ? (ti % (C / 8)) * 8 : (ti % 4) * 8;
+    const int sdst = is_w1 ? srow * P1 + scol : W1S + srow * P2 + scol;
+    auto fetch = [&](int kb) -> v8 {
+        return is_w1 ? *reinterpret_cast<const v8*>(w1 + ((long)kb * 32 + srow) * C + scol)
+                     : *reinterpret_cast<const v8*>(w2c + ((long)kb * C + srow) * 32 + scol);
+    };
+    auto commit = [&](int buf, v8 v) {
+        el* d = s_stage + buf * STAGE + sdst;
+        if (is_w1) *reinterpret_cast<v8*>(d) = v;
+        else { *reinterpret_cast<v4*>(d) = v4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<v4*>(d + 4) = v4{v[4], v[5], v[6], v[7]}; }
+    };
+
+    const long ntile = (a.M + 15) / 16;
+    const long niter = (ntile + NWV - 1) / NWV;                   // workgroup steps: 256 tokens each, uniform trip count for the barriers
+    for (long it = blockIdx.x; it < niter; it += gridDim.x) {
+        const long tok0 = (it * NWV + wave) * 16;
+        const long tok = tok0 + l15;
+        v8 xb[KS];
+        {
+            f4 lo[KS], hi[KS];
+            const float* xr = a.x + (tok < a.M ? tok : 0) * C + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lo[ks] = *reinterpret_cast<const f4*>(xr + ks * 32);
+                hi[ks] = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+            }
+            float mean = 0.f, rstd = 1.f;
+            if (a.do_ln) {
+                float s = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) s += ((lo[ks].x + lo[ks].y) + (lo[ks].z + lo[ks].w)) + ((hi[ks].x + hi[ks].y) + (hi[ks].z + hi[ks].w));
+                s += __shfl_xor(s, 16, WAVE);
+                s += __shfl_xor(s, 32, WAVE);
+                mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f4 d0 = lo[ks] - mean, d1 = hi[ks] - mean;
+                    q += ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) + ((d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w));
+                }
+                q += __shfl_xor(q, 16, WAVE);
+                q += __shfl_xor(q, 32, WAVE);
+                rstd = 1.0f / sqrtf(q * invC + a.eps);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4 h0 = M_::cvt((lo[ks] - mean) * rstd), h1 = M_::cvt((hi[ks] - mean) * rstd);
+                xb[ks] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            }
+        }
+        f4 o[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
+        v8 nxt = fetch(0);
+        __syncthreads();                                           // previous step's readers of stage 0 are done
+        commit(0, nxt);
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < NKB) nxt = fetch(kb + 1);                 // in flight during the MFMAs below
+            const el* sw1 = s_stage + buf * STAGE;
+            const el* sw2 = sw1 + W1S;
+            f4 s[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                s[h2] = *reinterpret_cast<const f4*>(a.b1 + kb * 32 + h2 * 16 + g * 4);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    s[h2] = M_::mma(*reinterpret_cast<const v8*>(sw1 + (h2 * 16 + l15) * P1 + ks * 32 + g * 8), xb[ks], s[h2]);
+            }
+            const f4 p0 = f4{gelu_fast(s[0].x), gelu_fast(s[0].y), gelu_fast(s[0].z), gelu_fast(s[0].w)};
+            const f4 p1 = f4{gelu_fast(s[1].x), gelu_fast(s[1].y), gelu_fast(s[1].z), gelu_fast(s[1].w)};
+            const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
+            const v8 pf = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const el* wr = sw2 + (nt * 16 + l15) * P2 + g * 4;
+                const v4 a0 = *reinterpret_cast<const v4*>(wr), a1 = *reinterpret_cast<const v4*>(wr + 16);
+                o[nt] = M_::mma(pf, v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, o[nt]);
+            }
+            if (kb + 1 < NKB) {
+                commit(buf ^ 1, nxt);                              // stage buf^1 was last read at slice kb-1: everybody passed the barrier below
+                __syncthreads();
+            }
+        }
+        // ---- epilogue, 64 channels at a time: (+ b2) * gamma -> slab -> + x -> row stores ------------------------------------------------
+#pragma unroll
+        for (int hh = 0; hh < C / 64; ++hh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cidx = hh * 64 + j * 16 + l15;
+                const float b2 = a.b2 ? a.b2[cidx] : 0.f, gm = a.gamma ? a.gamma[cidx] : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(g * 4 + r) * SPH + j * 16 + l15] = (o[hh * 4 + j][r] + b2) * gm;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (tok < a.M) {
+                const float* xr = a.x + tok * C + hh * 64 + g * 8;
+                float* yr = a.y + tok * C + hh * 64 + g * 8;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const f4 r0 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8);
+                    const f4 r1 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8 + 4);
+                    const f4 x0 = *reinterpret_cast<const f4*>(xr + k2 * 32), x1 = *reinterpret_cast<const f4*>(xr + k2 * 32 + 4);
+                    *reinterpret_cast<f4*>(yr + k2 * 32) = x0 + r0;
+                    *reinterpret_cast<f4*>(yr + k2 * 32 + 4) = x1 + r1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+template <int C, int HD>
+constexpr size_t mlp_smem() {
+    return (size_t)(HD * (C + 8) + C * (HD + 4)) * 2 + (size_t)HD * 4 + (size_t)16 * 16 * (C + 4) * 4;
+}
+
+}  // namespace
+
+extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const float* b1, const void* w2_16, const float* b2, const float* gamma,
+                                   float* y, long M, int C, int hidden, int layernorm, float eps, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && w1_16 && b1 && w2_16 && y && M > 0);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!((C == 64 && hidden == 256) || (C == 128 && hidden == 512)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: built for C = 64, hidden = 256 and C = 128, hidden = 512 (got C = %d, hidden = %d)", C, hidden);
+    if (!aligned16(x) || !aligned16(y) || !aligned16(w1_16) || !aligned16(w2_16))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: 16-byte aligned buffers required");
+    MlpArgs a{};
+    a.x = x; a.y = y; a.w1 = w1_16; a.w2 = w2_16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.M = M; a.eps = eps; a.do_ln = layernorm ? 1 : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (C == 128) {
+        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)16 * 16 * 68 * 4;
+        static_assert(sm <= 160 * 1024, "LDS budget");
+        const long niter = ((M + 15) / 16 + 15) / 16;
+        const int grid2 = (int)(niter < ncu ? niter : ncu);
+        if (precision == MI355_PREC_FP16) {
+            static bool at1 = false;
+            if (!at1) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at1 = true; }
+            mlp_fused_stream_kernel<1, 128, 512><<<grid2, 1024, sm, st>>>(a);
+        } else {
+            static bool at2 = false;
+            if (!at2) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at2 = true; }
+            mlp_fused_stream_kernel<2, 128, 512><<<grid2, 1024, sm, st>>>(a);
+        }
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
+    const long nchunk = (M + 31) / 32;
+    long grid = (nchunk + 15) / 16;
+    if (grid > ncu) grid = ncu;
+    constexpr size_t smem = mlp_smem<64, 256>();
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    if (precision == MI355_PREC_FP16) {
+        static bool attr1 = false;
+        if (!attr1) {
+            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr1 = true;
+        }
+        mlp_fused_kernel<1, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) {
+            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr2 = true;
+        }
+        mlp_fused_kernel<2, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}

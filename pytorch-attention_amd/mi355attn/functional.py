@@ -304,6 +304,44 @@ def weight16(param, precision=None):
     return _derived_get((param,), ("w16", p), tag, lambda: cast16(param.detach(), p))
 
 
+def mlp_fused_ok(C, hidden, precision=None):
+    """Shape / precision envelope of mi355_mlp_fused_fwd."""
+    return _prec(precision) in (PREC_FP16, PREC_BF16) and (C, hidden) in ((64, 256), (128, 512))
+
+
+def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None):
+    """y = x + gamma * fc2(gelu(fc1(ln(x)))) in one kernel (hidden activations never reach HBM).  `ln` is the LayerNorm in front of
+    the MLP (its affine part is folded into fc1 here, cached per parameter version) or None."""
+    p = _prec(precision)
+    x = require_device_f32(x, "x")
+    C = x.shape[-1]
+    Hd = fc1.weight.shape[0]
+
+    def build():
+        w1 = fc1.weight.detach()
+        b1 = fc1.bias.detach() if fc1.bias is not None else torch.zeros(Hd, dtype=torch.float32, device=w1.device)
+        if ln is not None:
+            b1 = b1 + w1 @ ln.bias.detach()
+            w1 = w1 * ln.weight.detach()[None, :]
+        return cast16(w1.contiguous(), p), b1.contiguous()
+
+    parts = [fc1.weight] + ([] if fc1.bias is None else [fc1.bias]) + ([] if ln is None else [ln.weight, ln.bias])
+    tag = tuple((t._version, t.data_ptr()) for t in parts)
+    anchors = (fc1,) if ln is None else (fc1, ln)
+    w1_16, b1 = _derived_get(anchors, ("mlp_fused_w1", p), tag, build)
+    if C == 64:
+        w2_16 = weight16(fc2.weight, p)
+    else:                                               # slice-major (hidden/32, C, 32): the kernel streams 32-unit slices through LDS
+        w2_16 = _derived_get((fc2,), ("mlp_fused_w2", p), (fc2.weight._version, fc2.weight.data_ptr()),
+                             lambda: cast16(fc2.weight.detach().reshape(C, Hd // 32, 32).permute(1, 0, 2).contiguous(), p))
+    y = torch.empty_like(x)
+    M = x.numel() // C
+    check(lib().mi355_mlp_fused_fwd(dptr(x), dptr(w1_16), dptr(b1), dptr(w2_16), dptr(_opt(fc2.bias, "fc2.bias")), dptr(_opt(gamma, "gamma")),
+                                    dptr(y), M, C, Hd, 0 if ln is None else 1, float(ln.eps) if ln is not None else 0.0, p,
+                                    stream_ptr(x.device)), "mi355_mlp_fused_fwd")
+    return y
+
+
 def layernorm16(x, weight, bias, eps=1e-5, precision=None):
     x = require_device_f32(x, "x")
     weight = require_device_f32(weight, "weight")

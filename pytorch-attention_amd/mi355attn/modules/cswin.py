@@ -110,6 +110,8 @@ class CSWinBlock(nn.Module):
             self.attns[0].run(qkv, att, 0)
         if fast:
             x = F.linear16(att, F.weight16(self.proj.weight, p), self.proj.bias, resid=x, precision=p)
+            if F.mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
+                return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=p)      # LN2 + fc1 + GELU + fc2 + residual
             u = F.layernorm16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
         else:
             x = F.linear(att, self.proj.weight, self.proj.bias, resid=x, precision=self.precision)

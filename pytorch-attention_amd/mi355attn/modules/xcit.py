@@ -104,6 +104,8 @@ class XCABlock(nn.Module):
 
         x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
         x = self.local_mp(norm(self.norm3, x, False), H, W, gamma=self.gamma3, resid=x)
+        if fast and F.mlp_fused_ok(x.shape[-1], self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
+            return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, gamma=self.gamma2, precision=p)   # LN2 + MLP + LayerScale + residual
         return self.mlp(norm(self.norm2, x, fast), gamma=self.gamma2, resid=x)
 
 

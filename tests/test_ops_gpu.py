@@ -594,3 +594,34 @@ def test_derived_weight_cache_is_tied_to_the_live_parameter():
         del w, w16
         gc.collect()
     assert len(Fm._derived) <= seen and all(all(r() is not None for r in e[0]) for e in Fm._derived.values())
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("C", [64, 128])
+@pytest.mark.parametrize("M,with_ln,with_gamma", [(802, True, False), (33, True, True), (4096, False, True), (1, True, False), (70000, True, True)])
+def test_mlp_fused(M, with_ln, with_gamma, prec, C):
+    """LayerNorm + fc1 + GELU + fc2 + residual in one kernel (C = 64: LDS-resident weights; C = 128: weights streamed in 32-unit
+    slices) against fp64; ragged token counts exercise partial chunks / idle waves, gamma the LayerScale variant."""
+    torch.manual_seed(M)
+    Hd = 4 * C
+    ln = torch.nn.LayerNorm(C)
+    fc1, fc2 = torch.nn.Linear(C, Hd), torch.nn.Linear(Hd, C)
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2); ln.bias.normal_(0, 0.2)
+    gamma = torch.randn(C) if with_gamma else None
+    x = torch.randn(M, C)
+    xd = x.double()
+    u = torch.nn.functional.layer_norm(xd, (C,), ln.weight.double(), ln.bias.double(), ln.eps) if with_ln else xd
+    h = gelu64(u @ fc1.weight.double().t() + fc1.bias.double())
+    z = h @ fc2.weight.double().t() + fc2.bias.double()
+    ref = (xd + (z * gamma.double() if with_gamma else z)).detach()
+    y = F().mlp_fused(x.cuda(), ln.cuda() if with_ln else None, fc1.cuda(), fc2.cuda(), gamma=None if gamma is None else gamma.cuda(),
+                      precision=prec)
+    assert_parity(y.cpu(), ref.float(), TOL[prec], "mlp_fused")
+
+
+def test_mlp_fused_rejects_other_shapes():
+    from mi355attn import Mi355Error
+    fc1, fc2 = torch.nn.Linear(256, 1024).cuda(), torch.nn.Linear(1024, 256).cuda()
+    with pytest.raises(Mi355Error, match="C = 64"):
+        F().mlp_fused(torch.randn(8, 256).cuda(), None, fc1, fc2, precision=1)
