@@ -580,8 +580,15 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant == 0)          // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups
+    if (variant == 0) {        // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups
         variant = (N <= 64) ? 9 : (N < 256 ? 1 : 7);   // per CU; narrow outputs use 256x64 / 128x128 tiles instead
+        int ncu = 256, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        // fewer 128x256 tiles than CUs (CSWin stage 4: M = 12544, N = 512 -> 196 tiles): halve the tile so that the chip fills
+        // (measured 57 -> 43 us on the K = 2048 fc2 of that stage, 25 -> 22 us on its proj)
+        if (variant == 7 && (long)cdiv(M, 128) * cdiv(N, 256) < ncu) variant = 1;
+    }
     else if (variant == 8) variant = 0;     // 8 = plain 128x128 without priority hints (tuning experiments)
 #define LAUNCH(T_, O_, BM_, BN_, WM_, WN_, P_, S_)                                                         \
     gemm16_kernel<T_, O_, BM_, BN_, WM_, WN_, P_, S_><<<cdiv(M, BM_) * cdiv(N, BN_), WM_ * WN_ * 64, 0, st>>>(g)

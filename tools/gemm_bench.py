@@ -17,13 +17,23 @@ M = 256 * 197
 # (name, N, K, out16, with_resid, gelu)
 shapes = [("qkv", 2304, 768, True, False, False), ("proj", 768, 768, False, True, False), ("fc1", 3072, 768, True, False, True),
           ("fc2", 768, 3072, False, True, True), ("fc1_nogelu", 3072, 768, True, False, False)]
+if os.environ.get("GEMM_SET") == "narrow":
+    # CSWin stage 3 / 4 and XCiT-S (dim 384) at B = 256: (name, N, K, out16, resid, gelu, M)
+    shapes = [("s3_qkv", 768, 256, True, False, False, 50176), ("s3_proj", 256, 256, False, True, False, 50176),
+              ("s3_fc1", 1024, 256, True, False, True, 50176), ("s3_fc2", 256, 1024, False, True, False, 50176),
+              ("s4_qkv", 1536, 512, True, False, False, 12544), ("s4_proj", 512, 512, False, True, False, 12544),
+              ("s4_fc1", 2048, 512, True, False, True, 12544), ("s4_fc2", 512, 2048, False, True, False, 12544),
+              ("x_qkv", 1152, 384, True, False, False, 50176), ("x_proj", 384, 384, False, True, False, 50176),
+              ("x_fc1", 1536, 384, True, False, True, 50176), ("x_fc2", 384, 1536, False, True, False, 50176)]
 if os.environ.get("GEMM_SHAPES"):
     shapes = [s_ for s_ in shapes if s_[0] in os.environ["GEMM_SHAPES"].split(",")]
 if os.environ.get("GEMM_LONGK"):
     shapes.append(("longK", 2304, 6144, True, False, False))
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,4,5,6,7".split(","))]
 res = []
-for name, N, K, out16, with_resid, gelu in shapes:
+for shp in shapes:
+    name, N, K, out16, with_resid, gelu = shp[:6]
+    M = shp[6] if len(shp) > 6 else 256 * 197
     torch.manual_seed(0)
     x16 = torch.randn(M, K, device=dev).half()
     w16 = (torch.randn(N, K, device=dev) / K ** 0.5).half()
