@@ -55,9 +55,6 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   by the 256 MiB Infinity Cache -- default; a value >= B disables chunking);
  *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 3);
  *   "reverse"       1 = the final pass walks the batch backwards (most recently touched rows first), default 0;
- *   "fused"         0 = two streaming passes (default); 1 = experimental single-pass register-resident SE/ECA kernel for
- *                   large shapes (x read once; measured slower on MI355X -- inter-workgroup hand-off latency),
- *                   2 = single pass whenever the shape is supported, regardless of size (tests).
  *   "se_single"     1 (default) = SE reads x once: 8 channel rows per workgroup stay in registers, the image's channel means are
  *                   exchanged between its workgroups as 8-byte {mean, tag} granules (one write-through store each, polled with
  *                   bounded sweeps); 0 = two passes (pool, then gate + scale).

@@ -11,13 +11,11 @@ static std::atomic<long> g_chunk_images{0};   // 0 = auto (about 200 MB of x per
 static std::atomic<long> g_nt{3};        // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
 static std::atomic<long> g_reverse{0};
 static std::atomic<long> g_gemm_variant{0};   // tile/schedule variant of the 16-bit GEMM (gemm16.hip)
-static std::atomic<long> g_fused{0};     // experimental single-pass SE/ECA kernel (measured 4x slower than two passes: DESIGN.md 6.1)
 
 static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
 static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
 static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in registers, three granule hops per band (cbam_single.hip)
 static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
-static std::atomic<long> g_cbam_threads{512}; // workgroup size of the single-read CBAM: 512 (2 per CU) or 256 (4 per CU, finer bands)
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
 static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
 
@@ -33,7 +31,6 @@ int fail(int code, const char* fmt, ...) {
 long opt_chunk_images() { return g_chunk_images.load(std::memory_order_relaxed); }
 long opt_nt() { return g_nt.load(std::memory_order_relaxed); }
 long opt_reverse() { return g_reverse.load(std::memory_order_relaxed); }
-long opt_fused() { return g_fused.load(std::memory_order_relaxed); }
 long opt_eca_single() { return g_eca_single.load(std::memory_order_relaxed); }
 long opt_se_single() { return g_se_single.load(std::memory_order_relaxed); }
 long opt_cbam_single() { return g_cbam_single.load(std::memory_order_relaxed); }
@@ -103,7 +100,6 @@ void ws_forget_range(const void* base, size_t bytes) {
     }
 }
 
-long opt_cbam_threads() { return g_cbam_threads.load(std::memory_order_relaxed); }
 long opt_zoo_single() { return g_zoo_single.load(std::memory_order_relaxed); }
 long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
@@ -135,11 +131,6 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_gemm_variant.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
-    if (std::strcmp(key, "fused") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= 2);
-        mi355::g_fused.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
     if (std::strcmp(key, "eca_single") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_eca_single.store(value, std::memory_order_relaxed);
@@ -158,11 +149,6 @@ int mi355_set_option(const char* key, long value) {
     if (std::strcmp(key, "ws_persistent") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_ws_persistent.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "cbam_threads") == 0) {
-        MI355_CHECK_ARG(value == 256 || value == 512);
-        mi355::g_cbam_threads.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
     if (std::strcmp(key, "zoo_single") == 0) {
@@ -193,13 +179,11 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "chunk_images") == 0) return mi355::opt_chunk_images();
     if (key && std::strcmp(key, "nt") == 0) return mi355::opt_nt();
     if (key && std::strcmp(key, "reverse") == 0) return mi355::opt_reverse();
-    if (key && std::strcmp(key, "fused") == 0) return mi355::opt_fused();
     if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
     if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
     if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
-    if (key && std::strcmp(key, "cbam_threads") == 0) return mi355::opt_cbam_threads();
     if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();
     if (key && std::strcmp(key, "cbam_single") == 0) return mi355::opt_cbam_single();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");

@@ -379,13 +379,9 @@ bool geometry(int nt, int C, int Cr, int H, int W, int ks, Geo& g) {
     return g.smem_base <= 40 * 1024;
 }
 
-// 512-thread workgroups (2 per CU, bands of <= 128 pixels) or 256-thread workgroups (4 per CU, <= 64 pixels): same bytes in
-// registers per CU, the second gives four independent load / exchange / store chains per CU instead of two.
-bool pick_geometry(int C, int Cr, int H, int W, int ks, Geo& g) {
-    const long pref = mi355::opt_cbam_threads();
-    if (pref == 256) return geometry(256, C, Cr, H, W, ks, g) || geometry(512, C, Cr, H, W, ks, g);
-    return geometry(512, C, Cr, H, W, ks, g) || geometry(256, C, Cr, H, W, ks, g);
-}
+// 512-thread workgroups, two per CU.  (256-thread workgroups with half-size bands -- four exchange chains per CU instead of two -- were
+// measured at 0.72 ms against 0.49 ms at the C2 shape: every phase got slower.  DESIGN.md 6.1.)
+bool pick_geometry(int C, int Cr, int H, int W, int ks, Geo& g) { return geometry(512, C, Cr, H, W, ks, g); }
 
 }  // namespace
 
@@ -396,8 +392,7 @@ unsigned long long* g_cbam_dbg = nullptr;
 
 // extra workspace of the single-read CBAM: g1 | g2 | g3 granules | ticket, err, pad (0 when no band geometry exists)
 size_t cbam_single_extra_bytes(int B, int C, int H, int W) {
-    int R = band_rows(H, W, 256);                                     // the finer banding needs the larger hop-1 array
-    if (!R) R = band_rows(H, W, 512);
+    const int R = band_rows(H, W, 512);
     if (!R) return 0;
     return ((size_t)B * (H / R) * C + (size_t)B * C + (size_t)B * H * W) * 16 + 16;
 }
@@ -424,7 +419,7 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     a.total = (int)total_l;
     a.nts = (opt_nt() & 2) ? 1 : 0;
     const bool full = (C == g.CL * g.NV);
-    const int per_cu = g.NT == 512 ? 2 : 4;
+    const int per_cu = 2;
     a.wlds = (g.smem_base + g.smem_w <= (size_t)(120 * 1024) / per_cu) ? 1 : 0;
     const size_t smem = g.smem_base + (a.wlds ? g.smem_w : 0);
     int dev = 0, ncu = 256;
@@ -443,15 +438,10 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
         hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);
         if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: memset -> %s", hipGetErrorString(e)); }
     }
-#define GO(SEG_, NV_)                                                                                  \
-    do {                                                                                               \
-        if (g.NT == 512) {                                                                             \
-            if (full) cbam_single_kernel<512, SEG_, NV_, true><<<(int)grid, 512, smem, st>>>(a);       \
-            else      cbam_single_kernel<512, SEG_, NV_, false><<<(int)grid, 512, smem, st>>>(a);      \
-        } else {                                                                                       \
-            if (full) cbam_single_kernel<256, SEG_, NV_, true><<<(int)grid, 256, smem, st>>>(a);       \
-            else      cbam_single_kernel<256, SEG_, NV_, false><<<(int)grid, 256, smem, st>>>(a);      \
-        }                                                                                              \
+#define GO(SEG_, NV_)                                                                              \
+    do {                                                                                           \
+        if (full) cbam_single_kernel<512, SEG_, NV_, true><<<(int)grid, 512, smem, st>>>(a);       \
+        else      cbam_single_kernel<512, SEG_, NV_, false><<<(int)grid, 512, smem, st>>>(a);      \
     } while (0)
     if (g.SEG == 32) {
         if (g.NV == 4) GO(32, 4);

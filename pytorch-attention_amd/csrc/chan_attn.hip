@@ -460,8 +460,6 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     const int groups = cdiv(C, RPB);
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
-    if (vec && mi355::opt_fused() && mi355::fused_applicable(B, C, H, W))      // x read once, y written once
-        return mi355::se_eca_fused(mode, x, wa, wb, y, B, C, Cr, H, W, pooled, static_cast<char*>(ws) + pooled_bytes(B, C), st);
     if (mode == 0 && vec && mi355::se_single_applicable(C, Cr, H, W) && !mi355::stream_is_capturing(st)) {       // SE: x read once, means exchanged as tagged granules
         char* state = static_cast<char*>(ws) + pooled_bytes(B, C);
         return mi355::se_single(x, wa, wb, y, B, C, Cr, H, W, state, state + mi355::fused_state_bytes(B), st);

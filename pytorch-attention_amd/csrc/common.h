@@ -16,7 +16,6 @@ int   fail(int code, const char* fmt, ...);
 long  opt_chunk_images();
 long  opt_nt();
 long  opt_reverse();
-long  opt_fused();
 long  opt_gemm_variant();
 long  opt_eca_single();
 long  opt_se_single();
@@ -28,7 +27,6 @@ void  ws_forget(const void* region);
 bool  stream_is_capturing(hipStream_t st);      // hipGraph capture in progress on this stream
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
-long  opt_cbam_threads();
 long  opt_zoo_single();
 size_t zoo_workspace_bytes(int B, int C);
 size_t cbam_single_extra_bytes(int B, int C, int H, int W);
@@ -42,9 +40,6 @@ int   se_single(const float* x, const float* w1, const float* w2, float* y, int 
 bool  eca_single_applicable(int C, int k, int H, int W);
 int   eca_single(const float* x, const float* taps, float* y, int B, int C, int k, int H, int W, hipStream_t st);
 size_t fused_state_bytes(int B);
-bool  fused_applicable(int B, int C, int H, int W);
-int   se_eca_fused(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr, int H, int W,
-                   float* means, void* state, hipStream_t st);
 // GEMM engine (gemm.hip), shared by the other translation units.  NT: B is (N,K) K-contiguous; KN: B is (K,N) N-contiguous.
 int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
             int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st);

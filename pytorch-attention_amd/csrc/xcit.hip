@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void lpi_kernel(const float* __restrict__ x, c
     };
     for (int n = tl; n < N; n += 32) {
         const f4 u = conv(s_x, k1, bias1, n);
-        const f4 v = f4{gelu_erf(u.x), gelu_erf(u.y), gelu_erf(u.z), gelu_erf(u.w)};
+        const f4 v = f4{gelu_fast(u.x), gelu_fast(u.y), gelu_fast(u.z), gelu_fast(u.w)};   // |erf error| <= 1.5e-7, ~3x fewer instructions than erff
         *reinterpret_cast<f4*>(s_m + n * LPI_CG + cq * 4) = (v - mean) * rstd * bw + bb;
     }
     __syncthreads();

@@ -43,43 +43,6 @@ def test_edge_shapes(shape):
     assert_parity(y_sa, O.cbam_spatial_forward(x, sd["sa.conv.weight"]), 1e-5, f"sa{shape}")
 
 
-FUSED_SHAPES = [(3, 8, 4, 4), (2, 64, 32, 32), (5, 36, 20, 20), (2, 16, 56, 56), (1, 12, 64, 60), (2, 256, 14, 14), (7, 128, 28, 28)]
-
-
-@pytest.mark.parametrize("shape", FUSED_SHAPES)
-def test_single_pass_kernel_matches_oracle_and_two_pass(shape, monkeypatch):
-    """Force the register-resident single-pass SE/ECA kernel on small shapes (all NV instantiations) and compare with the
-    oracle and with the two-pass path; the bounded-spin error word is checked after every call."""
-    import mi355attn
-    monkeypatch.setenv("MI355_CHECK_SYNC", "1")
-    B, C, H, W = shape
-    red = 16 if C >= 32 else 4
-    se, eca, _ = _mods(C, red)
-    torch.manual_seed(6)
-    x = torch.randn(*shape)
-    xd = x.cuda()
-    old = mi355attn.get_option("fused")
-    try:
-        mi355attn.set_option("fused", 2)
-        with torch.no_grad():
-            y_se, y_eca = se.cuda()(xd).cpu(), eca.cuda()(xd).cpu()
-            again = se(xd).cpu()
-        mi355attn.set_option("fused", 0)
-        mi355attn.set_option("se_single", 0)
-        mi355attn.set_option("eca_single", 0)
-        with torch.no_grad():
-            y_se2, y_eca2 = se(xd).cpu(), eca(xd).cpu()
-    finally:
-        mi355attn.set_option("fused", old)
-        mi355attn.set_option("se_single", 1)
-        mi355attn.set_option("eca_single", 1)
-    assert torch.equal(y_se, again), "single-pass kernel is not run-to-run deterministic"
-    assert_parity(y_se, O.se_forward(x, se.fc[0].weight, se.fc[2].weight), 1e-5, f"se fused {shape}")
-    assert_parity(y_eca, O.eca_forward(x, eca.conv.weight), 1e-5, f"eca fused {shape}")
-    assert_parity(y_se, y_se2, 1e-6, "single pass vs two pass (SE)")
-    assert_parity(y_eca, y_eca2, 1e-6, "single pass vs two pass (ECA)")
-
-
 ECA_SINGLE_SHAPES = [(2, 64, 32, 32), (3, 256, 56, 56), (1, 8, 4, 4), (2, 16, 2, 2), (2, 1024, 14, 14), (1, 24, 64, 64), (5, 40, 12, 12),
                      (1, 4096, 8, 8)]
 
@@ -204,7 +167,7 @@ def test_cbam_single_granule_protocol_under_repetition(monkeypatch):
 def test_persistent_workspace_epochs(monkeypatch):
     """With "ws_persistent" (what the Python binding runs with) the exchange area is zeroed once and every launch carries a fresh
     tag.  Interleave shapes and ops that share nothing but the process-wide epoch counter, switch the option off and on again,
-    and detour through the kernels that reset the shared ticket word: every result must stay bit-identical to the first."""
+    and detour through the two-pass kernel on the same workspace: every result must stay bit-identical to the first."""
     import mi355attn
     monkeypatch.setenv("MI355_CHECK_SYNC", "1")
     assert mi355attn.get_option("ws_persistent") == 1
@@ -220,10 +183,10 @@ def test_persistent_workspace_epochs(monkeypatch):
                 mi355attn.set_option("ws_persistent", 0)
             if rnd == 7:
                 mi355attn.set_option("ws_persistent", 1)
-            if rnd == 9:                                   # old flag-protocol kernel on the same dedicated workspace
-                mi355attn.set_option("fused", 2)
+            if rnd == 9:                                   # detour through the two-pass kernel on the same dedicated workspace
+                mi355attn.set_option("se_single", 0)
                 se_a(xa)
-                mi355attn.set_option("fused", 0)
+                mi355attn.set_option("se_single", 1)
             for (m, x), f in zip(mods, first):
                 assert torch.equal(m(x), f), f"round {rnd}"
     mi355attn.set_option("ws_persistent", 1)
@@ -241,29 +204,6 @@ def test_eca_single_is_independent_of_batch_grouping():
     assert torch.equal(full[7:12], part)
 
 
-def test_single_pass_sync_protocol_under_repetition(monkeypatch):
-    """200 back-to-back launches on a shape with many sibling workgroups per image: every run must equal the first
-    (stale or torn hand-offs would show up as a different gate), and no spin may time out."""
-    import mi355attn
-    monkeypatch.setenv("MI355_CHECK_SYNC", "0")
-    se, _, _ = _mods(256)
-    torch.manual_seed(8)
-    x = torch.randn(24, 256, 28, 28).cuda()
-    old = mi355attn.get_option("fused")
-    try:
-        mi355attn.set_option("fused", 2)
-        with torch.no_grad():
-            first = se.cuda()(x).clone()
-            for _ in range(200):
-                y = se(x)
-            monkeypatch.setenv("MI355_CHECK_SYNC", "1")
-            last = se(x)
-    finally:
-        mi355attn.set_option("fused", old)
-    assert torch.equal(y, first) and torch.equal(last, first)
-    assert_parity(first.cpu(), O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, "se fused repeat")
-
-
 def test_non_contiguous_and_offset_inputs():
     se, _, _ = _mods(64)
     torch.manual_seed(2)
@@ -275,14 +215,16 @@ def test_non_contiguous_and_offset_inputs():
 
 
 def test_chunk_option_does_not_change_results():
-    """The Infinity-Cache chunking knob reorders launches only: outputs must be bit-identical."""
+    """The Infinity-Cache chunking / non-temporal / order knobs of the multi-pass kernels reorder launches and change cache hints only:
+    outputs must be bit-identical (the single-read kernels are switched off so that the multi-pass path is what runs)."""
     import mi355attn
     se, eca, cbam = _mods(64)
     torch.manual_seed(9)
     x = torch.randn(13, 64, 28, 28).cuda()
     outs = []
-    old = {k: mi355attn.get_option(k) for k in ("chunk_images", "nt", "reverse", "fused")}
-    mi355attn.set_option("fused", 0)
+    old = {k: mi355attn.get_option(k) for k in ("chunk_images", "nt", "reverse", "se_single", "eca_single", "cbam_single")}
+    for k in ("se_single", "eca_single", "cbam_single"):
+        mi355attn.set_option(k, 0)
     for chunk, nt, rev in ((0, 3, 0), (1, 0, 0), (5, 1, 1), (13, 2, 1), (4, 3, 1)):
         mi355attn.set_option("chunk_images", chunk)
         mi355attn.set_option("nt", nt)

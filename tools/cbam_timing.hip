@@ -12,8 +12,6 @@ extern unsigned long long* g_cbam_dbg;
 }
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 256, C = 256, Cr = 16, H = 56, W = 56, ks = 7;
-    const int nt = argc > 2 ? atoi(argv[2]) : 512;
-    mi355_set_option("cbam_threads", nt);
     const size_t n = (size_t)B * C * H * W;
     float *x, *y, *w1, *w2, *wc;
     hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&w1, Cr * C * 4); hipMalloc(&w2, C * Cr * 4); hipMalloc(&wc, 2 * ks * ks * 4);
@@ -25,7 +23,7 @@ int main(int argc, char** argv) {
     hipMemcpy(wc, h.data() + 9000, 2 * ks * ks * 4, hipMemcpyHostToDevice);
     const size_t extra = mi355::cbam_single_extra_bytes(B, C, H, W);
     void* ws; hipMalloc(&ws, extra);
-    const int G = 256 * (nt == 512 ? 2 : 4);
+    const int G = 256 * 2;
     unsigned long long* dbg; hipMalloc(&dbg, (size_t)G * 16 * 10 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 4; ++it) {
