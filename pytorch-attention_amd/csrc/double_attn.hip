@@ -3,8 +3,8 @@
 //   [A; Bm; V] = [WA; WB; WV] X_b + bias          one batched K-major GEMM (the three 1x1 convs share the read of X)
 //   Bm = softmax over HW (rows),  V = softmax over c_n (columns)      two small fp32 kernels, in place
 //   G = A Bm^T (c_m x c_n, contraction over HW)    batched NT GEMM
-//   Z = G V    (c_m x HW)                          batched K-major GEMM
-//   y = WP Z + bP                                   batched K-major GEMM with row bias
+//   M' = WP G  (C x c_n, tiny)                     batched K-major GEMM;  y = WP (G V) + bP is evaluated as (WP G) V + bP
+//   y = M' V + bP                                   batched K-major GEMM with row bias
 // x, y are NCHW, i.e. each image is a (C x HW) matrix with HW contiguous: the activation is always the K-major operand
 // of the engine, never transposed in memory.
 #include "common.h"
@@ -40,16 +40,51 @@ __global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ p
     for (int j = 0; j < cn; ++j) col[(long)j * HW] = expf(col[(long)j * HW] - m) / s;
 }
 
+// The same softmax with the column held in registers: 256 threads = 64 pixels x 4 channel quarters, CPT channels per thread
+// (one read + one write of the tensor instead of three reads + one write).
+template <int CPT>
+__global__ __launch_bounds__(256) void softmax_cols_reg_kernel(float* __restrict__ p, int cn, int HW, long img_stride, long total) {
+    __shared__ float s_m[4][64], s_s[4][64];
+    const int px = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + px;
+    const bool live = i < total;
+    float* col = p + (live ? (i / HW) * img_stride + (i % HW) : 0) + (long)part * CPT * HW;
+    float v[CPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] = (live && part * CPT + j < cn) ? col[(long)j * HW] : -INFINITY;
+        m = fmaxf(m, v[j]);
+    }
+    s_m[part][px] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_m[0][px], s_m[1][px]), fmaxf(s_m[2][px], s_m[3][px]));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        v[j] = expf(v[j] - m);                                   // exp(-inf) = 0 for the padding channels
+        s += v[j];
+    }
+    s_s[part][px] = s;
+    __syncthreads();
+    s = (s_s[0][px] + s_s[1][px]) + (s_s[2][px] + s_s[3][px]);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (part * CPT + j < cn) col[(long)j * HW] = v[j] / s;
+    }
+}
+
 inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
 
 }  // namespace
 
 extern "C" {
 
-// workspace: Wcat (M3 x C) | bcat (M3) | ABV (B, M3, HW) | G (B, cm, cn) | Z (B, cm, HW)
+// workspace: Wcat (M3 x C) | bcat (M3) | ABV (B, M3, HW) | G (B, cm, cn) | M' (B, C, cn)
 size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, int W) {
     const size_t M3 = (size_t)cm + 2 * (size_t)cn, HW = (size_t)H * W;
-    return r16(M3 * C * 4) + r16(M3 * 4) + r16((size_t)B * M3 * HW * 4) + r16((size_t)B * cm * cn * 4) + r16((size_t)B * cm * HW * 4);
+    return r16(M3 * C * 4) + r16(M3 * 4) + r16((size_t)B * M3 * HW * 4) + r16((size_t)B * cm * cn * 4) + r16((size_t)B * C * cn * 4);
 }
 
 int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV,
@@ -84,15 +119,22 @@ int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, cons
         const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
         softmax_rows_kernel<<<grid, 256, 0, st>>>(ABV + (long)cm * HW, cn, HW, sABV, rows);
         const long total = (long)B * HW;
-        softmax_cols_kernel<<<cdiv(total, 256), 256, 0, st>>>(ABV + (long)(cm + cn) * HW, cn, HW, sABV, total);
+        float* Vp = ABV + (long)(cm + cn) * HW;
+        if (cn <= 64)       softmax_cols_reg_kernel<16><<<cdiv(total, 64), 256, 0, st>>>(Vp, cn, HW, sABV, total);
+        else if (cn <= 128) softmax_cols_reg_kernel<32><<<cdiv(total, 64), 256, 0, st>>>(Vp, cn, HW, sABV, total);
+        else if (cn <= 256) softmax_cols_reg_kernel<64><<<cdiv(total, 64), 256, 0, st>>>(Vp, cn, HW, sABV, total);
+        else                softmax_cols_kernel<<<cdiv(total, 256), 256, 0, st>>>(Vp, cn, HW, sABV, total);
     }
     rc = mi355::gemm_nt_batched(ABV, ABV + (long)cm * HW, G, B, cm, cn, HW, HW, HW, cn, sABV, sABV, (long)cm * cn, precision, st);
     if (rc) return rc;
-    rc = mi355::gemm_kn_batched(G, ABV + (long)(cm + cn) * HW, nullptr, nullptr, Z, B, cm, HW, cn, cn, HW, HW, (long)cm * cn, sABV,
-                                (long)cm * HW, MI355_ACT_NONE, precision, st);
-    if (rc) return rc;
-    rc = mi355::gemm_kn_batched(wP, Z, bP, nullptr, y, B, C, HW, cm, cm, HW, HW, 0, (long)cm * HW, (long)C * HW, MI355_ACT_NONE,
+    // y = WP (G V) + bP = (WP G) V + bP: the (C x c_n) product per image is tiny, and the (c_m x HW) intermediate Z of the reference's
+    // order (a write + a read of B*c_m*HW floats and one more pass of the engine) disappears.
+    float* Mp = Z;                                              // (B, C, cn) in the old Z region
+    rc = mi355::gemm_kn_batched(wP, G, nullptr, nullptr, Mp, B, C, cn, cm, cm, cn, cn, 0, (long)cm * cn, (long)C * cn, MI355_ACT_NONE,
                                 precision, st);
+    if (rc) return rc;
+    rc = mi355::gemm_kn_batched(Mp, ABV + (long)(cm + cn) * HW, bP, nullptr, y, B, C, HW, cn, cn, HW, HW, (long)C * cn, sABV,
+                                (long)C * HW, MI355_ACT_NONE, precision, st);
     if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;
