@@ -169,6 +169,12 @@ int mi355_sdpa16_fwd(const void* qkv16, void* out16, int B, int N, int heads, in
 int mi355_cswin_lepe_attn16_fwd(const void* qkv16, const float* getv_w, const float* getv_b, void* out16,
                                 int B, int reso, int Ctot, int c0, int Cb, int heads, int Hsp, int Wsp,
                                 float scale, int precision, mi355_stream_t stream);
+/* Both stripe branches of a CSWinBlock in ONE launch (cswin.py:155-165, 186-192): branch 0 = vertical stripes (H_sp = reso, W_sp =
+ * split) on channels [0, Ctot/2) with get_v weights w0/b0, branch 1 = horizontal stripes on [Ctot/2, Ctot) with w1/b1; `heads` per branch.
+ * Same arithmetic as two mi355_cswin_lepe_attn16_fwd calls. */
+int mi355_cswin_lepe_attn16_pair_fwd(const void* qkv16, const float* getv_w0, const float* getv_b0, const float* getv_w1,
+                                     const float* getv_b1, void* out16, int B, int reso, int Ctot, int heads, int split, float scale,
+                                     int precision, mi355_stream_t stream);
 
 /* Fused LayerNorm + MLP + residual for narrow token streams (C = 64 / hidden 256: CSWin stage 1; C = 128 / hidden 512: CSWin stage 2,
  * XCiT-nano; cswin.py:194-196 with Mlp :29-44, xcit.py:293 with Mlp :21-38):

@@ -35,8 +35,18 @@ struct AttnArgs {
     int pre_scale;         // 1: q*scale before QK^T (CSWin), 0: (QK^T)*scale (ViT)
 };
 
+// Two argument sets per launch: the two stripe branches of a CSWinBlock (cswin.py:155-165: vertical and horizontal stripes on the two
+// channel halves) have the same tile shape and run as ONE grid -- blocks [0, split) take a0, the rest a1 -- so the chip is filled
+// once instead of twice (the per-block critical path is ~18 us; two half-size launches each paid their own ramp and tail).
+struct AttnPair {
+    AttnArgs a0, a1;
+    int split;
+};
+
 template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW>
-__global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
+    const bool second = (int)blockIdx.x >= pr.split;
+    const AttnArgs a = second ? pr.a1 : pr.a0;
     constexpr int NTHR = NW * 64;             // NW waves share one head's K / V (8 for the 197-token ViT case: 4 waves per SIMD)
     static_assert(!IO16 || PREC != 0, "16-bit I/O exists for the fp16 / bf16 operand modes only");
     using M_ = Mma<PREC>;
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) slab_t s_o[NW * 16 * OP];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int bid = blockIdx.x;
+    int bid = (int)blockIdx.x - (second ? pr.split : 0);
     const int head = bid % a.heads; bid /= a.heads;
     const int win = bid % a.nwin;
     const int b = bid / a.nwin;
@@ -337,11 +347,18 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnArgs a) {
 }
 
 template <int D, bool LEPE, bool IO16>
-int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st) {
-    const int grid = B * a.nwin * a.heads;
+int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const AttnArgs* other = nullptr) {
+    AttnPair pr{};
+    pr.a0 = a;
+    pr.split = B * a.nwin * a.heads;
+    int grid = pr.split;
+    if (other) {
+        pr.a1 = *other;
+        grid += B * other->nwin * other->heads;
+    }
     if (IO16 && precision == MI355_PREC_STRICT)
         return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
-#define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(a)
+#define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(pr)
 #define BYKT(P)                                          \
     do {                                                 \
         if (a.T <= 64) GO(P, 4, 4);                      \
@@ -372,14 +389,21 @@ static int sdpa_common(const void* qkv, void* out, int B, int N, int heads, int 
     return io16 ? launch_attn<32, false, true>(a, B, precision, st) : launch_attn<32, false, false>(a, B, precision, st);
 }
 
-static int lepe_common(const void* qkv, const float* getv_w, const float* getv_b, void* out, int B, int reso, int Ctot, int c0, int Cb,
-                       int heads, int Hsp, int Wsp, float scale, int precision, bool io16, hipStream_t st) {
+static AttnArgs lepe_args(const void* qkv, const float* getv_w, const float* getv_b, void* out, int reso, int Ctot, int c0, int heads,
+                          int Hsp, int Wsp, float scale) {
     AttnArgs a{};
     a.qkv = qkv; a.out = out; a.lepe_w = getv_w; a.lepe_b = getv_b;
     a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
     a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = Hsp * Wsp;
     a.scale = scale; a.pre_scale = 1;
     a.wsp_magic = (unsigned)(((1ull << 32) + (unsigned)Wsp - 1) / (unsigned)Wsp);
+    return a;
+}
+
+static int lepe_common(const void* qkv, const float* getv_w, const float* getv_b, void* out, int B, int reso, int Ctot, int c0, int Cb,
+                       int heads, int Hsp, int Wsp, float scale, int precision, bool io16, hipStream_t st) {
+    (void)Cb;
+    const AttnArgs a = lepe_args(qkv, getv_w, getv_b, out, reso, Ctot, c0, heads, Hsp, Wsp, scale);
     return io16 ? launch_attn<32, true, true>(a, B, precision, st) : launch_attn<32, true, false>(a, B, precision, st);
 }
 
@@ -422,6 +446,23 @@ int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float
     LEPE_CHECKS("mi355_cswin_lepe_attn_fwd");
     int rc = lepe_common(qkv, getv_w, getv_b, out, B, reso, Ctot, c0, Cb, heads, Hsp, Wsp, scale, precision, false,
                          static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_cswin_lepe_attn16_pair_fwd(const void* qkv, const float* getv_w0, const float* getv_b0, const float* getv_w1, const float* getv_b1,
+                                     void* out, int B, int reso, int Ctot, int heads, int split, float scale, int precision,
+                                     mi355_stream_t stream) {
+    MI355_CHECK_ARG(qkv && getv_w0 && getv_b0 && getv_w1 && getv_b1 && out);
+    MI355_CHECK_ARG(B > 0 && reso > 0 && Ctot > 0 && heads > 0 && (Ctot / 2) % heads == 0 && split > 0 && reso % split == 0);
+    if (Ctot / 2 / heads != 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn16_pair_fwd: head dim %d (built: 32)", Ctot / 2 / heads);
+    if (reso * split > 224) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_lepe_attn16_pair_fwd: %d tokens per stripe window > 224", reso * split);
+    MI355_CHECK_ARG((Ctot & 15) == 0 && aligned16(qkv) && aligned16(out));
+    // branch 0: idx 0 of cswin.py:62-67 (H_sp = resolution, W_sp = split) on channels [0, C/2); branch 1: idx 1 on [C/2, C)
+    const AttnArgs a0 = lepe_args(qkv, getv_w0, getv_b0, out, reso, Ctot, 0, heads, reso, split, scale);
+    const AttnArgs a1 = lepe_args(qkv, getv_w1, getv_b1, out, reso, Ctot, Ctot / 2, heads, split, reso, scale);
+    int rc = launch_attn<32, true, true>(a0, B, precision, static_cast<hipStream_t>(stream), &a1);
     if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;

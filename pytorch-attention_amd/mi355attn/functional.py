@@ -255,6 +255,19 @@ def dtype16(precision):
     raise ValueError("the 16-bit dataflow exists for precision 1 (fp16) and 2 (bf16) only")
 
 
+def cswin_lepe_attention16_pair(qkv16, w0, b0, w1, b1, out16, reso, heads, split, scale, precision=None):
+    """Both stripe branches of a CSWinBlock in one launch (16-bit qkv / out buffers, `heads` per branch)."""
+    qkv16 = _require16(qkv16, "qkv16", precision)
+    ws = [require_device_f32(t, n) for t, n in ((w0, "attns.0.get_v.weight"), (b0, "attns.0.get_v.bias"), (w1, "attns.1.get_v.weight"),
+                                                (b1, "attns.1.get_v.bias"))]
+    B = qkv16.shape[0]
+    Ctot = qkv16.shape[-1] // 3
+    check(lib().mi355_cswin_lepe_attn16_pair_fwd(dptr(qkv16), dptr(ws[0]), dptr(ws[1]), dptr(ws[2]), dptr(ws[3]), dptr(out16), B, reso, Ctot,
+                                                 heads, split, float(scale), _prec(precision), stream_ptr(qkv16.device)),
+          "mi355_cswin_lepe_attn16_pair_fwd")
+    return out16
+
+
 def fast_gemm_ok(K, N):
     """Shape envelope of mi355_linear16_fwd (K-step 64, float4 epilogue)."""
     return K % 64 == 0 and N % 4 == 0

@@ -103,7 +103,11 @@ class CSWinBlock(nn.Module):
             u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             qkv = F.linear(u, self.qkv.weight, self.qkv.bias, precision=self.precision)    # (B,L,3C) == (B,L,3,C)
             att = torch.empty(B, L, C, dtype=torch.float32, device=x.device)
-        if self.branch_num == 2:
+        if self.branch_num == 2 and fast:
+            a0, a1 = self.attns[0], self.attns[1]                  # both stripe branches in one launch
+            F.cswin_lepe_attention16_pair(qkv, a0.get_v.weight, a0.get_v.bias, a1.get_v.weight, a1.get_v.bias, att,
+                                          self.patches_resolution, a0.num_heads, self.split_size, a0.scale, p)
+        elif self.branch_num == 2:
             self.attns[0].run(qkv, att, 0)
             self.attns[1].run(qkv, att, C // 2)
         else:
