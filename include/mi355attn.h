@@ -87,6 +87,12 @@ int         mi355_workspace_forget(const void* ws, size_t ws_bytes);
 size_t mi355_se_workspace_bytes(int B, int C, int H, int W);
 int    mi355_se_fwd(const float* x, const float* w1, const float* w2, float* y,
                     int B, int C, int Cr, int H, int W, void* ws, size_t ws_bytes, mi355_stream_t stream);
+/* SE with the options its copies inside the reference's CNNs use (cnns/efficientnet.py:13-28 and mnasnet.py:11-26 Linear
+ * layers WITH bias; mobilenetv3.py:15-30 / moat.py:18-33 without; ghostnet.py:48-65 1x1 convs with bias + hard-sigmoid gate):
+ *   y = x * gate(w2 relu(w1 mean_hw(x) + b1) + b2),  gate = 0: sigmoid, 1: hard sigmoid relu6(z + 3) / 6;  b1 (Cr), b2 (C) may be NULL.
+ * Same kernels, workspace (mi355_se_workspace_bytes) and single-read / two-pass selection as mi355_se_fwd. */
+int         mi355_se_ex_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int C,
+                            int Cr, int H, int W, int gate, void* ws, size_t ws_bytes, mi355_stream_t stream);
 
 /* ECALayer.forward  (attention_mechanisms/eca.py:26-30; kernel-size rule :21-22 stays on the host)
  *   y = x * sigmoid(conv1d_k(mean_hw(x)) across the channel axis, zero pad (k-1)/2, no bias); wconv (k,) = conv.weight. */

@@ -17,6 +17,7 @@ the build container under the seed protocol of SURVEY.md section 8(c): ``tests/g
 the generating script, ``tests/golden/golden.json`` + ``tests/golden/small/*.npz`` are its committed
 outputs, and ``tests/test_oracle_golden.py`` checks every oracle function against them (``-m "not gpu"``).
 """
+from .chan_attn import se_ex_forward  # noqa: F401
 from .chan_attn import simam_forward, srm_forward, gct_gauss_forward, lct_forward, gct_forward  # noqa: F401
 from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, cbam_channel_forward, \
     cbam_spatial_forward, double_attention_forward, eca_gate_explicit, spatial_conv_explicit

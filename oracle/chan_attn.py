@@ -198,3 +198,20 @@ def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False
         e = (x if after_relu else x.abs()).sum(dim=(2, 3)) * al
         norm = ga / (e.abs().mean(dim=1, keepdim=True) + epsilon)
     return x * (1.0 + torch.tanh(e * norm + be))[:, :, None, None]
+
+
+def se_ex_forward(x, w1, b1, w2, b2, gate="sigmoid", dtype=torch.float32):
+    """SE with biases and a selectable gate -- cnns/efficientnet.py:23-28 (Linear + bias, sigmoid), cnns/ghostnet.py:59-65 (1x1 conv + bias,
+    hard_sigmoid = relu6(z + 3) / 6, :41-45).  b1 / b2 may be None."""
+    x = x.detach().to("cpu", dtype)
+    t = lambda v: None if v is None else v.detach().to("cpu", dtype)
+    w1, w2 = t(w1).reshape(w1.shape[0], -1), t(w2).reshape(w2.shape[0], -1)
+    p = x.mean(dim=(2, 3))
+    h = p @ w1.t()
+    if b1 is not None:
+        h = h + t(b1)
+    z = torch.relu(h) @ w2.t()
+    if b2 is not None:
+        z = z + t(b2)
+    g = torch.sigmoid(z) if gate == "sigmoid" else torch.clamp(z + 3.0, 0.0, 6.0) / 6.0
+    return x * g[:, :, None, None]

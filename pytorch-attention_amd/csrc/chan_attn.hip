@@ -115,7 +115,8 @@ __device__ __forceinline__ void stx(v4f v, v4f* p) {
 template <int MODE, bool VEC, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
                                                         const float* __restrict__ wa, const float* __restrict__ wb,
-                                                        float* __restrict__ y, int C, int Cr, int HW, int groups, int reverse) {
+                                                        float* __restrict__ y, int C, int Cr, int HW, int groups, int reverse,
+                                                        const mi355::SeExtra ex) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_p = smem;            // C
     float* s_h = smem + C;        // Cr (SE)
@@ -133,14 +134,14 @@ __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict
         for (int j0 = 0; j0 < Cr; j0 += 16) {
             const int j = j0 + jl;
             float acc = (j < Cr) ? dot16(wa + (long)j * C, s_p, C, part) : 0.f;
-            if (part == 0 && j < Cr) s_h[j] = fmaxf(acc, 0.f);
+            if (part == 0 && j < Cr) s_h[j] = fmaxf(acc + (ex.b1 ? ex.b1[j] : 0.f), 0.f);
         }
         __syncthreads();
         if (t < RPB && c0 + t < C) {
             const float* w2r = wb + (long)(c0 + t) * Cr;
             float z = 0.f;
             for (int j = 0; j < Cr; ++j) z += w2r[j] * s_h[j];
-            s_g[t] = sigmoidf_(z);
+            s_g[t] = se_gate(z + (ex.b2 ? ex.b2[c0 + t] : 0.f), ex.gate);
         }
     } else {
         if (t < RPB && c0 + t < C) {
@@ -453,7 +454,7 @@ size_t mi355_se_workspace_bytes(int B, int C, int, int) {
 size_t mi355_eca_workspace_bytes(int B, int C, int, int) { return pooled_bytes(B, C) + mi355::fused_state_bytes(B); }
 
 static int se_eca_common(int mode, const float* x, const float* wa, const float* wb, float* y, int B, int C, int Cr,
-                         int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+                         int H, int W, void* ws, size_t ws_bytes, hipStream_t st, mi355::SeExtra ex = mi355::SeExtra{nullptr, nullptr, 0}) {
     const int HW = H * W;
     const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
     float* pooled = static_cast<float*>(ws);
@@ -462,7 +463,7 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
     if (mode == 0 && vec && mi355::se_single_applicable(C, Cr, H, W) && !mi355::stream_is_capturing(st)) {       // SE: x read once, means exchanged as tagged granules
         char* state = static_cast<char*>(ws) + pooled_bytes(B, C);
-        return mi355::se_single(x, wa, wb, y, B, C, Cr, H, W, state, state + mi355::fused_state_bytes(B), st);
+        return mi355::se_single(x, wa, wb, y, B, C, Cr, H, W, state, state + mi355::fused_state_bytes(B), ex, st);
     }
     if (mode == 1 && vec && mi355::eca_single_applicable(C, Cr, H, W))         // ECA: x read once, no exchange between workgroups
         return mi355::eca_single(x, wa, y, B, C, Cr, H, W, st);
@@ -478,11 +479,11 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
 #define SCALE_CALL(NTL, NTS)                                                                                          \
         do {                                                                                                           \
             if (mode == 0) {                                                                                           \
-                if (vec) gate_scale_kernel<0, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse);   \
-                else     gate_scale_kernel<0, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse);  \
+                if (vec) gate_scale_kernel<0, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse, ex);   \
+                else     gate_scale_kernel<0, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, wb, yc, C, Cr, HW, groups, tu.reverse, ex);  \
             } else {                                                                                                   \
-                if (vec) gate_scale_kernel<1, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse);  \
-                else     gate_scale_kernel<1, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse); \
+                if (vec) gate_scale_kernel<1, true, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse, ex);  \
+                else     gate_scale_kernel<1, false, NTL, NTS><<<grid, 256, smem, st>>>(xc, pc, wa, nullptr, yc, C, Cr, HW, groups, tu.reverse, ex); \
             }                                                                                                          \
         } while (0)
         NT_DISPATCH(tu.ntl, tu.nts, SCALE_CALL);
@@ -499,6 +500,14 @@ int mi355_se_fwd(const float* x, const float* w1, const float* w2, float* y, int
     MI355_CHECK_ARG(B > 0 && C > 0 && Cr > 0 && H > 0 && W > 0);
     MI355_CHECK_ARG(ws_bytes >= mi355_se_workspace_bytes(B, C, H, W));
     return se_eca_common(0, x, w1, w2, y, B, C, Cr, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int mi355_se_ex_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int C, int Cr,
+                    int H, int W, int gate, void* ws, size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && w1 && w2 && y && ws);
+    MI355_CHECK_ARG(B > 0 && C > 0 && Cr > 0 && H > 0 && W > 0 && (gate == 0 || gate == 1));
+    MI355_CHECK_ARG(ws_bytes >= mi355_se_workspace_bytes(B, C, H, W));
+    return se_eca_common(0, x, w1, w2, y, B, C, Cr, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), mi355::SeExtra{b1, b2, gate});
 }
 
 int mi355_eca_fwd(const float* x, const float* wconv, float* y, int B, int C, int k, int H, int W, void* ws,

@@ -104,8 +104,9 @@ __global__ __launch_bounds__(512, 6) void eca_halo_kernel(const float* __restric
 typedef unsigned long long u64;
 
 struct SeSingleArgs {
-    const float* x; float* y; const float* w1; const float* w2;
+    const float* x; float* y; const float* w1; const float* w2; const float* b1; const float* b2;
     u64* gran; u32* ticket; u32* err;
+    int gate;
     int C, Cr, HW, n4, gpi, total;
     u32 tag, tbase;                    // granule tag and ticket base of this launch (api.hip ws_epoch)
 };
@@ -190,13 +191,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
             acc += __shfl_xor(acc, 4, WAVE);
             acc += __shfl_xor(acc, 2, WAVE);
             acc += __shfl_xor(acc, 1, WAVE);
-            if (part == 0 && j < a.Cr) s_h[j] = fmaxf(acc, 0.f);
+            if (part == 0 && j < a.Cr) s_h[j] = fmaxf(acc + (a.b1 ? a.b1[j] : 0.f), 0.f);
         }
         __syncthreads();
         const float* w2r = w2 + (long)(c0 + wave) * a.Cr;
         float z = 0.f;
         for (int j = lane; j < a.Cr; j += 64) z += w2r[j] * s_h[j];
-        const float g = sigmoidf_(wave_sum(z));
+        const float g = se_gate(wave_sum(z) + (a.b2 ? a.b2[c0 + wave] : 0.f), a.gate);
         u32 ob = voff;                                                // row step in the VGPR offset of the stores: cbam_single.hip
         asm volatile("" : "+v"(ob));
 #pragma unroll
@@ -257,9 +258,9 @@ bool se_single_applicable(int C, int Cr, int H, int W) {
 
 // `state` = arrive[B] | ticket | err (fused_state_bytes), `gran` = B*C granules (se_single_extra_bytes)
 int se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,
-              void* gran, hipStream_t st) {
+              void* gran, SeExtra ex, hipStream_t st) {
     SeSingleArgs a{};
-    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2;
+    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.b1 = ex.b1; a.b2 = ex.b2; a.gate = ex.gate;
     a.gran = static_cast<u64*>(gran);
     a.ticket = static_cast<u32*>(state) + B;
     a.err = a.ticket + 1;

@@ -35,8 +35,14 @@ int   cbam_single(const float* x, const float* w1, const float* w2, const float*
                   int ks, void* extra, hipStream_t st);
 size_t se_single_extra_bytes(int B, int C);
 bool  se_single_applicable(int C, int Cr, int H, int W);
+// SE variants embedded in the reference's CNNs: optional biases of the two excitation layers and the gate function
+struct SeExtra {
+    const float* b1;     // (Cr) or null
+    const float* b2;     // (C) or null
+    int gate;            // 0 sigmoid, 1 hard sigmoid relu6(z + 3) / 6
+};
 int   se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,
-                void* gran, hipStream_t st);
+                void* gran, SeExtra ex, hipStream_t st);
 bool  eca_single_applicable(int C, int k, int H, int W);
 int   eca_single(const float* x, const float* taps, float* y, int B, int C, int k, int H, int W, hipStream_t st);
 size_t fused_state_bytes(int B);
@@ -85,6 +91,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float se_gate(float z, int kind) { return kind ? fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f : sigmoidf_(z); }
 // exact-erf GELU (nn.GELU() default), library erff: used off the hot path (LPI)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf-form GELU for the GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level) on the

@@ -70,6 +70,26 @@ def se_forward(x, w1, w2):
     return y
 
 
+def se_ex_forward(x, w1, b1, w2, b2, gate="sigmoid"):
+    """SE with optional excitation biases and a choice of gate ("sigmoid" | "hard_sigmoid"): the variants inside the reference's CNNs."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    w1 = require_device_f32(w1, "w1").reshape(w1.shape[0], -1)
+    w2 = require_device_f32(w2, "w2").reshape(w2.shape[0], -1)
+    Cr = w1.shape[0]
+    if tuple(w1.shape) != (Cr, C) or tuple(w2.shape) != (C, Cr):
+        raise ValueError(f"SE weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not match C={C}")
+    if gate not in ("sigmoid", "hard_sigmoid"):
+        raise ValueError("gate must be 'sigmoid' or 'hard_sigmoid'")
+    y = torch.empty_like(x)
+    n = lib().mi355_se_workspace_bytes(B, C, H, W)
+    ws = _ffi.workspace_dedicated(("se", B, C, H, W), n, x.device)
+    check(lib().mi355_se_ex_fwd(dptr(x), dptr(w1), dptr(_opt(b1, "b1")), dptr(w2), dptr(_opt(b2, "b2")), dptr(y), B, C, Cr, H, W,
+                                1 if gate == "hard_sigmoid" else 0, dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_se_ex_fwd")
+    _check_sync_state(ws, B, C, "mi355_se_ex_fwd")
+    return y
+
+
 def eca_forward(x, wconv):
     """ECALayer forward: x (B,C,H,W), wconv (1,1,k) or (k,)."""
     x = require_device_f32(x, "x")

@@ -7,3 +7,4 @@ from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed
                    xcit_nano_12_p16)
 from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401
 from .mhsa import SRAttention, SRAttentionRelPos, SRConvAttention  # noqa: F401
+from .se_variants import SELayerBias, SELayerHidden, SqueezeExcite  # noqa: F401

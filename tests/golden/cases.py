@@ -117,6 +117,16 @@ CASES = [
     dict(id="segformer_attn", mod="vision_transformers.segformer", cls="Attention", args=(64,), kwargs=dict(num_heads=1, qkv_bias=True, sr_ratio=8),
          shape=(2, 3136, 64), fwd_args=(56, 56),
          oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 1, 56, 56, 8, layout="q,kv", dtype=dt)),
+    # ---- squeeze-excite copies inside the CNN files (module level) ----------------------------------------------------
+    dict(id="se_effnet", mod="cnns.efficientnet", cls="SELayer", args=(96, 4), shape=(2, 96, 28, 28), small=True,
+         oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["fc.0.weight"], sd["fc.0.bias"], sd["fc.2.weight"], sd["fc.2.bias"], "sigmoid", dt)),
+    dict(id="se_mnasnet", mod="cnns.mnasnet", cls="SELayer", args=(72, 4), shape=(2, 72, 14, 14),
+         oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["fc.0.weight"], sd["fc.0.bias"], sd["fc.2.weight"], sd["fc.2.bias"], "sigmoid", dt)),
+    dict(id="se_mbv3", mod="cnns.mobilenetv3", cls="SELayer", args=(120, 32), shape=(2, 120, 28, 28),
+         oracle=lambda x, sd, dt: O.se_forward(x, sd["fc.0.weight"], sd["fc.2.weight"], dt)),
+    dict(id="se_ghost", mod="cnns.ghostnet", cls="SqueezeExcite", args=(160,), shape=(2, 160, 14, 14), small=True, prep="perturb_all",
+         oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["conv_reduce.weight"], sd["conv_reduce.bias"], sd["conv_expand.weight"],
+                                                  sd["conv_expand.bias"], "hard_sigmoid", dt)),
     dict(id="xcit_nano_full", mod="vision_transformers.xcit", cls="xcit_nano_12_p16", shape=(2, 3, 224, 224), slow=True,
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 4, 12, 2, dt)),
 ]

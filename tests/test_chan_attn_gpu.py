@@ -391,3 +391,28 @@ def test_exchange_kernels_under_graph_capture():
             want = [m(x) for m in mods]                   # eager calls in between: per-launch tags, remembered workspaces
         for a, b, m in zip(got, want, mods):
             assert_parity(a.cpu(), b.cpu(), 2e-6, f"replay {rep} {type(m).__name__}")
+
+
+@pytest.mark.parametrize("single", [1, 0])
+@pytest.mark.parametrize("shape", [(2, 96, 28, 28), (3, 40, 7, 9), (2, 256, 56, 56)])
+def test_se_variants_bias_and_hard_sigmoid(shape, single):
+    """SE with excitation biases (efficientnet / mnasnet) and with the hard-sigmoid gate (ghostnet) through the single-read and the
+    two-pass kernels, against the oracle."""
+    import mi355attn
+    from mi355attn.modules import SELayerBias, SqueezeExcite
+    from cases import perturb_all
+    B, C, H, W = shape
+    torch.manual_seed(51)
+    a, g = SELayerBias(C, 4).eval(), SqueezeExcite(C).eval()
+    perturb_all(a); perturb_all(g)
+    x = torch.randn(*shape)
+    mi355attn.set_option("se_single", single)
+    try:
+        with torch.no_grad():
+            ya, yg = a.cuda()(x.cuda()).cpu(), g.cuda()(x.cuda()).cpu()
+    finally:
+        mi355attn.set_option("se_single", 1)
+    sa, sg = {k: v.cpu() for k, v in a.state_dict().items()}, {k: v.cpu() for k, v in g.state_dict().items()}
+    assert_parity(ya, O.se_ex_forward(x, sa["fc.0.weight"], sa["fc.0.bias"], sa["fc.2.weight"], sa["fc.2.bias"]), 1e-5, "se + bias")
+    assert_parity(yg, O.se_ex_forward(x, sg["conv_reduce.weight"], sg["conv_reduce.bias"], sg["conv_expand.weight"], sg["conv_expand.bias"],
+                                      "hard_sigmoid"), 1e-5, "se + bias + hard sigmoid")

@@ -18,7 +18,7 @@ from conftest import assert_parity
 pytestmark = pytest.mark.gpu
 
 VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256", "simam64", "srm64", "gctg64", "lct64", "gct64", "gct64_l1",
-               "simam256", "srm256", "gctg256", "lct256", "gct256"}
+               "simam256", "srm256", "gctg256", "lct256", "gct256", "se_effnet", "se_mnasnet", "se_mbv3", "se_ghost"}
 
 
 def _run(c, precision=None):
