@@ -169,6 +169,16 @@ int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias
  * Needs K % 64 == 0, N % 4 == 0, ldx % 8 == 0 (other shapes: cast back and use mi355_linear_fwd). */
 int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
                        int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, mi355_stream_t stream);
+/* Channel-major token mixing (mlp_mixer.py:45-47: norm1 -> transpose(1,2) -> token_mlp -> transpose(1,2) -> + x) without transposes
+ * in HBM.  mi355_layernorm16_t_fwd writes LayerNorm(x (B,N,C)) TRANSPOSED per image in 16 bit: ut (B, C, NP), zero-filled for
+ * N <= n < NP (NP % 32 == 0; pick NP % 64 == 0 so that it is a valid K for mi355_linear16_fwd against a weight zero-padded to
+ * (T, NP)).  mi355_linear16_tr_fwd is mi355_linear16_fwd with the result written transposed per image and no gamma/act:
+ *   Y[(img * N + n) * rows_per_image + c] = resid[same] + (X16[img * rows_per_image + c, :] . W16[n, :]) + bias[n]
+ * for M = B * rows_per_image rows of X16; Y / resid fp32 (B, N, rows_per_image).  Needs K % 64 == 0, rows_per_image % 4 == 0. */
+int mi355_layernorm16_t_fwd(const float* x, const float* weight, const float* bias, void* ut16, int B, int N, int C, int NP, float eps,
+                            int precision, mi355_stream_t stream);
+int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K,
+                          int ldx, int rows_per_image, int precision, mi355_stream_t stream);
 /* mi355_sdpa_fwd / mi355_cswin_lepe_attn_fwd with 16-bit qkv and out buffers (same layouts). */
 int mi355_sdpa16_fwd(const void* qkv16, void* out16, int B, int N, int heads, int d, float scale, int precision,
                      mi355_stream_t stream);

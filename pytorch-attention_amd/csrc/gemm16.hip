@@ -24,6 +24,7 @@ struct G16Args {
     const float* bias; const float* gamma; const float* resid;
     int M, N, K, lda, ldb, ldc;
     int act;
+    int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
 };
 
 template <typename T> struct Vec8;
@@ -38,7 +39,10 @@ template <>
 __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // Tile BM x BN x 64 per workgroup of WM x WN waves; each wave owns a (BM/WM) x (BN/WN) sub-tile = MF x NF MFMA 16x16 tiles.
-template <typename T, bool OUT16, int BM, int BN, int WM, int WN, bool PRIO, int STAGES>
+// TR = true: the product is written TRANSPOSED per image -- row m = img * tr_rows + c, column n -> Y[(img * N + n) * tr_rows + c]
+// (+ the residual at the same address, bias indexed by n): the Mixer token-mixing product computed channel-major lands back in
+// the token-major activation without a transpose pass.
+template <typename T, bool OUT16, int BM, int BN, int WM, int WN, bool PRIO, int STAGES, bool TR = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fb[j], fa[i], acc[i][j]);   // D^T = W.X^T: see the epilogue
+                for (int j = 0; j < NF; ++j) {
+                    if constexpr (TR) acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);          // D = X.W^T: lane holds 4 rows of one column
+                    else              acc[i][j] = mma16<T>(fb[j], fa[i], acc[i][j]);          // D^T = W.X^T: see the epilogue
+                }
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -144,7 +151,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
     //      operand, activations as B), so lane (l15, g) holds output row m = i*16 + l15 and four CONSECUTIVE columns
     //      n = j*16 + g*4 + [0,4): one 16-byte (fp32) / 8-byte (16-bit) store per tile and lane, the four lane groups of a row
     //      completing a 64-byte run -- no LDS transpose, ~8x fewer epilogue instructions than the slab version -----------------
-    {
+    if constexpr (TR) {
+        // lane (l15, g) holds column n = j*16 + l15 and four CONSECUTIVE rows m = i*16 + g*4 + [0,4) -- consecutive channels of
+        // one image (tr_rows % 4 == 0), i.e. 16 contiguous bytes of the token-major output; the four lane groups and the MF
+        // row tiles of a wave complete a 256-byte run per token
+        float* Cf = static_cast<float*>(g.C);
+        const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = n0 + wc * TN + j * 16 + l15;
+            if (n >= g.N) continue;
+            const float bn = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + wr * TM + i * 16 + g4;
+                if (m >= g.M) continue;                         // M % 4 == 0 is a launch precondition
+                const int img = m / g.tr_rows, c = m - img * g.tr_rows;
+                const long o = ((long)img * g.N + n) * g.tr_rows + c;
+                f4 v = acc[i][j] + f4{bn, bn, bn, bn};
+                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + o);
+                *reinterpret_cast<f4*>(Cf + o) = v;
+            }
+        }
+    } else {
         float* Cf = static_cast<float*>(g.C);
         T* Ch = static_cast<T*>(g.C);
         const int l15 = lane & 15, g4 = (lane >> 4) * 4;
@@ -618,6 +648,27 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     }
 #undef BY_VARIANT
 #undef LAUNCH
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K,
+                          int ldx, int rows_per_image, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X16 && W16 && Y && M > 0 && N > 0 && K > 0 && ldx >= K && rows_per_image > 0);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if ((K % BK) || (ldx & 7) || (rows_per_image & 3) || (M % rows_per_image) || !aligned16(X16) || !aligned16(W16) || !aligned16(Y) ||
+        (resid && !aligned16(resid)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear16_tr_fwd: needs K %% 64 == 0, rows_per_image %% 4 == 0 dividing M (K=%d M=%d rows=%d)",
+                           K, M, rows_per_image);
+    G16Args g{};
+    g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = N; g.act = MI355_ACT_NONE; g.tr_rows = rows_per_image;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool wide = N > 128;
+#define TRL(T_, BN_, WN_) gemm16_kernel<T_, false, 128, BN_, 2, WN_, true, 1, true><<<cdiv(M, 128) * cdiv(N, BN_), 2 * WN_ * 64, 0, st>>>(g)
+    if (precision == MI355_PREC_FP16) { if (wide) TRL(_Float16, 256, 4); else TRL(_Float16, 128, 2); }
+    else                              { if (wide) TRL(__bf16, 256, 4); else TRL(__bf16, 128, 2); }
+#undef TRL
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

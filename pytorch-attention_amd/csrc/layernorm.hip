@@ -139,6 +139,87 @@ int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias
 
 }  // extern "C"
 
+// LayerNorm over channels, written TRANSPOSED per image in the 16-bit operand format: x (B, N, C) fp32 -> ut (B, C, NP), ut[b,c,n] =
+// LN(x[b,n,:])[c] for n < N and 0 for N <= n < NP.  This is the K-major activation the Mixer token-mixing product wants as a
+// plain row-major GEMM operand (mlp_mixer.py:45-47: norm1 -> transpose(1,2) -> token_mlp).  One workgroup = 32 tokens of one image;
+// a wave normalises two tokens at a time (lane c = lane + 64k, coalesced 256-byte loads) and parks the pair as one 32-bit word
+// in LDS at [c][pair] with a 17-word pitch (odd: conflict-free for the column writes and the row reads); four lanes then
+// write each channel's 64-byte run.
+namespace {
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template <typename T, int KC>
+__global__ __launch_bounds__(256) void layernorm16_t_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                           T* __restrict__ ut, int N, int C, int NP, float eps) {
+    extern __shared__ unsigned int lds_t[];                      // [C][17]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n0 = blockIdx.x * 32, img = blockIdx.y;
+    float wv[KC], bv[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = lane + 64 * k;
+        wv[k] = c < C ? w[c] : 0.f; bv[k] = c < C ? b[c] : 0.f;
+    }
+    const float inv = 1.f / (float)C;
+#pragma unroll 1
+    for (int pr = 0; pr < 4; ++pr) {
+        const int tp = wave * 4 + pr;                            // pair index inside the tile: tokens n0 + 2*tp, +1
+        const int na = n0 + 2 * tp, nb = na + 1;
+        float va[KC], vb[KC];
+        const float* ra = x + ((long)img * N + (na < N ? na : 0)) * C;
+        const float* rb = x + ((long)img * N + (nb < N ? nb : 0)) * C;
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = lane + 64 * k;
+            va[k] = c < C ? ra[c] : 0.f; vb[k] = c < C ? rb[c] : 0.f;
+            sa += va[k]; sb += vb[k];
+        }
+        sa = wave_sum(sa) * inv; sb = wave_sum(sb) * inv;
+        float qa = 0.f, qb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = lane + 64 * k;
+            const float da = c < C ? va[k] - sa : 0.f, db = c < C ? vb[k] - sb : 0.f;
+            qa += da * da; qb += db * db;
+        }
+        const float ia = rsqrtf(wave_sum(qa) * inv + eps), ib = rsqrtf(wave_sum(qb) * inv + eps);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = lane + 64 * k;
+            if (c >= C) continue;
+            const T ha = na < N ? (T)((va[k] - sa) * ia * wv[k] + bv[k]) : (T)0.f;
+            const T hb = nb < N ? (T)((vb[k] - sb) * ib * wv[k] + bv[k]) : (T)0.f;
+            lds_t[c * 17 + tp] = (unsigned int)__builtin_bit_cast(unsigned short, ha) | ((unsigned int)__builtin_bit_cast(unsigned short, hb) << 16);
+        }
+    }
+    __syncthreads();
+    for (int idx = t; idx < C * 4; idx += 256) {
+        const int c = idx >> 2, q = idx & 3;
+        const unsigned int* p = lds_t + c * 17 + q * 4;
+        u4 o{p[0], p[1], p[2], p[3]};
+        *reinterpret_cast<u4*>(ut + ((long)img * C + c) * NP + n0 + q * 8) = o;
+    }
+}
+}  // namespace
+
+extern "C" int mi355_layernorm16_t_fwd(const float* x, const float* weight, const float* bias, void* ut16, int B, int N, int C, int NP,
+                                       float eps, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && bias && ut16 && B > 0 && N > 0 && C > 0 && NP >= N);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if ((NP & 31) || C > 1024 || !aligned16(ut16))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_layernorm16_t_fwd: needs NP %% 32 == 0 and C <= 1024 (NP=%d C=%d)", NP, C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(NP / 32, B);
+    const size_t lds = (size_t)C * 17 * 4;
+#define LNT(T_, KC_) layernorm16_t_kernel<T_, KC_><<<grid, 256, lds, st>>>(x, weight, bias, static_cast<T_*>(ut16), N, C, NP, eps)
+#define LNT_BY_C(T_) do { if (C <= 256) LNT(T_, 4); else if (C <= 512) LNT(T_, 8); else LNT(T_, 16); } while (0)
+    if (precision == MI355_PREC_FP16) LNT_BY_C(_Float16); else LNT_BY_C(__bf16);
+#undef LNT_BY_C
+#undef LNT
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
 // mean over the token axis: y[b, c] = (1/N) sum_n x[b*batch_stride + n*C + c]   (CSWin head cswin.py:341, Mixer head mlp_mixer.py:77,
 // ViT global_pool="avg" ViT.py:189-190 via an offset base pointer).  One workgroup per (image, 256-channel slab).
 namespace {

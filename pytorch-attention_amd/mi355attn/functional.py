@@ -403,6 +403,46 @@ def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=Fa
     return y
 
 
+def layernorm16_t(x, weight, bias, eps=1e-5, NP=None, precision=None):
+    """LayerNorm over C of x (B, N, C), written transposed per image in 16 bit: (B, C, NP), zeros for n >= N."""
+    x = require_device_f32(x, "x")
+    weight = require_device_f32(weight, "weight")
+    bias = require_device_f32(bias, "bias")
+    B, N, C = x.shape
+    NP = NP or -(-N // 64) * 64
+    ut = torch.empty(B, C, NP, dtype=dtype16(precision), device=x.device)
+    check(lib().mi355_layernorm16_t_fwd(dptr(x), dptr(weight), dptr(bias), dptr(ut), B, N, C, NP, float(eps), _prec(precision),
+                                        stream_ptr(x.device)), "mi355_layernorm16_t_fwd")
+    return ut
+
+
+def linear16_tr(xt16, w16, bias, resid, precision=None):
+    """xt16 (B, C, K) 16-bit, w16 (N, K) -> fp32 (B, N, C) = resid + (xt16 @ w16^T + bias) transposed per image."""
+    xt16 = _require16(xt16, "xt16", precision)
+    w16 = _require16(w16, "w16", precision)
+    bias, resid = _opt(bias, "bias"), _opt(resid, "resid")
+    B, C, K = xt16.shape
+    N = w16.shape[0]
+    if w16.shape[1] != K:
+        raise ValueError(f"linear16_tr: weight in_features {w16.shape[1]} != {K}")
+    if resid is not None and tuple(resid.shape) != (B, N, C):
+        raise ValueError("linear16_tr: residual shape mismatch")
+    y = torch.empty(B, N, C, dtype=torch.float32, device=xt16.device)
+    check(lib().mi355_linear16_tr_fwd(dptr(xt16), dptr(w16), dptr(bias), dptr(resid), dptr(y), B * C, N, K, K, C, _prec(precision),
+                                      stream_ptr(xt16.device)), "mi355_linear16_tr_fwd")
+    return y
+
+
+def weight16_padk(w, K, precision=None):
+    """16-bit copy of a Linear weight (N, k) zero-padded along in_features to K (cached with the parameter)."""
+    def build():
+        out = torch.zeros(w.shape[0], K, dtype=dtype16(precision), device=w.device)
+        out[:, :w.shape[1]] = w.detach()
+        return out
+    tag = (w._version, w.data_ptr(), tuple(w.shape))
+    return _derived_get((w,), ("w16padk", K, _prec(precision)), tag, build)
+
+
 def sdpa16(qkv16, num_heads, scale, precision=None):
     qkv16 = _require16(qkv16, "qkv16", precision)
     B, N, C3 = qkv16.shape

@@ -35,9 +35,18 @@ class MixerLayer(nn.Module):
 
     def forward(self, x):
         t = self.token_mlp
-        u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        hid = F.token_mix(t.fc1.weight, u, t.fc1.bias, act=F.ACT_GELU, precision=self.precision)     # (B,T,C)
-        x = F.token_mix(t.fc2.weight, hid, t.fc2.bias, resid=x, precision=self.precision)            # (B,N,C)
+        p = F._prec(self.precision)
+        T, N = t.fc1.weight.shape
+        if p in (F.PREC_FP16, F.PREC_BF16) and T % 64 == 0 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024:
+            # channel-major on the 16-bit GEMM engine: LN(x)^T (B,C,NP) -> gelu(. W1^T + b1) (B,C,T) -> (. W2^T + b2)^T + x
+            NP = -(-N // 64) * 64
+            ut = F.layernorm16_t(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, NP, p)
+            ht = F.linear16(ut, F.weight16_padk(t.fc1.weight, NP, p), t.fc1.bias, act=F.ACT_GELU, out16=True, precision=p)
+            x = F.linear16_tr(ht, F.weight16(t.fc2.weight, p), t.fc2.bias, x, p)
+        else:
+            u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            hid = F.token_mix(t.fc1.weight, u, t.fc1.bias, act=F.ACT_GELU, precision=self.precision)     # (B,T,C)
+            x = F.token_mix(t.fc2.weight, hid, t.fc2.bias, resid=x, precision=self.precision)            # (B,N,C)
         c = self.channel_mlp
         if _fast(self.precision, c.fc1, c.fc2):
             u = F.layernorm16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, F._prec(self.precision))

@@ -540,6 +540,44 @@ def test_linear16_rejects_shapes_outside_the_envelope():
 
 
 @pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,N,C,NP", [(3, 196, 512, 256), (2, 50, 132, 64), (1, 64, 64, 64), (2, 33, 1024, 96), (5, 7, 4, 32)])
+def test_layernorm16_transposed(B, N, C, NP, prec):
+    """LayerNorm written channel-major per image in 16 bit, zero-filled up to NP tokens (the Mixer token-mixing operand)."""
+    torch.manual_seed(B * N + C)
+    x, w, b = (torch.randn(B, N, C) * 2 + 0.5).cuda(), torch.randn(C).cuda(), torch.randn(C).cuda()
+    ut = F().layernorm16_t(x, w, b, 1e-5, NP, prec)
+    assert ut.shape == (B, C, NP) and torch.count_nonzero(ut[:, :, N:]) == 0
+    ref = torch.nn.functional.layer_norm(x.double().cpu(), (C,), w.double().cpu(), b.double().cpu(), 1e-5).transpose(1, 2)
+    assert_parity(ut[:, :, :N].float().cpu(), ref.float(), 6e-4 if prec == 1 else 5e-3, f"ln16_t{(B, N, C)} p{prec}")
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,C,N,K", [(3, 512, 196, 256), (2, 132, 50, 64), (1, 64, 7, 128), (5, 4, 300, 64), (2, 260, 129, 192)])
+def test_linear16_transposed_output(B, C, N, K, prec):
+    """Same products as mi355_linear16_fwd, written (B, N, C) instead of (B, C, N), bias per n, residual in the output layout."""
+    torch.manual_seed(B + C + N + K)
+    f = F()
+    xt16 = f.cast16(torch.randn(B, C, K).cuda(), prec)
+    w16 = f.cast16((torch.randn(N, K) / math.sqrt(K)).cuda(), prec)
+    bias, resid = torch.randn(N).cuda(), torch.randn(B, N, C).cuda()
+    got = f.linear16_tr(xt16, w16, bias, resid, prec)
+    ref = xt16.double().cpu() @ w16.double().cpu().t() + bias.double().cpu()
+    assert_parity(got.cpu(), (ref.transpose(1, 2) + resid.double().cpu()).float(), 1e-5, f"linear16_tr{(B, C, N, K)} p{prec}")
+    if N % 4 == 0:
+        plain = f.linear16(xt16, w16, bias, precision=prec)
+        assert torch.equal(got, plain.transpose(1, 2) + resid)
+    got = f.linear16_tr(xt16, w16, None, None, prec)
+    assert_parity(got.cpu(), (xt16.double().cpu() @ w16.double().cpu().t()).transpose(1, 2).float(), 1e-5, "no bias / resid")
+
+
+def test_linear16_transposed_rejects_bad_rows():
+    from mi355attn import Mi355Error
+    f = F()
+    with pytest.raises(Mi355Error):
+        f.linear16_tr(torch.randn(2, 6, 64).cuda().half(), torch.randn(8, 64).cuda().half(), None, None, 1)     # C % 4 != 0
+
+
+@pytest.mark.parametrize("prec", [1, 2])
 @pytest.mark.parametrize("rows,cols", [(300, 384), (1000, 768), (802, 64), (33, 128), (9, 52)])
 def test_layernorm16(rows, cols, prec):
     torch.manual_seed(rows)
