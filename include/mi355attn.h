@@ -138,6 +138,91 @@ int mi355_lct_fwd(const float* x, const float* w, const float* b, float* y, int 
 int mi355_gct_fwd(const float* x, const float* alpha, const float* gamma, const float* beta, float* y, int B, int C, int H, int W,
                   float epsilon, int mode_l1, int after_relu, void* ws, size_t ws_bytes, mi355_stream_t stream);
 
+/* ---- gates built from axis reductions (second group) ---------------------------------------------------------
+ * x, y (B,C,H,W) fp32 contiguous; caller workspace of mi355_axis_attn_workspace_bytes (mi355_bam_workspace_bytes for BAM), no state
+ * kept between calls.  BatchNorm layers run in eval mode and are passed FOLDED: scale = weight / sqrt(running_var + eps),
+ * shift = bias - running_mean * scale (+ scale * the preceding convolution's bias where noted).
+ *   gc        gc_module.py:30-43   ctx[b,c] = sum_hw x[b,c,hw] * (conv_w . x[b,:,hw] + conv_b)   (the declared softmax is never applied),
+ *                                  y = x + W2 relu(LayerNorm_Cr(W1 ctx + b1)) + b2;  w1 (Cr,C), w2 (C,Cr), ln_w / ln_b (Cr)
+ *   coordatt  coordatten.py:30-44  p = [mean_w x ; mean_h x] (B,C,H+W); h = relu(bn(W1 p + b1)) (hidden rows);
+ *                                  y = x * (Wh h[:, :H] + bh)[b,c,i] * (Ww h[:, H:] + bw)[b,c,j]   (no sigmoid in the reference);
+ *                                  w1 (hidden,C), wh / ww (C,hidden)
+ *   triplet   triplet_attention.py:58-63   three AttentionGates s = sigmoid(relu(bn(conv_kxk([mean, max])))) over the pooled axis:
+ *                                  s_ch[b,c,i] from pooling over w, s_cw[b,c,j] over h, s_hw[b,i,j] over c;
+ *                                  y = (x s_ch + x s_cw + x s_hw) / 3.  w_* (2,k,k); affine = 6 floats {scale, shift} x {ch, cw, hw},
+ *                                  shift including scale * conv bias.
+ *   bam       bam.py:63-71         y = x + x * sigmoid(cg[b,c] + sg[b,hw]);  cg = bn1d(W2 relu(W1 mean_hw x + b1) + b2),
+ *                                  sg = bn(conv3(relu(bn(dconv2(relu(bn(dconv1(conv1 x)))))))), dconv = 3x3, dilation = padding.
+ *                                  Parameters as an array of MI355_BAM_NPARAMS device pointers (host array), indexed by the enum. */
+size_t mi355_axis_attn_workspace_bytes(int B, int C, int H, int W);
+int mi355_gc_fwd(const float* x, const float* conv_w, const float* conv_b, const float* w1, const float* b1, const float* ln_w,
+                 const float* ln_b, const float* w2, const float* b2, float* y, int B, int C, int Cr, int H, int W, float ln_eps,
+                 void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+int mi355_coordatt_fwd(const float* x, const float* w1, const float* b1, const float* bn_scale, const float* bn_shift, const float* wh,
+                       const float* bh, const float* ww, const float* bw, float* y, int B, int C, int hidden, int H, int W,
+                       void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+int mi355_triplet_fwd(const float* x, const float* w_ch, const float* w_cw, const float* w_hw, const float* affine, float* y, int B, int C,
+                      int H, int W, int ksize, void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+enum {
+    MI355_BAM_FC1_W = 0,       /* (Cr,C)      channel_attn.mlp[0].weight */
+    MI355_BAM_FC1_B,           /* (Cr)        channel_attn.mlp[0].bias */
+    MI355_BAM_FC2_W,           /* (C,Cr)      channel_attn.mlp[2].weight */
+    MI355_BAM_FC2_B,           /* (C)         channel_attn.mlp[2].bias */
+    MI355_BAM_BN1D_SCALE,      /* (C)         channel_attn.bn folded */
+    MI355_BAM_BN1D_SHIFT,      /* (C) */
+    MI355_BAM_CONV1_W,         /* (Cr,C)      spatial_attn.conv1.weight */
+    MI355_BAM_CONV1_B,         /* (Cr) */
+    MI355_BAM_DCONV1_W,        /* (Cr,Cr,3,3) spatial_attn.conv2[0].weight */
+    MI355_BAM_DCONV1_SCALE,    /* (Cr)        conv2[1] folded */
+    MI355_BAM_DCONV1_SHIFT,    /* (Cr)        conv2[1] folded + scale * conv2[0].bias */
+    MI355_BAM_DCONV2_W,        /* (Cr,Cr,3,3) spatial_attn.conv2[3].weight */
+    MI355_BAM_DCONV2_SCALE,    /* (Cr)        conv2[4] folded */
+    MI355_BAM_DCONV2_SHIFT,    /* (Cr) */
+    MI355_BAM_CONV3_W,         /* (Cr)        spatial_attn.conv3.weight * bn scale */
+    MI355_BAM_CONV3_B,         /* (1)         spatial_attn.bn folded + scale * conv3.bias */
+    MI355_BAM_NPARAMS
+};
+size_t mi355_bam_workspace_bytes(int B, int C, int Cr, int H, int W);
+int mi355_bam_fwd(const float* x, const float* const* params, float* y, int B, int C, int Cr, int H, int W, int dilation,
+                  void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
+/*   sk        sk_module.py:41-56   u1 = relu(bn(conv3x3_grouped(x))), u2 = relu(bn(conv3x3_grouped_dilation2(x))), s = mean_hw(u1 + u2),
+ *                                  z = relu(bn1d(fc s)), [a, b] = softmax over the two branches of [fc1 z, fc2 z], y = u1 a + u2 b.
+ *                                  x (B,Cin,H,W), y (B,planes,H,W); planes / groups in {1,2,4,8,16}; parameters as an array of
+ *                                  MI355_SK_NPARAMS device pointers. */
+enum {
+    MI355_SK_CONV3_W = 0,      /* (planes, Cin/groups, 3, 3)  split_3x3[0].weight */
+    MI355_SK_CONV3_SCALE,      /* (planes)   split_3x3[1] folded */
+    MI355_SK_CONV3_SHIFT,      /* (planes)   split_3x3[1] folded + scale * split_3x3[0].bias */
+    MI355_SK_CONV5_W,          /* (planes, Cin/groups, 3, 3)  split_5x5[0].weight (3x3, dilation 2) */
+    MI355_SK_CONV5_SCALE,
+    MI355_SK_CONV5_SHIFT,
+    MI355_SK_FC_W,             /* (d, planes) fc[0].weight */
+    MI355_SK_FC_B,             /* (d) */
+    MI355_SK_FC_BN_SCALE,      /* (d)        fc[1] folded */
+    MI355_SK_FC_BN_SHIFT,      /* (d) */
+    MI355_SK_FC1_W,            /* (planes, d) */
+    MI355_SK_FC1_B,            /* (planes) */
+    MI355_SK_FC2_W,            /* (planes, d) */
+    MI355_SK_FC2_B,            /* (planes) */
+    MI355_SK_NPARAMS
+};
+size_t mi355_sk_workspace_bytes(int B, int planes, int H, int W);
+int mi355_sk_fwd(const float* x, const float* const* params, float* y, int B, int Cin, int planes, int groups, int d, int H, int W,
+                 void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
+/* DANet dual attention (dual_attention.py).  CAM :35-42: y = beta * softmax(X X^T) X + x with X = x viewed as (C, HW) per image; beta is
+ * a 1-element device array; H*W and C multiples of 4; workspace of mi355_cam_workspace_bytes (the Gram matrices).  The logits are
+ * unscaled sums over HW, so precision 0 (fp32-class split-bf16 MFMA) is the mode that meets the parity tolerance.
+ * PAM :20-28 is composed by the caller from mi355_conv2d_tokens_fwd (the three 1x1 convs as one token-major GEMM),
+ * mi355_sdpa_general_fwd (one head of width C, scale 1) and mi355_tokens_to_nchw_axpy_fwd:
+ *   y[b,c,p] = alpha[0] * tokens[b,p,c] + x[b,c,p]      tokens (B,HW,C), x / y (B,C,HW), alpha a 1-element device array. */
+size_t mi355_cam_workspace_bytes(int B, int C);
+int mi355_cam_fwd(const float* x, const float* beta, float* y, int B, int C, int H, int W, int precision, void* workspace,
+                  size_t workspace_bytes, mi355_stream_t stream);
+int mi355_tokens_to_nchw_axpy_fwd(const float* tokens, const float* x, const float* alpha, float* y, int B, int HW, int C,
+                                  mi355_stream_t stream);
+
 /* ---- dense building blocks used by the transformer blocks ---------------------------------------- */
 
 /* nn.Linear (+ optional GELU, LayerScale, residual):  Y = resid + gamma * act(X W^T + bias)

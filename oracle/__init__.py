@@ -18,6 +18,7 @@ the generating script, ``tests/golden/golden.json`` + ``tests/golden/small/*.npz
 outputs, and ``tests/test_oracle_golden.py`` checks every oracle function against them (``-m "not gpu"``).
 """
 from .chan_attn import se_ex_forward  # noqa: F401
+from .axis_attn import gc_forward, coordatt_forward, triplet_forward, bam_forward, sk_forward, pam_forward, cam_forward  # noqa: F401
 from .chan_attn import simam_forward, srm_forward, gct_gauss_forward, lct_forward, gct_forward  # noqa: F401
 from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, cbam_channel_forward, \
     cbam_spatial_forward, double_attention_forward, eca_gate_explicit, spatial_conv_explicit

@@ -68,6 +68,17 @@ SIGNATURES = {
     "mi355_gct_gauss_fwd": (c_int, [c_vp, c_vp] + [c_int] * 4 + [ctypes.c_float, ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
     "mi355_lct_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
     "mi355_gct_fwd": (c_int, [c_vp] * 5 + [c_int] * 4 + [ctypes.c_float, c_int, c_int, c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_axis_attn_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
+    "mi355_gc_fwd": (c_int, [c_vp] * 10 + [c_int] * 5 + [ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_coordatt_fwd": (c_int, [c_vp] * 10 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_triplet_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_bam_workspace_bytes": (ctypes.c_size_t, [c_int] * 5),
+    "mi355_bam_fwd": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_sk_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
+    "mi355_sk_fwd": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_cam_workspace_bytes": (ctypes.c_size_t, [c_int] * 2),
+    "mi355_cam_fwd": (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_tokens_to_nchw_axpy_fwd": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "mi355_mlp_fused_fwd": (c_int, [c_vp] * 7 + [ctypes.c_long, c_int, c_int, c_int, ctypes.c_float, c_int, c_vp]),
     "mi355_sdpa_general_fwd": (c_int, [c_vp] * 5 + [c_int] * 5 + [ctypes.c_long] * 5 + [ctypes.c_float, c_int, c_int, c_vp]),
     "mi355_dwconv_patch_tokens_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),

@@ -70,6 +70,119 @@ def se_forward(x, w1, w2):
     return y
 
 
+# ---- gates built from axis reductions: GCModule, CoordinateAttention, TripletAttention, BAM (csrc/axis_attn.hip) ---------------
+def bn_fold(bn, pre_bias=None):
+    """(scale, shift) of an eval-mode BatchNorm, optionally absorbing the bias of the layer in front of it:
+    bn(z + pre_bias) = z * scale + shift.  Cached with the BatchNorm (and the bias) like the other derived tensors."""
+    def build():
+        s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        t = bn.bias.detach() - bn.running_mean.detach() * s
+        if pre_bias is not None:
+            t = t + s * pre_bias.detach().reshape(-1)
+        return s.float().contiguous(), t.float().contiguous()
+
+    anchors = (bn,) if pre_bias is None else (bn, pre_bias)
+    tag = _bn_tag(bn) + (() if pre_bias is None else (pre_bias._version, pre_bias.data_ptr()))
+    return _derived_get(anchors, ("bnfold",), tag, build)
+
+
+def _axis(x):
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    ws = workspace(lib().mi355_axis_attn_workspace_bytes(B, C, H, W), x.device)
+    return x, torch.empty_like(x), ws, (B, C, H, W)
+
+
+def _flat(t, name, *shape):
+    return require_device_f32(t, name).reshape(*shape) if t is not None else None
+
+
+def gc_forward(x, conv_w, conv_b, w1, b1, ln_w, ln_b, ln_eps, w2, b2):
+    x, y, ws, (B, C, H, W) = _axis(x)
+    Cr = w1.shape[0]
+    check(lib().mi355_gc_fwd(dptr(x), dptr(_flat(conv_w, "conv.weight", C)), dptr(_flat(conv_b, "conv.bias", 1)),
+                             dptr(_flat(w1, "transform.0.weight", Cr, C)), dptr(_flat(b1, "transform.0.bias", Cr)),
+                             dptr(_flat(ln_w, "transform.1.weight", Cr)), dptr(_flat(ln_b, "transform.1.bias", Cr)),
+                             dptr(_flat(w2, "transform.3.weight", C, Cr)), dptr(_flat(b2, "transform.3.bias", C)), dptr(y),
+                             B, C, Cr, H, W, float(ln_eps), dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_gc_fwd")
+    return y
+
+
+def coordatt_forward(x, w1, b1, bn_scale, bn_shift, wh, bh, ww, bw):
+    x, y, ws, (B, C, H, W) = _axis(x)
+    hid = w1.shape[0]
+    check(lib().mi355_coordatt_fwd(dptr(x), dptr(_flat(w1, "conv1.weight", hid, C)), dptr(_flat(b1, "conv1.bias", hid)),
+                                   dptr(_flat(bn_scale, "bn1 scale", hid)), dptr(_flat(bn_shift, "bn1 shift", hid)),
+                                   dptr(_flat(wh, "conv_h.weight", C, hid)), dptr(_flat(bh, "conv_h.bias", C)),
+                                   dptr(_flat(ww, "conv_w.weight", C, hid)), dptr(_flat(bw, "conv_w.bias", C)), dptr(y),
+                                   B, C, hid, H, W, dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_coordatt_fwd")
+    return y
+
+
+def triplet_forward(x, w_ch, w_cw, w_hw, affine, ksize):
+    x, y, ws, (B, C, H, W) = _axis(x)
+    n = 2 * ksize * ksize
+    check(lib().mi355_triplet_fwd(dptr(x), dptr(_flat(w_ch, "ch.conv.conv.weight", n)), dptr(_flat(w_cw, "cw.conv.conv.weight", n)),
+                                  dptr(_flat(w_hw, "hw.conv.conv.weight", n)), dptr(_flat(affine, "gate affine", 6)), dptr(y),
+                                  B, C, H, W, int(ksize), dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_triplet_fwd")
+    return y
+
+
+def bam_forward(x, params, Cr, dilation):
+    """`params`: the MI355_BAM_NPARAMS tensors in the order of the enum in include/mi355attn.h."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    if len(params) != 16:
+        raise ValueError("bam_forward: expected 16 parameter tensors")
+    ps = [require_device_f32(t, f"bam parameter {i}") for i, t in enumerate(params)]
+    table = (ctypes.c_void_p * 16)(*[t.data_ptr() for t in ps])
+    ws = workspace(lib().mi355_bam_workspace_bytes(B, C, Cr, H, W), x.device)
+    y = torch.empty_like(x)
+    check(lib().mi355_bam_fwd(dptr(x), ctypes.cast(table, ctypes.c_void_p), dptr(y), B, C, Cr, H, W, int(dilation), dptr(ws), ws.numel(),
+                              stream_ptr(x.device)), "mi355_bam_fwd")
+    return y
+
+
+def sk_forward(x, params, planes, groups, d):
+    """`params`: the MI355_SK_NPARAMS tensors in the order of the enum in include/mi355attn.h."""
+    x = require_device_f32(x, "x")
+    B, Cin, H, W = x.shape
+    if len(params) != 14:
+        raise ValueError("sk_forward: expected 14 parameter tensors")
+    ps = [require_device_f32(t, f"sk parameter {i}") for i, t in enumerate(params)]
+    table = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ps])
+    ws = workspace(lib().mi355_sk_workspace_bytes(B, planes, H, W), x.device)
+    y = torch.empty(B, planes, H, W, dtype=torch.float32, device=x.device)
+    check(lib().mi355_sk_fwd(dptr(x), ctypes.cast(table, ctypes.c_void_p), dptr(y), B, Cin, planes, int(groups), int(d), H, W, dptr(ws),
+                             ws.numel(), stream_ptr(x.device)), "mi355_sk_fwd")
+    return y
+
+
+def cam_forward(x, beta, precision=PREC_STRICT):
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    beta = require_device_f32(beta, "beta").reshape(1)
+    ws = workspace(lib().mi355_cam_workspace_bytes(B, C), x.device)
+    y = torch.empty_like(x)
+    check(lib().mi355_cam_fwd(dptr(x), dptr(beta), dptr(y), B, C, H, W, _prec(precision), dptr(ws), ws.numel(), stream_ptr(x.device)),
+          "mi355_cam_fwd")
+    return y
+
+
+def tokens_to_nchw_axpy(tokens, x, alpha):
+    """y[b,c,h,w] = alpha * tokens[b, h*W + w, c] + x[b,c,h,w]."""
+    x = require_device_f32(x, "x")
+    tokens = require_device_f32(tokens, "tokens")
+    B, C, H, W = x.shape
+    if tuple(tokens.shape) != (B, H * W, C):
+        raise ValueError("tokens_to_nchw_axpy: tokens must be (B, H*W, C)")
+    alpha = require_device_f32(alpha, "alpha").reshape(1)
+    y = torch.empty_like(x)
+    check(lib().mi355_tokens_to_nchw_axpy_fwd(dptr(tokens), dptr(x), dptr(alpha), dptr(y), B, H * W, C, stream_ptr(x.device)),
+          "mi355_tokens_to_nchw_axpy_fwd")
+    return y
+
+
 def se_ex_forward(x, w1, b1, w2, b2, gate="sigmoid"):
     """SE with optional excitation biases and a choice of gate ("sigmoid" | "hard_sigmoid"): the variants inside the reference's CNNs."""
     x = require_device_f32(x, "x")

@@ -8,3 +8,4 @@ from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed
 from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401
 from .mhsa import SRAttention, SRAttentionRelPos, SRConvAttention  # noqa: F401
 from .se_variants import SELayerBias, SELayerHidden, SqueezeExcite  # noqa: F401
+from .axis import BAM, CAM, PAM, CoordinateAttention, GCModule, SKLayer, TripletAttention  # noqa: F401

@@ -89,6 +89,47 @@ CASES = [
     dict(id="gct64_l1", mod="attention_mechanisms.gate_channel_module", cls="GCT", args=(64,), kwargs=dict(mode="l1"),
          shape=(2, 64, 32, 32), prep="perturb_all",
          oracle=lambda x, sd, dt: O.gct_forward(x, sd["alpha"], sd["gamma"], sd["beta"], 1e-5, "l1", False, dt)),
+    # ---- gates from axis reductions (second group): GCModule, CoordinateAttention, TripletAttention, BAM ------------
+    dict(id="gc64", mod="attention_mechanisms.gc_module", cls="GCModule", args=(64,), shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.gc_forward(x, sd, dt)),
+    dict(id="coord64", mod="attention_mechanisms.coordatten", cls="CoordinateAttention", args=(64, 64), shape=(2, 64, 32, 32),
+         small=True, prep="perturb_all", oracle=lambda x, sd, dt: O.coordatt_forward(x, sd, dt)),
+    dict(id="triplet64", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    dict(id="triplet_k5", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", kwargs=dict(kernel_size=5),
+         shape=(2, 48, 20, 28), prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    dict(id="bam64", mod="attention_mechanisms.bam", cls="BAM", args=(64,), shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.bam_forward(x, sd, 4, dt)),
+    dict(id="gc256", mod="attention_mechanisms.gc_module", cls="GCModule", args=(256,), shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.gc_forward(x, sd, dt)),
+    dict(id="coord256", mod="attention_mechanisms.coordatten", cls="CoordinateAttention", args=(256, 256), shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.coordatt_forward(x, sd, dt)),
+    dict(id="coord_ragged", mod="attention_mechanisms.coordatten", cls="CoordinateAttention", args=(40, 40), shape=(3, 40, 13, 70),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.coordatt_forward(x, sd, dt)),
+    dict(id="triplet256", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    dict(id="bam256", mod="attention_mechanisms.bam", cls="BAM", args=(256,), shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.bam_forward(x, sd, 4, dt)),
+    dict(id="gc_ragged", mod="attention_mechanisms.gc_module", cls="GCModule", args=(48,), shape=(3, 48, 7, 9),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.gc_forward(x, sd, dt)),
+    dict(id="bam_ragged", mod="attention_mechanisms.bam", cls="BAM", args=(80,), shape=(3, 80, 9, 11),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.bam_forward(x, sd, 4, dt)),
+    dict(id="triplet_tall", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", kwargs=dict(kernel_size=3),
+         shape=(2, 12, 70, 6), prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    dict(id="sk64", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(64, 64), shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.sk_forward(x, sd, 32, dt)),
+    dict(id="sk256", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(256, 256), shape=(4, 256, 56, 56),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.sk_forward(x, sd, 32, dt)),
+    dict(id="sk_ragged", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(48, 96), kwargs=dict(groups=12),
+         shape=(3, 48, 9, 11), prep="perturb_all", oracle=lambda x, sd, dt: O.sk_forward(x, sd, 12, dt)),
+    dict(id="pam64", mod="attention_mechanisms.dual_attention", cls="PAM", args=(64,), shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.pam_forward(x, sd, dt)),
+    dict(id="pam64_ragged", mod="attention_mechanisms.dual_attention", cls="PAM", args=(64,), shape=(3, 64, 13, 9),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.pam_forward(x, sd, dt)),
+    dict(id="cam64", mod="attention_mechanisms.dual_attention", cls="CAM", shape=(2, 64, 32, 32), small=True,
+         prep="perturb_all", oracle=lambda x, sd, dt: O.cam_forward(x, sd, dt)),
+    dict(id="cam256", mod="attention_mechanisms.dual_attention", cls="CAM", shape=(4, 256, 28, 28),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.cam_forward(x, sd, dt)),
     dict(id="simam256", mod="attention_mechanisms.simam", cls="simam_module", shape=(4, 256, 56, 56),
          oracle=lambda x, sd, dt: O.simam_forward(x, 1e-4, dt)),
     dict(id="srm256", mod="attention_mechanisms.srm", cls="SRM", args=(256,), shape=(4, 256, 56, 56), prep="perturb_all",

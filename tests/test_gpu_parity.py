@@ -19,6 +19,12 @@ pytestmark = pytest.mark.gpu
 
 VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256", "simam64", "srm64", "gctg64", "lct64", "gct64", "gct64_l1",
                "simam256", "srm256", "gctg256", "lct256", "gct256", "se_effnet", "se_mnasnet", "se_mbv3", "se_ghost"}
+# fp32 vector math as well, but with longer dependent chains (convolutions, LayerNorm / BatchNorm of reduced vectors): 3e-5
+VECTOR_CHAINS = {"gc64", "coord64", "triplet64", "triplet_k5", "bam64", "gc256", "coord256", "coord_ragged", "triplet256", "bam256",
+                 "gc_ragged", "bam_ragged", "triplet_tall", "sk64", "sk256", "sk_ragged"}
+# DANet's position attention uses UNSCALED dot-product logits (dual_attention.py:26): operand rounding is amplified by the logit
+# magnitude, so even the split-bf16 mode is only held to the 1e-3 parity tolerance
+UNSCALED_LOGITS = {"pam64", "pam64_ragged"}
 
 
 def _run(c, precision=None):
@@ -44,7 +50,7 @@ def _run(c, precision=None):
 def test_hip_matches_oracle_and_golden(cid, golden):
     c, g = BY_ID[cid], golden[cid]
     y, ref = _run(c)
-    tol = 1e-5 if cid in VECTOR_ONLY else 1e-3
+    tol = 1e-5 if cid in VECTOR_ONLY else (3e-5 if cid in VECTOR_CHAINS else 1e-3)
     assert_parity(y, ref, tol, cid)
     yf = y.reshape(-1)
     samples = torch.tensor(g["samples"], dtype=torch.float64)
@@ -53,7 +59,8 @@ def test_hip_matches_oracle_and_golden(cid, golden):
     assert abs(float(yf.double().sum()) - g["sum"]) <= tol * g["abs_sum"]
 
 
-@pytest.mark.parametrize("cid", [c["id"] for c in CASES if c["id"] not in VECTOR_ONLY and not c.get("slow")])
+@pytest.mark.parametrize("cid", [c["id"] for c in CASES if c["id"] not in VECTOR_ONLY | VECTOR_CHAINS | UNSCALED_LOGITS
+                                 and not c.get("slow")])
 def test_strict_precision_is_fp32_class(cid):
     """precision 0 (3-way split bf16) must land two orders of magnitude inside the tolerance."""
     y, ref = _run(BY_ID[cid], precision=0)
