@@ -172,4 +172,35 @@ def workload_zoo(B, dev):
     return dict(name="SimAM+SRM+GaussianGCT+LCT+GCT fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, gather=None, dtype="f32")
 
 
-WORKLOADS = {"zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}
+def workload_zoo2(B, dev):
+    """GCModule, CoordinateAttention, TripletAttention, BAM, SKLayer, CAM (second group) at the C2 shape.  The gates are
+    HBM-bound (algorithmic bytes = read x + write y); SKLayer's grouped 3x3 branches and CAM's Gram products are counted in FLOPs."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+    from cases import perturb_all
+    from mi355attn.modules import BAM, CAM, CoordinateAttention, GCModule, SKLayer, TripletAttention
+    C, H = 256, 56
+    torch.manual_seed(4321)
+    x = torch.randn(B, C, H, H, device=dev)
+    nbytes = 2.0 * C * H * H * 4
+    sk_flop = 2.0 * 2 * H * H * C * (C // 32) * 9                  # two grouped 3x3 branches
+    cam_flop = 2.0 * 2 * C * C * H * H                             # X X^T and attn X
+    blocks = []
+    for name, ctor, orc, bound, work in (
+            ("GCModule(256)", lambda: GCModule(C), lambda xs, s: O.gc_forward(xs, s), "hbm", nbytes),
+            ("CoordinateAttention(256)", lambda: CoordinateAttention(C, C), lambda xs, s: O.coordatt_forward(xs, s), "hbm", nbytes),
+            ("TripletAttention(7)", lambda: TripletAttention(), lambda xs, s: O.triplet_forward(xs, s), "hbm", nbytes),
+            ("BAM(256)", lambda: BAM(C), lambda xs, s: O.bam_forward(xs, s), "hbm", nbytes),
+            ("SKLayer(256,256)", lambda: SKLayer(C, C), lambda xs, s: O.sk_forward(xs, s), "mfma", sk_flop),
+            ("CAM", lambda: CAM(), lambda xs, s: O.cam_forward(xs, s), "mfma", cam_flop)):
+        m = _seeded(ctor)
+        perturb_all(m)
+        m.eval()
+        sd = _sd(m)
+        cpu = (lambda f, s: (lambda xs: f(xs, s)))(orc, sd)
+        blocks.append(dict(name=name, module=m.to(dev), x=x, bound=bound, work=work * B, cpu=cpu))
+    return dict(name="GC+CoordAtt+Triplet+BAM+SK+CAM fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, gather=None, dtype="f32")
+
+
+WORKLOADS = {"zoo2": workload_zoo2, "zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

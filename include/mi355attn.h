@@ -216,12 +216,27 @@ int mi355_sk_fwd(const float* x, const float* const* params, float* y, int B, in
  * unscaled sums over HW, so precision 0 (fp32-class split-bf16 MFMA) is the mode that meets the parity tolerance.
  * PAM :20-28 is composed by the caller from mi355_conv2d_tokens_fwd (the three 1x1 convs as one token-major GEMM),
  * mi355_sdpa_general_fwd (one head of width C, scale 1) and mi355_tokens_to_nchw_axpy_fwd:
- *   y[b,c,p] = alpha[0] * tokens[b,p,c] + x[b,c,p]      tokens (B,HW,C), x / y (B,C,HW), alpha a 1-element device array. */
+ *   y[b,c,p] = alpha[0] * tokens[b,p,c] + x[b,c,p]      tokens (B,HW,C), x / y (B,C,HW), alpha a 1-element device array;
+ *   alpha == NULL means 1, x == NULL means 0 (a plain token-major -> NCHW transpose). */
 size_t mi355_cam_workspace_bytes(int B, int C);
 int mi355_cam_fwd(const float* x, const float* beta, float* y, int B, int C, int H, int W, int precision, void* workspace,
                   size_t workspace_bytes, mi355_stream_t stream);
 int mi355_tokens_to_nchw_axpy_fwd(const float* tokens, const float* x, const float* alpha, float* y, int B, int HW, int C,
                                   mi355_stream_t stream);
+
+/* ---- glue of the remaining multi-head-attention copies ------------------------------------------------------------
+ * mi355_dwconv_nchw_tokens_fwd: depth-wise ks x ks convolution (stride 1, zero padding (ks-1)/2) of an NCHW map, written token-major:
+ *   y[b, i*W+j, c] = bias[c] + sum_uv weight[c,u,v] * x[b,c,i+u-pad,j+v-pad]     (cvt.py:48-50 with the BatchNorm folded by the caller)
+ * mi355_qk_logits_fwd: unscaled attention logits, logits[b,h,i,j] = q[b,i,h*d:(h+1)*d] . k[b,j,h*d:(h+1)*d]; q (B,Nq,*) / k (B,Nkv,*) fp32
+ *   with row strides ldq / ldk (views into a fused projection), logits (B,heads,Nq,Nkv) fp32.
+ * mi355_topk_mask_fwd: in place on `rows` rows of length N: the k largest entries of a row become 0, all others -1e30 -- the additive
+ *   bias that makes mi355_sdpa_general_fwd the k-NN attention of kvt.py:83-89 (top-k of the scaled logits == top-k of the unscaled
+ *   ones).  N <= 4096. */
+int mi355_dwconv_nchw_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C, int H, int W, int ks,
+                                 mi355_stream_t stream);
+int mi355_qk_logits_fwd(const float* q, const float* k, float* logits, int B, int heads, int Nq, int Nkv, int head_dim, int ldq, int ldk,
+                        int precision, mi355_stream_t stream);
+int mi355_topk_mask_fwd(float* logits, long rows, int N, int k, mi355_stream_t stream);
 
 /* ---- dense building blocks used by the transformer blocks ---------------------------------------- */
 

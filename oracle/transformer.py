@@ -185,3 +185,78 @@ def mhsa_forward(x, p, num_heads, H=None, W=None, sr_ratio=1, relative_pos=None,
         e = torch.exp(s)
         out[..., sl] = (e / e.sum(dim=-1, keepdim=True)) @ v[..., sl]
     return linear(out, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))
+
+
+# ---- the remaining copies of the multi-head pattern: dilateformer, bvit, efficientformer, kvt, cvt, p2t ---------------
+def _heads_attention(q, k, v, scale, topk=None):
+    """softmax(q k^T * scale) v per head; q (B,h,Nq,dq), k (B,h,Nk,dq), v (B,h,Nk,dv).  topk: keep the k largest logits of every row
+    (the rest -> -inf) as kvt.py:84-88 does with topk + scatter + where."""
+    attn = (q @ k.transpose(-1, -2)) * scale
+    if topk is not None:
+        index = torch.topk(attn, k=topk, dim=-1)[1]
+        mask = torch.zeros_like(attn).scatter_(-1, index, 1.0)
+        attn = torch.where(mask > 0, attn, torch.full_like(attn, float("-inf")))
+    return torch.softmax(attn, dim=-1) @ v
+
+
+def global_attention_forward(x, p, num_heads, dtype=torch.float32):
+    """GlobalAttention.forward -- vision_transformers/dilateformer.py:152-164: plain MHSA on a channels-last (B,H,W,C) grid."""
+    x = _t(x, dtype)
+    B, H, W, C = x.shape
+    d = C // num_heads
+    qkv = linear(x.reshape(B, H * W, C), _t(p["qkv.weight"], dtype), _t(p["qkv.bias"], dtype) if "qkv.bias" in p else None)
+    qkv = qkv.reshape(B, H * W, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    o = _heads_attention(qkv[0], qkv[1], qkv[2], d ** -0.5).transpose(1, 2).reshape(B, H, W, C)
+    return linear(o, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))
+
+
+def broad_attention_forward(x, p, heads, dim_head, dtype=torch.float32):
+    """Broad_Attention.forward -- vision_transformers/bvit.py:66-76: returns (to_out(out), q, k, v) with q, k, v as (b, h, n, d)."""
+    x = _t(x, dtype)
+    B, N, _ = x.shape
+    qkv = linear(x, _t(p["to_qkv.weight"], dtype), None).chunk(3, dim=-1)
+    q, k, v = [t.reshape(B, N, heads, dim_head).permute(0, 2, 1, 3) for t in qkv]
+    o = _heads_attention(q, k, v, dim_head ** -0.5).permute(0, 2, 1, 3).reshape(B, N, heads * dim_head)
+    if "to_out.0.weight" in p:
+        o = linear(o, _t(p["to_out.0.weight"], dtype), _t(p["to_out.0.bias"], dtype))
+    return o, q, k, v
+
+
+def qk_v_attention_forward(x, p, query_dim, num_heads, dtype=torch.float32):
+    """Attention.forward -- vision_transformers/efficientformer.py:70-81: q / k of width query_dim / heads, v of width dim / heads."""
+    x = _t(x, dtype)
+    B, N, C = x.shape
+    opt = lambda k: _t(p[k], dtype) if k in p else None
+    qk = linear(x, _t(p["qk.weight"], dtype), opt("qk.bias")).reshape(B, N, 2, num_heads, query_dim // num_heads).permute(2, 0, 3, 1, 4)
+    v = linear(x, _t(p["v.weight"], dtype), opt("v.bias")).reshape(B, N, num_heads, C // num_heads).permute(0, 2, 1, 3)
+    o = _heads_attention(qk[0], qk[1], v, (query_dim // num_heads) ** -0.5).transpose(1, 2).reshape(B, N, C)
+    return linear(o, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))
+
+
+def knn_attention_forward(x, p, num_heads, topk, dtype=torch.float32):
+    """KNNAttention.forward -- vision_transformers/kvt.py:80-94: every query keeps its `topk` largest scaled logits."""
+    x = _t(x, dtype)
+    B, N, C = x.shape
+    d = C // num_heads
+    qkv = linear(x, _t(p["qkv.weight"], dtype), _t(p["qkv.bias"], dtype) if "qkv.bias" in p else None)
+    qkv = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    o = _heads_attention(qkv[0], qkv[1], qkv[2], d ** -0.5, topk=topk).transpose(1, 2).reshape(B, N, C)
+    return linear(o, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))
+
+
+def conv_attention_forward(x, p, num_heads, dtype=torch.float32, bn_eps=1e-5):
+    """Attention.forward -- vision_transformers/cvt.py:64-76: qkv from depth-wise conv -> BatchNorm2d (eval) -> 1x1 conv on an NCHW map,
+    attention over the H*W positions, 1x1 conv projection, NCHW result."""
+    import torch.nn.functional as TF
+    x = _t(x, dtype)
+    B, C, H, W = x.shape
+    d = C // num_heads
+    g = lambda k: _t(p[k], dtype)
+    ks = p["conv_proj_qkv.0.weight"].shape[-1]
+    y = TF.conv2d(x, g("conv_proj_qkv.0.weight"), g("conv_proj_qkv.0.bias"), padding=(ks - 1) // 2, groups=C)
+    y = (y - g("conv_proj_qkv.1.running_mean")[None, :, None, None]) / torch.sqrt(g("conv_proj_qkv.1.running_var")[None, :, None, None] + bn_eps)
+    y = y * g("conv_proj_qkv.1.weight")[None, :, None, None] + g("conv_proj_qkv.1.bias")[None, :, None, None]
+    qkv = TF.conv2d(y, g("conv_proj_qkv.2.weight"), g("conv_proj_qkv.2.bias")).reshape(B, 3, num_heads, d, H * W).permute(1, 0, 2, 4, 3)
+    o = _heads_attention(qkv[0], qkv[1], qkv[2], d ** -0.5)                 # (B, h, N, d)
+    o = o.transpose(-1, -2).reshape(B, C, H, W)
+    return TF.conv2d(o, g("proj.weight"), g("proj.bias"))

@@ -33,36 +33,94 @@ template <int MODE, int KMAX, int VEC>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, int C, long HW, int K) {
     using V = typename PixVec<VEC>::t;
-    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
-    if (p >= HW) return;
+    const long p_raw = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const bool live = p_raw < HW;
+    const long p = live ? p_raw : 0;                             // idle threads shadow pixel 0 (they take part in the LDS staging barrier)
     const int b = blockIdx.y;
     const float* xp = x + (long)b * C * HW + p;
     constexpr int NA = MODE == 0 ? KMAX : 2;
+    constexpr int U = (MODE == 0 && KMAX >= 16) ? 4 : 8;
     V acc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) acc[k] = splat(V{}, (MODE == 1 && k == 1) ? -INFINITY : 0.f);
-    constexpr int U = (MODE == 0 && KMAX >= 16) ? 4 : 8;
-    for (int c = 0; c < C; c += U) {
-        V v[U];
+    // wide outputs: the (K, C) weight is staged transposed in LDS ([c][KMAX], zero rows past K) so that a channel's KMAX weights are
+    // a few broadcast 16-byte reads instead of KMAX strided scalar loads
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    if constexpr (MODE == 0 && KMAX >= 4) {
+        for (int q = threadIdx.x; q < C * KMAX; q += 256) {
+            const int c = q / KMAX, k = q - c * KMAX;
+            wl[q] = k < K ? w[(long)k * C + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    auto sweep = [&](int cbeg, int cend) {                       // channels [cbeg, cend) into acc, U loads in flight
+        for (int c = cbeg; c < cend; c += U) {
+            V v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const V*>(xp + (long)(c + u < C ? c + u : C - 1) * HW);
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const V*>(xp + (long)(c + u < cend ? c + u : cend - 1) * HW);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool in = c + u < C;
-            if constexpr (MODE == 0) {
+            for (int u = 0; u < U; ++u) {
+                const bool in = c + u < cend;
+                if constexpr (MODE == 0 && KMAX >= 4) {
+                    if (in) {
+                        const f4* wr = reinterpret_cast<const f4*>(wl + (c + u) * KMAX);
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const float wk = (k < K && in) ? w[(long)k * C + c + u] : 0.f;
-                    acc[k] += wk * v[u];
+                        for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+                            const f4 wk = wr[k4];
+                            acc[k4 * 4 + 0] += wk.x * v[u]; acc[k4 * 4 + 1] += wk.y * v[u];
+                            acc[k4 * 4 + 2] += wk.z * v[u]; acc[k4 * 4 + 3] += wk.w * v[u];
+                        }
+                    }
+                } else if constexpr (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        const float wk = (k < K && in) ? w[(long)k * C + c + u] : 0.f;
+                        acc[k] += wk * v[u];
+                    }
+                } else {
+                    acc[0] += in ? v[u] : splat(V{}, 0.f);
+                    acc[1] = vmaxf(acc[1], in ? v[u] : splat(V{}, -INFINITY));
                 }
-            } else {
-                acc[0] += in ? v[u] : splat(V{}, 0.f);
-                acc[1] = vmaxf(acc[1], in ? v[u] : splat(V{}, -INFINITY));
             }
         }
+    };
+    if constexpr (KMAX == 1) {
+        // Every image of a batch has the same layout, and C*HW*4 bytes is often a multiple of the HBM channel-interleave period
+        // (256 x 56 x 56 x 4 = 49 x 64 KB), so workgroups sweeping the channels in lock step would all queue on the same few
+        // memory channels.  The channel axis is cut into eight groups and image b starts at group b mod 8; each group is summed in
+        // its own fixed order and the eight partials are combined in a fixed order, so the result does not depend on b.
+        constexpr int G = 8;
+        const int gs = ((C + G - 1) / G + U - 1) / U * U;
+        V part[G][NA];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < NA; ++k) part[g][k] = splat(V{}, (MODE == 1 && k == 1) ? -INFINITY : 0.f);
+        for (int step = 0; step < G; ++step) {
+            const int g = (b + step) & (G - 1);
+            const int cbeg = g * gs, cend = cbeg + gs < C ? cbeg + gs : C;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) acc[k] = splat(V{}, (MODE == 1 && k == 1) ? -INFINITY : 0.f);
+            if (cbeg < cend) sweep(cbeg, cend);
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int k = 0; k < NA; ++k) part[q][k] = q == g ? acc[k] : part[q][k];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (MODE == 1 && k == 1)
+                acc[k] = vmaxf(vmaxf(vmaxf(part[0][k], part[1][k]), vmaxf(part[2][k], part[3][k])),
+                               vmaxf(vmaxf(part[4][k], part[5][k]), vmaxf(part[6][k], part[7][k])));
+            else
+                acc[k] = ((part[0][k] + part[1][k]) + (part[2][k] + part[3][k])) + ((part[4][k] + part[5][k]) + (part[6][k] + part[7][k]));
+        }
+    } else {
+        sweep(0, C);
     }
     const int nout = MODE == 0 ? K : 2;
     float* op = out + (long)b * nout * HW + p;
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         if (k < nout) {
@@ -77,8 +135,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
 template <int MODE, int KMAX>
 void launch_chan_reduce(const float* x, const float* w, const float* bias, float* out, int B, int C, long HW, int K, hipStream_t st) {
     const bool vec = (HW & 3) == 0 && aligned16(x) && aligned16(out);
-    if (vec) chan_reduce_kernel<MODE, KMAX, 4><<<dim3(cdiv(HW / 4, 256), B), 256, 0, st>>>(x, w, bias, out, C, HW, K);
-    else     chan_reduce_kernel<MODE, KMAX, 1><<<dim3(cdiv(HW, 256), B), 256, 0, st>>>(x, w, bias, out, C, HW, K);
+    const size_t lds = (MODE == 0 && KMAX >= 4) ? (size_t)C * KMAX * sizeof(float) : 0;
+    if (vec) chan_reduce_kernel<MODE, KMAX, 4><<<dim3(cdiv(HW / 4, 256), B), 256, lds, st>>>(x, w, bias, out, C, HW, K);
+    else     chan_reduce_kernel<MODE, KMAX, 1><<<dim3(cdiv(HW, 256), B), 256, lds, st>>>(x, w, bias, out, C, HW, K);
 }
 
 // ---- reductions over W (one value per row) and over H (one value per column) of every (image, channel) plane -----------------
@@ -144,13 +203,70 @@ __global__ __launch_bounds__(256) void plane_pool_kernel(const float* __restrict
     }
 }
 
+// The same reductions for planes that fit LDS (H * (W + 1) floats <= 64 KB): one workgroup per plane streams it in with 16-byte
+// loads (a few in flight per thread), parks it in LDS with an odd pitch, then half of the threads reduce rows and the other half
+// columns, both conflict-free.
+template <bool WITH_MAX, int VEC>
+__global__ __launch_bounds__(256) void plane_pool_lds_kernel(const float* __restrict__ x, float* __restrict__ h_mean, float* __restrict__ h_max,
+                                                            float* __restrict__ w_mean, float* __restrict__ w_max, int H, int W) {
+    extern __shared__ float tile[];
+    const long plane = blockIdx.x;
+    const int t = threadIdx.x, pitch = W + 1;
+    const float* xp = x + plane * (long)H * W;
+    if constexpr (VEC == 4) {
+        const int w4 = W >> 2, n4 = H * w4;
+        int row = t / w4, col = t - row * w4;
+        const int drow = 256 / w4, dcol = 256 - drow * w4;
+        for (int i = t; i < n4; i += 256) {
+            const f4 v = *reinterpret_cast<const f4*>(xp + (long)i * 4);
+            float* d = tile + row * pitch + col * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            row += drow; col += dcol;
+            if (col >= w4) { col -= w4; ++row; }
+        }
+    } else {
+        const int n = H * W;
+        int row = t / W, col = t - row * W;
+        const int drow = 256 / W, dcol = 256 - drow * W;
+        for (int i = t; i < n; i += 256) {
+            tile[row * pitch + col] = xp[i];
+            row += drow; col += dcol;
+            if (col >= W) { col -= W; ++row; }
+        }
+    }
+    __syncthreads();
+    if (t < 128) {
+        for (int r = t; r < H; r += 128) {
+            const float* q = tile + r * pitch;
+            float s = 0.f, m = -INFINITY;
+            for (int j = 0; j < W; ++j) { s += q[j]; if constexpr (WITH_MAX) m = fmaxf(m, q[j]); }
+            h_mean[plane * H + r] = s / (float)W;
+            if constexpr (WITH_MAX) h_max[plane * H + r] = m;
+        }
+    } else {
+        for (int j = t - 128; j < W; j += 128) {
+            const float* q = tile + j;
+            float s = 0.f, m = -INFINITY;
+            for (int r = 0; r < H; ++r) { s += q[r * pitch]; if constexpr (WITH_MAX) m = fmaxf(m, q[r * pitch]); }
+            w_mean[plane * W + j] = s / (float)H;
+            if constexpr (WITH_MAX) w_max[plane * W + j] = m;
+        }
+    }
+}
+
 template <bool WITH_MAX>
 int launch_plane_pool(const float* x, float* h_mean, float* h_max, float* w_mean, float* w_max, long planes, int H, int W, hipStream_t st) {
+    const size_t lds = (size_t)H * (W + 1) * sizeof(float);
+    if (lds <= 65536 && planes < (1L << 31)) {
+        if ((W & 3) == 0 && aligned16(x)) plane_pool_lds_kernel<WITH_MAX, 4><<<(int)planes, 256, lds, st>>>(x, h_mean, h_max, w_mean, w_max, H, W);
+        else                              plane_pool_lds_kernel<WITH_MAX, 1><<<(int)planes, 256, lds, st>>>(x, h_mean, h_max, w_mean, w_max, H, W);
+        return MI355_OK;
+    }
     const int grid = cdiv(planes, 4);
     if (W <= 64)       plane_pool_kernel<WITH_MAX, 1><<<grid, 256, 0, st>>>(x, h_mean, h_max, w_mean, w_max, planes, H, W);
     else if (W <= 128) plane_pool_kernel<WITH_MAX, 2><<<grid, 256, 0, st>>>(x, h_mean, h_max, w_mean, w_max, planes, H, W);
     else if (W <= 256) plane_pool_kernel<WITH_MAX, 4><<<grid, 256, 0, st>>>(x, h_mean, h_max, w_mean, w_max, planes, H, W);
-    else return mi355::fail(MI355_EUNSUPPORTED, "axis pooling: W = %d > 256", W);
+    else return mi355::fail(MI355_EUNSUPPORTED, "axis pooling: W = %d > 256 with a plane larger than 64 KB", W);
     return MI355_OK;
 }
 
@@ -166,22 +282,22 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
     float s0 = 0.f, s1 = 0.f;
     if constexpr (VEC == 4) {
         const long n4 = HW >> 2;
-        long q = lane;
-        for (; q + 64 < n4; q += 128) {
-            const f4 a = *reinterpret_cast<const f4*>(xp + q * 4), b = *reinterpret_cast<const f4*>(xp + (q + 64) * 4);
-            if (vp) {
-                const f4 u = *reinterpret_cast<const f4*>(vp + q * 4), w = *reinterpret_cast<const f4*>(vp + (q + 64) * 4);
-                s0 += a.x * u.x + a.y * u.y + a.z * u.z + a.w * u.w;
-                s1 += b.x * w.x + b.y * w.y + b.z * w.z + b.w * w.w;
-            } else {
-                s0 += (a.x + a.y) + (a.z + a.w);
-                s1 += (b.x + b.y) + (b.z + b.w);
+        for (long q0 = lane; q0 < n4; q0 += 256) {               // four 16-byte loads of x (and of v) in flight per lane
+            f4 a[4], u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long q = q0 + 64 * k < n4 ? q0 + 64 * k : q0;
+                a[k] = *reinterpret_cast<const f4*>(xp + q * 4);
+                if (vp) u[k] = *reinterpret_cast<const f4*>(vp + q * 4);
             }
-        }
-        for (; q < n4; q += 64) {
-            const f4 a = *reinterpret_cast<const f4*>(xp + q * 4);
-            if (vp) { const f4 u = *reinterpret_cast<const f4*>(vp + q * 4); s0 += a.x * u.x + a.y * u.y + a.z * u.z + a.w * u.w; }
-            else s0 += (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (q0 + 64 * k < n4) {
+                    const float d = vp ? a[k].x * u[k].x + a[k].y * u[k].y + a[k].z * u[k].z + a[k].w * u[k].w
+                                       : (a[k].x + a[k].y) + (a[k].z + a[k].w);
+                    if (k & 1) s1 += d; else s0 += d;
+                }
+            }
         }
     } else {
         for (long q = lane; q < HW; q += 64) s0 += vp ? xp[q] * vp[q] : xp[q];
@@ -243,6 +359,8 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     else yp[0] = yv[0];
 }
 
+// One element group per thread and nothing else: measured 6.4 TB/s of combined read + write at the C2 shape, above the float4 copy
+// yardstick; a wave-per-plane variant with four loads in flight per lane and no integer divisions was 12 % slower.
 template <int MODE>
 void launch_apply(ApplyArgs g, int B, hipStream_t st) {
     const long n = (long)B * g.C * g.H * g.W;
@@ -296,8 +414,22 @@ __global__ __launch_bounds__(256) void coord_mlp_kernel(const float* __restrict_
     const int ld = on_h ? H : W;
     for (int k = wave; k < hid; k += 4) {
         float s = b1 ? b1[k] : 0.f;
-        if (valid)
-            for (int c = 0; c < C; ++c) s = __builtin_fmaf(w1[(long)k * C + c], src[(long)c * ld], s);
+        if (valid) {
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int c = 0;
+            for (; c + 8 <= C; c += 8) {                         // eight independent loads in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long)(c + u) * ld];
+                const float* wr = w1 + (long)k * C + c;
+                s = __builtin_fmaf(wr[0], v[0], s);   s1 = __builtin_fmaf(wr[1], v[1], s1);
+                s2 = __builtin_fmaf(wr[2], v[2], s2); s3 = __builtin_fmaf(wr[3], v[3], s3);
+                s = __builtin_fmaf(wr[4], v[4], s);   s1 = __builtin_fmaf(wr[5], v[5], s1);
+                s2 = __builtin_fmaf(wr[6], v[6], s2); s3 = __builtin_fmaf(wr[7], v[7], s3);
+            }
+            for (; c < C; ++c) s = __builtin_fmaf(w1[(long)k * C + c], src[(long)c * ld], s);
+            s = (s + s1) + (s2 + s3);
+        }
         hl[k * 64 + lane] = fmaxf(s * bn_s[k] + bn_t[k], 0.f);
     }
     __syncthreads();
@@ -314,29 +446,54 @@ __global__ __launch_bounds__(256) void coord_mlp_kernel(const float* __restrict_
 
 // ---- TripletAttention's AttentionGate on a pooled 2-plane map: sigmoid(relu(bn(conv_kxk([mean, max])))) ---------------------------
 // in0 / in1: (B, R, S) planes with batch stride `bs`; w: (2, k, k); aff[0] = folded scale, aff[1] = folded shift (conv bias included).
+template <int KS>
 __global__ __launch_bounds__(256) void gate_conv_kernel(const float* __restrict__ in0, const float* __restrict__ in1, long bs, const float* __restrict__ w,
-                                                       const float* __restrict__ aff, float* __restrict__ out, int R, int S, int k) {
+                                                       const float* __restrict__ aff, float* __restrict__ out, int R, int S, int kdyn) {
+    // a thread computes four consecutive outputs of one row: per input row it loads the k + 3 values under the sliding window once
+    constexpr int KMAXW = KS > 0 ? KS : 15;
+    const int k = KS > 0 ? KS : kdyn;
     __shared__ float wl[2 * 15 * 15];
     for (int q = threadIdx.x; q < 2 * k * k; q += 256) wl[q] = w[q];
     __syncthreads();
+    const int s4 = (S + 3) >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long RS = (long)R * S;
-    if (idx >= RS) return;
-    const int b = blockIdx.y, r = (int)(idx / S), s = (int)(idx - (long)r * S), pad = (k - 1) / 2;
+    if (idx >= (long)R * s4) return;
+    const int b = blockIdx.y, r = (int)(idx / s4), s0 = (int)(idx - (long)r * s4) * 4, pad = (k - 1) / 2;
     const float* p0 = in0 + (long)b * bs;
     const float* p1 = in1 + (long)b * bs;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int u = 0; u < k; ++u) {
         const int rr = r + u - pad;
         if (rr < 0 || rr >= R) continue;
-        for (int v = 0; v < k; ++v) {
-            const int ss = s + v - pad;
-            if (ss < 0 || ss >= S) continue;
-            acc = __builtin_fmaf(wl[u * k + v], p0[(long)rr * S + ss], acc);
-            acc = __builtin_fmaf(wl[k * k + u * k + v], p1[(long)rr * S + ss], acc);
+        float a[KMAXW + 3], m[KMAXW + 3];
+#pragma unroll
+        for (int q = 0; q < KMAXW + 3; ++q) {
+            const int ss = s0 + q - pad;
+            const bool in = q < k + 3 && ss >= 0 && ss < S;
+            a[q] = in ? p0[(long)rr * S + ss] : 0.f;
+            m[q] = in ? p1[(long)rr * S + ss] : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < KMAXW; ++v) {
+            if (v < k) {
+                const float w0 = wl[u * k + v], w1 = wl[k * k + u * k + v];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(w1, m[v + e], __builtin_fmaf(w0, a[v + e], acc[e]));
+            }
         }
     }
-    out[(long)b * RS + idx] = sigmoidf_(fmaxf(acc * aff[0] + aff[1], 0.f));
+    float* op = out + (long)b * R * S + (long)r * S + s0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (s0 + e < S) op[e] = sigmoidf_(fmaxf(acc[e] * aff[0] + aff[1], 0.f));
+}
+
+void launch_gate_conv(const float* in0, const float* in1, long bs, const float* w, const float* aff, float* out, int B, int R, int S, int k,
+                      hipStream_t st) {
+    const dim3 grid(cdiv((long)R * ((S + 3) >> 2), 256), B);
+    if (k == 7)      gate_conv_kernel<7><<<grid, 256, 0, st>>>(in0, in1, bs, w, aff, out, R, S, k);
+    else if (k == 3) gate_conv_kernel<3><<<grid, 256, 0, st>>>(in0, in1, bs, w, aff, out, R, S, k);
+    else             gate_conv_kernel<0><<<grid, 256, 0, st>>>(in0, in1, bs, w, aff, out, R, S, k);
 }
 
 // ---- BAM ---------------------------------------------------------------------------------------------------------------------
@@ -362,11 +519,18 @@ __global__ __launch_bounds__(256) void bam_channel_kernel(const float* __restric
 }
 
 // dilated 3x3 convolution Cr -> Cr (zero padding = dilation) + folded affine + ReLU on (B, Cr, H, W).  One thread computes all
-// CMAX >= Cr output channels of four consecutive pixels, so that every (wave-uniform, scalar-loaded) weight feeds four FMAs.
+// CMAX >= Cr output channels of four (two for CMAX = 32) consecutive pixels; the weights sit in LDS as [ci][tap][CMAX] and come in
+// as broadcast 16-byte reads.
 template <int CMAX>
 __global__ __launch_bounds__(256) void small_conv_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, float* __restrict__ out, int Cr, int H, int W, int dil) {
-    constexpr int PIX = 4;
+    constexpr int PIX = CMAX >= 32 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [ci][3][3][CMAX], zero past Cr
+    for (int q = threadIdx.x; q < Cr * 9 * CMAX; q += 256) {
+        const int o = q % CMAX, tap = (q / CMAX) % 9, ci = q / (CMAX * 9);
+        wl[q] = o < Cr ? w[((long)o * Cr + ci) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
     const long HW = (long)H * W;
     const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * PIX;
     if (p0 >= HW) return;
@@ -394,13 +558,18 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const float* __restrict
                     const int ii = pi[e] + (u - 1) * dil, jj = pj[e] + (v - 1) * dil;
                     xv[e] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? ip[(long)ci * HW + (long)ii * W + jj] : 0.f;
                 }
+                const f4* wr = reinterpret_cast<const f4*>(wl + ((ci * 3 + u) * 3 + v) * CMAX);
 #pragma unroll
-                for (int o = 0; o < CMAX; ++o)
-                    if (o < Cr) {
-                        const float wk = w[(((long)o * Cr + ci) * 3 + u) * 3 + v];
+                for (int o4 = 0; o4 < CMAX / 4; ++o4) {
+                    const f4 wk = wr[o4];
 #pragma unroll
-                        for (int e = 0; e < PIX; ++e) acc[o][e] = __builtin_fmaf(wk, xv[e], acc[o][e]);
+                    for (int e = 0; e < PIX; ++e) {
+                        acc[o4 * 4 + 0][e] = __builtin_fmaf(wk.x, xv[e], acc[o4 * 4 + 0][e]);
+                        acc[o4 * 4 + 1][e] = __builtin_fmaf(wk.y, xv[e], acc[o4 * 4 + 1][e]);
+                        acc[o4 * 4 + 2][e] = __builtin_fmaf(wk.z, xv[e], acc[o4 * 4 + 2][e]);
+                        acc[o4 * 4 + 3][e] = __builtin_fmaf(wk.w, xv[e], acc[o4 * 4 + 3][e]);
                     }
+                }
             }
         }
     }
@@ -493,9 +662,9 @@ int mi355_triplet_fwd(const float* x, const float* w_ch, const float* w_cw, cons
     const int rc = launch_plane_pool<true>(x, h_mean, h_max, w_mean, w_max, (long)bc, H, W, st);
     if (rc != MI355_OK) return rc;
     launch_chan_reduce<1, 1>(x, nullptr, nullptr, zp, B, C, HW, 2, st);
-    gate_conv_kernel<<<dim3(cdiv((long)C * H, 256), B), 256, 0, st>>>(h_mean, h_max, (long)C * H, w_ch, affine + 0, s_ch, C, H, ksize);
-    gate_conv_kernel<<<dim3(cdiv((long)C * W, 256), B), 256, 0, st>>>(w_mean, w_max, (long)C * W, w_cw, affine + 2, s_cw, C, W, ksize);
-    gate_conv_kernel<<<dim3(cdiv(HW, 256), B), 256, 0, st>>>(zp, zp + HW, 2 * HW, w_hw, affine + 4, s_hw, H, W, ksize);
+    launch_gate_conv(h_mean, h_max, (long)C * H, w_ch, affine + 0, s_ch, B, C, H, ksize, st);
+    launch_gate_conv(w_mean, w_max, (long)C * W, w_cw, affine + 2, s_cw, B, C, W, ksize, st);
+    launch_gate_conv(zp, zp + HW, 2 * HW, w_hw, affine + 4, s_hw, B, H, W, ksize, st);
     ApplyArgs g{};
     g.x = x; g.y = y; g.a = s_ch; g.b = s_cw; g.c = s_hw; g.C = C; g.H = H; g.W = W;
     launch_apply<AP_TRIPLET>(g, B, st);
@@ -515,6 +684,11 @@ int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C,
     for (int q = 0; q < MI355_BAM_NPARAMS; ++q) MI355_CHECK_ARG(p[q] != nullptr);
     MI355_CHECK_ARG(workspace_bytes >= mi355_bam_workspace_bytes(B, C, Cr, H, W) && aligned16(workspace));
     if (Cr > 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: reduced width %d > 32", Cr);
+    {
+        const int kmax = Cr <= 4 ? 4 : (Cr <= 8 ? 8 : (Cr <= 16 ? 16 : 32));
+        if ((size_t)C * kmax * sizeof(float) > 65536)
+            return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: C = %d with reduced width %d exceeds the 64 KB weight stage", C, Cr);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long HW = (long)H * W;
     float* ws = static_cast<float*>(workspace);
@@ -533,11 +707,11 @@ int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C,
 #define RED(K_) launch_chan_reduce<0, K_>(x, p[MI355_BAM_CONV1_W], p[MI355_BAM_CONV1_B], t0, B, C, HW, Cr, st)
     CR_DISPATCH(RED);
 #undef RED
-    const dim3 grid(cdiv(cdiv(HW, 4), 256), B);
-#define SC1(K_) small_conv_kernel<K_><<<grid, 256, 0, st>>>(t0, p[MI355_BAM_DCONV1_W], p[MI355_BAM_DCONV1_SCALE], p[MI355_BAM_DCONV1_SHIFT], t1, Cr, H, W, dilation)
+    const dim3 grid(cdiv(cdiv(HW, Cr > 16 ? 2 : 4), 256), B);
+#define SC1(K_) small_conv_kernel<K_><<<grid, 256, (size_t)Cr * 9 * K_ * sizeof(float), st>>>(t0, p[MI355_BAM_DCONV1_W], p[MI355_BAM_DCONV1_SCALE], p[MI355_BAM_DCONV1_SHIFT], t1, Cr, H, W, dilation)
     CR_DISPATCH(SC1);
 #undef SC1
-#define SC2(K_) small_conv_kernel<K_><<<grid, 256, 0, st>>>(t1, p[MI355_BAM_DCONV2_W], p[MI355_BAM_DCONV2_SCALE], p[MI355_BAM_DCONV2_SHIFT], t0, Cr, H, W, dilation)
+#define SC2(K_) small_conv_kernel<K_><<<grid, 256, (size_t)Cr * 9 * K_ * sizeof(float), st>>>(t1, p[MI355_BAM_DCONV2_W], p[MI355_BAM_DCONV2_SCALE], p[MI355_BAM_DCONV2_SHIFT], t0, Cr, H, W, dilation)
     CR_DISPATCH(SC2);
 #undef SC2
 #undef CR_DISPATCH

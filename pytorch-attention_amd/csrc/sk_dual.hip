@@ -90,17 +90,118 @@ __global__ __launch_bounds__(256) void sk_branch_kernel(const float* __restrict_
     if (t < COG) pooled[(long)b * planes + co0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
+// The same two branches with the group's input staged in LDS: a workgroup owns (group, band of BR rows, image), parks the cin_g input
+// planes of the band with a zero halo of two (rows and columns; row pitch PW = W + 4 rounded to 4) and the group's weights as
+// [ci][tap][branch][COG]; a thread computes four horizontally adjacent pixels of both branches from five 8-float row windows
+// per input channel (two aligned 16-byte LDS reads each: columns j-2 .. j+5 cover the taps of both dilations).  No bounds checks and
+// no global address arithmetic in the FMA loop.  pooled_part[(b, channel, band)] holds the band's share of sum_hw (u1 + u2).
+template <int COG>
+__global__ __launch_bounds__(256) void sk_branch_lds_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ sc1,
+                                                           const float* __restrict__ sh1, const float* __restrict__ w2, const float* __restrict__ sc2,
+                                                           const float* __restrict__ sh2, float* __restrict__ u1, float* __restrict__ u2,
+                                                           float* __restrict__ pooled_part, int Cin, int planes, int cin_g, int H, int W, int BR,
+                                                           int PW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[4][COG];
+    const int g = blockIdx.x, band = blockIdx.y, nb = gridDim.y, b = blockIdx.z, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = band * BR, TS = (BR + 4) * PW;                // tile stride per input channel
+    float* tile = lds;                                           // cin_g * TS
+    float* wl = lds + cin_g * TS;                                // cin_g * 9 * 2 * COG
+    const long HW = (long)H * W;
+    const float* xg = x + ((long)b * Cin + (long)g * cin_g) * HW;
+    const int co0 = g * COG, w4 = W >> 2;
+    for (int q = t; q < cin_g * TS; q += 256) tile[q] = 0.f;
+    for (int q = t; q < cin_g * 9 * 2 * COG; q += 256) {
+        const int o = q % COG, br = (q / COG) & 1, tap = (q / (2 * COG)) % 9, ci = q / (18 * COG);
+        wl[q] = (br ? w2 : w1)[((long)(co0 + o) * cin_g + ci) * 9 + tap];
+    }
+    __syncthreads();
+    for (int q = t; q < cin_g * (BR + 4) * w4; q += 256) {
+        const int c4 = q % w4, rr = (q / w4) % (BR + 4), ci = q / (w4 * (BR + 4));
+        const int i = i0 - 2 + rr;
+        if (i >= 0 && i < H) {
+            const f4 v = *reinterpret_cast<const f4*>(xg + (long)ci * HW + (long)i * W + c4 * 4);
+            float* d = tile + ci * TS + rr * PW + 2 + c4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    float psum[COG];
+#pragma unroll
+    for (int o = 0; o < COG; ++o) psum[o] = 0.f;
+    for (int item = t; item < BR * w4; item += 256) {
+        const int r = item / w4, c4 = item - r * w4, i = i0 + r;
+        if (i >= H) continue;
+        float a1[COG][4], a2[COG][4];
+#pragma unroll
+        for (int o = 0; o < COG; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a1[o][e] = 0.f; a2[o][e] = 0.f; }
+        for (int ci = 0; ci < cin_g; ++ci) {
+            const float* tp = tile + ci * TS + r * PW + c4 * 4;
+            float f[5][8];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const f4 lo = *reinterpret_cast<const f4*>(tp + k * PW), hi = *reinterpret_cast<const f4*>(tp + k * PW + 4);
+                f[k][0] = lo.x; f[k][1] = lo.y; f[k][2] = lo.z; f[k][3] = lo.w;
+                f[k][4] = hi.x; f[k][5] = hi.y; f[k][6] = hi.z; f[k][7] = hi.w;
+            }
+            const float* wc = wl + ci * 18 * COG;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const float* wt = wc + (u * 3 + v) * 2 * COG;
+#pragma unroll
+                    for (int o = 0; o < COG; ++o) {
+                        const float wa = wt[o], wb = wt[COG + o];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a1[o][e] = __builtin_fmaf(wa, f[1 + u][e + 1 + v], a1[o][e]);        // dilation 1: rows i-1..i+1, cols j-1..j+1
+                            a2[o][e] = __builtin_fmaf(wb, f[2 * u][e + 2 * v], a2[o][e]);        // dilation 2: rows i-2..i+2, cols j-2..j+2
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < COG; ++o) {
+            const float s1 = sc1[co0 + o], t1 = sh1[co0 + o], s2 = sc2[co0 + o], t2 = sh2[co0 + o];
+            const long off = ((long)b * planes + co0 + o) * HW + (long)i * W + c4 * 4;
+            f4 r1, r2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r1[e] = fmaxf(a1[o][e] * s1 + t1, 0.f); r2[e] = fmaxf(a2[o][e] * s2 + t2, 0.f); }
+            *reinterpret_cast<f4*>(u1 + off) = r1;
+            *reinterpret_cast<f4*>(u2 + off) = r2;
+            psum[o] += ((r1.x + r2.x) + (r1.y + r2.y)) + ((r1.z + r2.z) + (r1.w + r2.w));
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COG; ++o) {
+        const float s = wave_sum(psum[o]);
+        if (lane == 0) red[wave][o] = s;
+    }
+    __syncthreads();
+    if (t < COG) pooled_part[((long)b * planes + co0 + t) * nb + band] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
 // fc -> BatchNorm1d (folded) -> ReLU -> fc1 / fc2 -> softmax over the two branches; one workgroup per image.  att: (B, 2, planes)
 __global__ __launch_bounds__(256) void sk_select_kernel(const float* __restrict__ pooled, const float* __restrict__ wf, const float* __restrict__ bf,
                                                        const float* __restrict__ bn_s, const float* __restrict__ bn_t, const float* __restrict__ wa,
                                                        const float* __restrict__ ba, const float* __restrict__ wb, const float* __restrict__ bb,
-                                                       float* __restrict__ att, int planes, int d, float inv_hw) {
-    extern __shared__ float z[];                                 // d
+                                                       float* __restrict__ att, int planes, int d, float inv_hw, int nb) {
+    extern __shared__ float z[];                                 // d | planes
+    float* s = z + d;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
-    const float* s = pooled + (long)b * planes;
+    for (int c = t; c < planes; c += 256) {                      // the bands' shares of the pooled sum, added in band order
+        const float* pp = pooled + ((long)b * planes + c) * nb;
+        float acc = 0.f;
+        for (int q = 0; q < nb; ++q) acc += pp[q];
+        s[c] = acc * inv_hw;
+    }
+    __syncthreads();
     for (int k = wave; k < d; k += 4) {
         float acc = 0.f;
-        for (int c = lane; c < planes; c += 64) acc = __builtin_fmaf(wf[(long)k * planes + c], s[c] * inv_hw, acc);
+        for (int c = lane; c < planes; c += 64) acc = __builtin_fmaf(wf[(long)k * planes + c], s[c], acc);
         acc = wave_sum(acc);
         if (lane == 0) z[k] = fmaxf((acc + bf[k]) * bn_s[k] + bn_t[k], 0.f);
     }
@@ -164,14 +265,14 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_axpy_kernel(const float* _
         tile[ty + r * 8][tx] = (p < HW && c < C) ? tb[p * C + c] : 0.f;
     }
     __syncthreads();
-    const float a = alpha[0];
+    const float a = alpha ? alpha[0] : 1.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + ty + r * 8;
         const long p = p0 + tx;
         if (c < C && p < HW) {
             const long o = ((long)b * C + c) * HW + p;
-            y[o] = a * tile[tx][ty + r * 8] + x[o];
+            y[o] = a * tile[tx][ty + r * 8] + (x ? x[o] : 0.f);
         }
     }
 }
@@ -184,7 +285,7 @@ extern "C" {
 
 size_t mi355_sk_workspace_bytes(int B, int planes, int H, int W) {
     if (B <= 0 || planes <= 0 || H <= 0 || W <= 0) return 0;
-    return 4 * (2 * fl((size_t)B * planes * H * W) + fl((size_t)B * planes) + fl((size_t)B * 2 * planes)) + 256;
+    return 4 * (2 * fl((size_t)B * planes * H * W) + fl((size_t)B * planes * H) + fl((size_t)B * 2 * planes)) + 256;
 }
 
 int mi355_sk_fwd(const float* x, const float* const* p, float* y, int B, int Cin, int planes, int groups, int d, int H, int W,
@@ -196,30 +297,59 @@ int mi355_sk_fwd(const float* x, const float* const* p, float* y, int B, int Cin
     const int cog = planes / groups, cin_g = Cin / groups;
     if (cog != 1 && cog != 2 && cog != 4 && cog != 8 && cog != 16)
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_sk_fwd: planes / groups = %d not in {1,2,4,8,16}", cog);
-    if (d > 8192) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sk_fwd: d = %d > 8192", d);
+    if (d + planes > 12288) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sk_fwd: d + planes = %d > 12288", d + planes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long HW = (long)H * W;
     float* ws = static_cast<float*>(workspace);
     float* u1 = ws;                                            // split_3x3(x): sk_module.py:43
     float* u2 = u1 + fl((size_t)B * planes * HW);              // split_5x5(x): :44
     float* pooled = u2 + fl((size_t)B * planes * HW);          // sum_hw (u1 + u2): :45-46
-    float* att = pooled + fl((size_t)B * planes);              // softmax over the branches: :48-50
-    const dim3 grid(groups, B);
+    float* att = pooled + fl((size_t)B * planes * H);          // softmax over the branches: :48-50
+    // LDS-tiled kernel when W % 4 == 0 and a band of >= 1 rows of the group's input (+ halo) fits 48 KB; bands are balanced
+    int nb = 1;
+    const int PW = (W + 4 + 3) & ~3;
+    const size_t wbytes = (size_t)cin_g * 18 * cog * sizeof(float);
+    const size_t row_bytes = (size_t)cin_g * PW * sizeof(float);
+    const long max_rows = ((long)49152 - (long)wbytes) / (long)row_bytes - 4;
+    const bool tiled = (W & 3) == 0 && aligned16(x) && aligned16(u1) && max_rows >= 1 && cog <= 8 && B <= 65535;
+    if (tiled) {
+        int brmax = max_rows < H ? (int)max_rows : H;
+        const int fill = 256 / (W >> 2);                          // rows that one pass of the 256 threads covers (a thread = 4 pixels)
+        if (fill >= 1 && brmax > fill) brmax = fill;
+        nb = cdiv(H, brmax);
+        const int BR = cdiv(H, nb);
+        nb = cdiv(H, BR);
+        const size_t lds = (size_t)cin_g * (BR + 4) * PW * sizeof(float) + wbytes;
+        const dim3 tgrid(groups, nb, B);
+#define SKT(COG_)                                                                                                                    \
+    sk_branch_lds_kernel<COG_><<<tgrid, 256, lds, st>>>(x, p[MI355_SK_CONV3_W], p[MI355_SK_CONV3_SCALE], p[MI355_SK_CONV3_SHIFT],    \
+                                                        p[MI355_SK_CONV5_W], p[MI355_SK_CONV5_SCALE], p[MI355_SK_CONV5_SHIFT], u1, u2, \
+                                                        pooled, Cin, planes, cin_g, H, W, BR, PW)
+        switch (cog) {
+            case 1: SKT(1); break;
+            case 2: SKT(2); break;
+            case 4: SKT(4); break;
+            default: SKT(8); break;
+        }
+#undef SKT
+    } else {
+        const dim3 grid(groups, B);
 #define SKB(COG_, PIX_)                                                                                                             \
     sk_branch_kernel<COG_, PIX_><<<grid, 256, 0, st>>>(x, p[MI355_SK_CONV3_W], p[MI355_SK_CONV3_SCALE], p[MI355_SK_CONV3_SHIFT],   \
                                                        p[MI355_SK_CONV5_W], p[MI355_SK_CONV5_SCALE], p[MI355_SK_CONV5_SHIFT], u1, u2, \
                                                        pooled, Cin, planes, cin_g, H, W)
-    switch (cog) {
-        case 1: SKB(1, 4); break;
-        case 2: SKB(2, 4); break;
-        case 4: SKB(4, 4); break;
-        case 8: SKB(8, 4); break;
-        default: SKB(16, 2); break;
-    }
+        switch (cog) {
+            case 1: SKB(1, 4); break;
+            case 2: SKB(2, 4); break;
+            case 4: SKB(4, 4); break;
+            case 8: SKB(8, 4); break;
+            default: SKB(16, 2); break;
+        }
 #undef SKB
-    sk_select_kernel<<<B, 256, d * sizeof(float), st>>>(pooled, p[MI355_SK_FC_W], p[MI355_SK_FC_B], p[MI355_SK_FC_BN_SCALE], p[MI355_SK_FC_BN_SHIFT],
-                                                        p[MI355_SK_FC1_W], p[MI355_SK_FC1_B], p[MI355_SK_FC2_W], p[MI355_SK_FC2_B], att, planes, d,
-                                                        1.0f / (float)HW);
+    }
+    sk_select_kernel<<<B, 256, (size_t)(d + planes) * sizeof(float), st>>>(pooled, p[MI355_SK_FC_W], p[MI355_SK_FC_B], p[MI355_SK_FC_BN_SCALE],
+                                                                          p[MI355_SK_FC_BN_SHIFT], p[MI355_SK_FC1_W], p[MI355_SK_FC1_B], p[MI355_SK_FC2_W],
+                                                                          p[MI355_SK_FC2_B], att, planes, d, 1.0f / (float)HW, nb);
     const long n = (long)B * planes * HW;
     if ((HW & 3) == 0 && aligned16(y)) sk_apply_kernel<4><<<cdiv(n / 4, 256), 256, 0, st>>>(u1, u2, att, y, n / 4, HW, planes);
     else                               sk_apply_kernel<1><<<cdiv(n, 256), 256, 0, st>>>(u1, u2, att, y, n, HW, planes);
@@ -251,7 +381,7 @@ int mi355_cam_fwd(const float* x, const float* beta, float* y, int B, int C, int
 
 int mi355_tokens_to_nchw_axpy_fwd(const float* tokens, const float* x, const float* alpha, float* y, int B, int HW, int C,
                                   mi355_stream_t stream) {
-    MI355_CHECK_ARG(tokens && x && alpha && y && B > 0 && HW > 0 && C > 0 && B <= 65535);
+    MI355_CHECK_ARG(tokens && y && B > 0 && HW > 0 && C > 0 && B <= 65535);
     tokens_to_nchw_axpy_kernel<<<dim3(cdiv(HW, 32), cdiv(C, 32), B), 256, 0, static_cast<hipStream_t>(stream)>>>(tokens, x, alpha, y, HW, C);
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -79,6 +79,9 @@ SIGNATURES = {
     "mi355_cam_workspace_bytes": (ctypes.c_size_t, [c_int] * 2),
     "mi355_cam_fwd": (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
     "mi355_tokens_to_nchw_axpy_fwd": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
+    "mi355_dwconv_nchw_tokens_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),
+    "mi355_qk_logits_fwd": (c_int, [c_vp] * 3 + [c_int] * 8 + [c_vp]),
+    "mi355_topk_mask_fwd": (c_int, [c_vp, ctypes.c_long, c_int, c_int, c_vp]),
     "mi355_mlp_fused_fwd": (c_int, [c_vp] * 7 + [ctypes.c_long, c_int, c_int, c_int, ctypes.c_float, c_int, c_vp]),
     "mi355_sdpa_general_fwd": (c_int, [c_vp] * 5 + [c_int] * 5 + [ctypes.c_long] * 5 + [ctypes.c_float, c_int, c_int, c_vp]),
     "mi355_dwconv_patch_tokens_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),

@@ -756,6 +756,93 @@ def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None):
     return out
 
 
+def tokens_to_nchw(tokens, H, W):
+    """(B, H*W, C) -> (B, C, H, W)."""
+    tokens = require_device_f32(tokens, "tokens")
+    B, L, C = tokens.shape
+    if L != H * W:
+        raise ValueError("tokens_to_nchw: token count does not match (H, W)")
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=tokens.device)
+    check(lib().mi355_tokens_to_nchw_axpy_fwd(dptr(tokens), dptr(None), dptr(None), dptr(y), B, L, C, stream_ptr(tokens.device)),
+          "mi355_tokens_to_nchw_axpy_fwd")
+    return y
+
+
+def dwconv_bn_nchw_tokens(x, conv_w, conv_b, bn):
+    """Depth-wise conv (stride 1, 'same' padding) + eval BatchNorm2d of an NCHW map, written token-major (B, H*W, C); conv bias and
+    BatchNorm are folded into one weight / bias pair, cached per version."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    ks = conv_w.shape[-1]
+
+    def build():
+        s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        cb = conv_b.detach() if conv_b is not None else torch.zeros_like(s)
+        return (conv_w.detach().reshape(C, ks * ks) * s[:, None]).contiguous(), ((cb - bn.running_mean.detach()) * s + bn.bias.detach()).contiguous()
+
+    tag = ((conv_w._version, conv_w.data_ptr()),) + _bn_tag(bn) + ((conv_b._version, conv_b.data_ptr()) if conv_b is not None else ())
+    w, b = _derived_get((conv_w, bn), ("dwbn_nchw",), tag, build)
+    y = torch.empty(B, H * W, C, dtype=torch.float32, device=x.device)
+    check(lib().mi355_dwconv_nchw_tokens_fwd(dptr(x), dptr(w), dptr(b), dptr(y), B, C, H, W, ks, stream_ptr(x.device)),
+          "mi355_dwconv_nchw_tokens_fwd")
+    return y
+
+
+def qk_logits(q, k, num_heads, precision=PREC_STRICT):
+    """Unscaled logits (B, heads, Nq, Nkv) of (B,Nq,C) queries against (B,Nkv,C) keys (views into fused projections welcome)."""
+    q, ldq = _rows3(q, "q")
+    k, ldk = _rows3(k, "k")
+    B, Nq, C = q.shape
+    Nkv = k.shape[1]
+    if q.dtype != torch.float32 or k.dtype != torch.float32:
+        raise TypeError("qk_logits: fp32 tensors expected")
+    out = torch.empty(B, num_heads, Nq, Nkv, dtype=torch.float32, device=q.device)
+    check(lib().mi355_qk_logits_fwd(dptr(q), dptr(k), dptr(out), B, num_heads, Nq, Nkv, C // num_heads, ldq, ldk, _prec(precision),
+                                    stream_ptr(q.device)), "mi355_qk_logits_fwd")
+    return out
+
+
+def topk_mask_(logits, k):
+    """In place: the k largest entries of every last-axis row -> 0, the others -> -1e30 (an additive attention bias)."""
+    logits = require_device_f32(logits, "logits")
+    N = logits.shape[-1]
+    check(lib().mi355_topk_mask_fwd(dptr(logits), logits.numel() // N, N, int(k), stream_ptr(logits.device)), "mi355_topk_mask_fwd")
+    return logits
+
+
+def head_padded(weight, bias, groups, d, dp, axis):
+    """Linear parameters with every head's slice of width d padded to dp with zeros -- along the output features (axis 0: weight rows
+    and bias, `groups` = number of head slices) or the input features (axis 1: weight columns).  Lets head widths outside the
+    attention kernel's {32, 64} run on it: zero q/k columns add nothing to the logits, zero v columns produce zero outputs that the
+    padded projection ignores.  Cached with the parameters."""
+    def build():
+        w = weight.detach()
+        if axis == 0:
+            wp = torch.zeros(groups * dp, w.shape[1], dtype=torch.float32, device=w.device)
+            wp.view(groups, dp, -1)[:, :d] = w.view(groups, d, -1)
+            bp = None
+            if bias is not None:
+                bp = torch.zeros(groups * dp, dtype=torch.float32, device=w.device)
+                bp.view(groups, dp)[:, :d] = bias.detach().view(groups, d)
+            return wp, bp
+        wp = torch.zeros(w.shape[0], groups * dp, dtype=torch.float32, device=w.device)
+        wp.view(-1, groups, dp)[:, :, :d] = w.view(-1, groups, d)
+        return wp, None
+
+    anchors = (weight,) if bias is None else (weight, bias)
+    tag = tuple((t._version, t.data_ptr()) for t in anchors)
+    return _derived_get(anchors, ("headpad", groups, d, dp, axis), tag, build)
+
+
+def attn_head_width(d):
+    """Head width the streaming attention kernel runs a logical width d on (zero padded)."""
+    if d <= 32:
+        return 32
+    if d <= 64:
+        return 64
+    raise ValueError(f"attention head width {d} > 64 is outside the kernel's envelope")
+
+
 def dwconv_patch_tokens(x, conv_w, conv_b, bn, H, W, sr):
     """Depth-wise conv (kernel == stride == sr, optional bias) + optional eval BatchNorm2d on a token grid:
     (B, H*W, C) -> (B, (H/sr)*(W/sr), C).  Conv bias and BatchNorm are folded into one weight / bias pair, cached per version."""

@@ -158,6 +158,24 @@ CASES = [
     dict(id="segformer_attn", mod="vision_transformers.segformer", cls="Attention", args=(64,), kwargs=dict(num_heads=1, qkv_bias=True, sr_ratio=8),
          shape=(2, 3136, 64), fwd_args=(56, 56),
          oracle=lambda x, sd, dt: O.mhsa_forward(x, sd, 1, 56, 56, 8, layout="q,kv", dtype=dt)),
+    dict(id="dilate_gattn", mod="vision_transformers.dilateformer", cls="GlobalAttention", args=(72,), kwargs=dict(num_heads=3, qkv_bias=True),
+         shape=(2, 14, 14, 72), oracle=lambda x, sd, dt: O.global_attention_forward(x, sd, 3, dt)),
+    dict(id="dilate_gattn_d32", mod="vision_transformers.dilateformer", cls="GlobalAttention", args=(256,), shape=(2, 7, 9, 256),
+         oracle=lambda x, sd, dt: O.global_attention_forward(x, sd, 8, dt)),
+    dict(id="bvit_attn", mod="vision_transformers.bvit", cls="Broad_Attention", args=(192,), kwargs=dict(heads=3, dim_head=64),
+         shape=(2, 197, 192), oracle=lambda x, sd, dt: O.broad_attention_forward(x, sd, 3, 64, dt)),
+    dict(id="bvit_attn_d48", mod="vision_transformers.bvit", cls="Broad_Attention", args=(96,), kwargs=dict(heads=2, dim_head=48),
+         shape=(2, 50, 96), oracle=lambda x, sd, dt: O.broad_attention_forward(x, sd, 2, 48, dt)),
+    dict(id="effformer_attn", mod="vision_transformers.efficientformer", cls="Attention", args=(448, 32, 8), kwargs=dict(qkv_bias=True),
+         shape=(2, 49, 448), oracle=lambda x, sd, dt: O.qk_v_attention_forward(x, sd, 32, 8, dt)),
+    dict(id="kvt_attn", mod="vision_transformers.kvt", cls="KNNAttention", args=(256, 4), kwargs=dict(qkv_bias=True, topk=100),
+         shape=(2, 197, 256), oracle=lambda x, sd, dt: O.knn_attention_forward(x, sd, 4, 100, dt)),
+    dict(id="kvt_attn_small", mod="vision_transformers.kvt", cls="KNNAttention", args=(96, 4), kwargs=dict(topk=7),
+         shape=(3, 50, 96), oracle=lambda x, sd, dt: O.knn_attention_forward(x, sd, 4, 7, dt)),
+    dict(id="cvt_attn", mod="vision_transformers.cvt", cls="Attention", args=(64,), kwargs=dict(num_heads=1), shape=(2, 64, 28, 28),
+         prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.conv_attention_forward(x, sd, 1, dt)),
+    dict(id="cvt_attn_d24", mod="vision_transformers.cvt", cls="Attention", args=(96,), kwargs=dict(num_heads=4, ks=5), shape=(2, 96, 9, 13),
+         prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.conv_attention_forward(x, sd, 4, dt)),
     # ---- squeeze-excite copies inside the CNN files (module level) ----------------------------------------------------
     dict(id="se_effnet", mod="cnns.efficientnet", cls="SELayer", args=(96, 4), shape=(2, 96, 28, 28), small=True,
          oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["fc.0.weight"], sd["fc.0.bias"], sd["fc.2.weight"], sd["fc.2.bias"], "sigmoid", dt)),
@@ -218,6 +236,14 @@ N_SAMPLES = 257            # strided sample positions recorded per case (prime -
 def sample_index(numel, n=N_SAMPLES):
     """Deterministic sample positions: i * (numel-1) // (n-1), i = 0..n-1 (first and last included)."""
     return [i * (numel - 1) // (n - 1) for i in range(n)]
+
+
+def flat_out(y):
+    """Modules that return several tensors (bvit's Broad_Attention: out, q, k, v) are compared on the concatenation of all of them."""
+    import torch
+    if isinstance(y, (tuple, list)):
+        return torch.cat([t.reshape(-1) for t in y])
+    return y
 
 
 def build_case(c, cls):

@@ -27,7 +27,31 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-from cases import CASES, build_case, make_arg, sample_index  # noqa: E402
+from cases import CASES, build_case, flat_out, make_arg, sample_index  # noqa: E402
+
+
+def _stub_timm():
+    """vision_transformers/dilateformer.py:19-20 imports timm helpers (DropPath, to_2tuple, trunc_normal_, _cfg) that are not
+    installed here.  GlobalAttention (the class the fixtures cover) uses none of them, so importing the file only needs the
+    names to exist."""
+    import types
+    try:
+        import timm  # noqa: F401
+        return
+    except ImportError:
+        pass
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    vit = types.ModuleType("timm.models.vision_transformer")
+
+    def _unavailable(*a, **k):
+        raise RuntimeError("timm is not installed: stub used only to import dilateformer.py")
+
+    layers.DropPath = layers.to_2tuple = layers.trunc_normal_ = _unavailable
+    vit._cfg = _unavailable
+    timm.models, models.layers, models.vision_transformer = models, layers, vit
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers, "timm.models.vision_transformer": vit})
 
 
 def main():
@@ -36,6 +60,7 @@ def main():
     args = ap.parse_args()
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
+    _stub_timm()
     torch.set_num_threads(os.cpu_count())
     out = {"torch": torch.__version__, "protocol": "weights seed 1234, input seed 4321, eval, fp32 CPU",
            "cases": {}}
@@ -45,7 +70,7 @@ def main():
         cls = getattr(mod, c["cls"])
         m, x = build_case(c, cls)
         with torch.no_grad():
-            y = m(x, *[make_arg(a) for a in c.get("fwd_args", ())])
+            y = flat_out(m(x, *[make_arg(a) for a in c.get("fwd_args", ())]))
         yf = y.reshape(-1)
         n = yf.numel()
         rec = {

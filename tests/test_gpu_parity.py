@@ -12,7 +12,7 @@ import importlib
 import pytest
 import torch
 
-from cases import BY_ID, CASES, build_case, make_arg, sample_index
+from cases import BY_ID, CASES, build_case, flat_out, make_arg, sample_index
 from conftest import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +31,7 @@ def _run(c, precision=None):
     import mi355attn
     cls = getattr(importlib.import_module(c["mod"]), c["cls"])
     m, x = build_case(c, cls)
-    ref = c["oracle"](x, m.state_dict(), torch.float32)
+    ref = flat_out(c["oracle"](x, m.state_dict(), torch.float32))
     old = mi355attn.default_precision()
     if precision is not None:
         mi355attn.set_default_precision(precision)
@@ -39,7 +39,7 @@ def _run(c, precision=None):
         dev = m.to("cuda")
         with torch.no_grad():
             args = [make_arg(a) for a in c.get("fwd_args", ())]
-            y = dev(x.to("cuda"), *[a.cuda() if isinstance(a, torch.Tensor) else a for a in args])
+            y = flat_out(dev(x.to("cuda"), *[a.cuda() if isinstance(a, torch.Tensor) else a for a in args]))
         torch.cuda.synchronize()
     finally:
         mi355attn.set_default_precision(old)

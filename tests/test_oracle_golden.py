@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import BY_ID, CASES, build_case, sample_index
+from cases import BY_ID, CASES, build_case, flat_out, sample_index
 from conftest import REFERENCE, ROOT, have_reference, rel_fro
 
 
@@ -46,7 +46,7 @@ def test_dropin_params_match_reference_init(cid, golden):
 def test_oracle_matches_golden(cid, golden):
     c, g = BY_ID[cid], golden[cid]
     m, x = _build(c)
-    y = c["oracle"](x, m.state_dict(), torch.float32)
+    y = flat_out(c["oracle"](x, m.state_dict(), torch.float32))
     assert list(y.shape) == g["y_shape"]
     yf = y.reshape(-1)
     n = yf.numel()
@@ -68,8 +68,8 @@ def test_oracle_matches_full_small_tensor(cid):
     for k, v in m.state_dict().items():
         assert np.array_equal(v.numpy(), z["p:" + k]), f"parameter {k} differs from the reference init"
     ref = torch.from_numpy(z["y"])
-    y32 = c["oracle"](x, m.state_dict(), torch.float32)
-    y64 = c["oracle"](x, m.state_dict(), torch.float64)
+    y32 = flat_out(c["oracle"](x, m.state_dict(), torch.float32))
+    y64 = flat_out(c["oracle"](x, m.state_dict(), torch.float64))
     assert rel_fro(y32, ref) <= 2e-6
     assert rel_fro(ref, y64) <= 2e-6          # the reference itself sits this close to the fp64 truth
 
