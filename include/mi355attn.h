@@ -232,6 +232,13 @@ int mi355_tokens_to_nchw_axpy_fwd(const float* tokens, const float* x, const flo
  * mi355_topk_mask_fwd: in place on `rows` rows of length N: the k largest entries of a row become 0, all others -1e30 -- the additive
  *   bias that makes mi355_sdpa_general_fwd the k-NN attention of kvt.py:83-89 (top-k of the scaled logits == top-k of the unscaled
  *   ones).  N <= 4096. */
+/* P2T's pooled key/value source (p2t.py:76-83) on the token layout.  mi355_adaptive_pool_tokens_fwd: F.adaptive_avg_pool2d of the
+ * (H x W) token grid x (B, H*W, C) to y (B, OH*OW, C).  mi355_dwconv3x3_tokens_residual_fwd: y = x + dwconv3x3(x) + bias on a (H x W)
+ * token grid (weight (C,3,3)); y points into a longer token sequence whose images are y_batch_stride floats apart (the concatenation
+ * of the pyramid levels, p2t.py:82). */
+int mi355_adaptive_pool_tokens_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, mi355_stream_t stream);
+int mi355_dwconv3x3_tokens_residual_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int H, int W, int C,
+                                        long y_batch_stride, mi355_stream_t stream);
 int mi355_dwconv_nchw_tokens_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C, int H, int W, int ks,
                                  mi355_stream_t stream);
 int mi355_qk_logits_fwd(const float* q, const float* k, float* logits, int B, int heads, int Nq, int Nkv, int head_dim, int ldq, int ldk,

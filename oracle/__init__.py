@@ -25,7 +25,8 @@ from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, c
 from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_mlp_forward,
                           vit_encoder_forward, vit_patch_embed_forward, vit_forward,
                           mixer_layer_forward, sdpa_core, mixer_forward, mhsa_forward, global_attention_forward,
-                          broad_attention_forward, qk_v_attention_forward, knn_attention_forward, conv_attention_forward)
+                          broad_attention_forward, qk_v_attention_forward, knn_attention_forward, conv_attention_forward,
+                          pooling_attention_forward)
 from .cswin import lepe_attention_forward, cswin_block_forward, window_token_index, cswin_forward
 from .xcit import (xca_forward, lpi_forward, xca_block_forward, xcit_forward, conv_patch_embed_forward, fourier_position_rows,
                    class_attention_block_forward)

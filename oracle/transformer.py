@@ -260,3 +260,25 @@ def conv_attention_forward(x, p, num_heads, dtype=torch.float32, bn_eps=1e-5):
     o = _heads_attention(qkv[0], qkv[1], qkv[2], d ** -0.5)                 # (B, h, N, d)
     o = o.transpose(-1, -2).reshape(B, C, H, W)
     return TF.conv2d(o, g("proj.weight"), g("proj.bias"))
+
+
+def pooling_attention_forward(x, p, H, W, d_convs, num_heads, pool_ratios, dtype=torch.float32):
+    """PoolingAttention.forward -- vision_transformers/p2t.py:71-95.  `d_convs`: the depth-wise 3x3 Conv2d modules the enclosing block
+    passes in (p2t.py:127-128), one per pool ratio."""
+    import torch.nn.functional as TF
+    x = _t(x, dtype)
+    B, N, C = x.shape
+    d = C // num_heads
+    opt = lambda k: _t(p[k], dtype) if k in p else None
+    q = linear(x, _t(p["q.0.weight"], dtype), opt("q.0.bias")).reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
+    grid = x.permute(0, 2, 1).reshape(B, C, H, W)
+    pools = []
+    for ratio, conv in zip(pool_ratios, d_convs):
+        pool = TF.adaptive_avg_pool2d(grid, (round(H / ratio), round(W / ratio)))
+        pool = pool + TF.conv2d(pool, _t(conv.weight, dtype), _t(conv.bias, dtype), padding=1, groups=C)
+        pools.append(pool.reshape(B, C, -1))
+    pools = torch.cat(pools, dim=2).permute(0, 2, 1)
+    pools = layernorm(pools, _t(p["norm.weight"], dtype), _t(p["norm.bias"], dtype))
+    kv = linear(pools, _t(p["kv.0.weight"], dtype), opt("kv.0.bias")).reshape(B, -1, 2, num_heads, d).permute(2, 0, 3, 1, 4)
+    o = _heads_attention(q, kv[0], kv[1], d ** -0.5).transpose(1, 2).reshape(B, N, C)
+    return linear(o, _t(p["proj.weight"], dtype), _t(p["proj.bias"], dtype))

@@ -44,6 +44,50 @@ __global__ __launch_bounds__(256) void dwconv_nchw_tokens_kernel(const float* __
     }
 }
 
+// P2T's pooled key/value source (p2t.py:76-83) on the token layout: adaptive average pooling of the (H x W) token grid to (OH x OW)
+// with ATen's bin edges (start = floor(i * H / OH), end = ceil((i + 1) * H / OH)), channels fastest.
+__global__ __launch_bounds__(256) void adaptive_pool_tokens_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int OH,
+                                                                  int OW, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long t = idx / C;
+    const int oj = (int)(t % OW), oi = (int)((t / OW) % OH);
+    const long b = t / ((long)OW * OH);
+    const int i0 = (int)(((long)oi * H) / OH), i1 = (int)((((long)oi + 1) * H + OH - 1) / OH);
+    const int j0 = (int)(((long)oj * W) / OW), j1 = (int)((((long)oj + 1) * W + OW - 1) / OW);
+    const float* xb = x + b * (long)H * W * C + c;
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i)
+        for (int j = j0; j < j1; ++j) s += xb[((long)i * W + j) * C];
+    y[idx] = s / (float)((i1 - i0) * (j1 - j0));
+}
+
+// y[b, p, c] = x[b, p, c] + bias[c] + sum_uv w[c, u, v] * x[b, (i+u-1, j+v-1), c]: the `pool + l(pool)` of p2t.py:79 with l a depth-wise
+// 3x3 convolution, on a (H x W) token grid; y rows live in a longer token sequence (batch stride y_bstride).
+__global__ __launch_bounds__(256) void dwconv3x3_tokens_residual_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                       float* __restrict__ y, int H, int W, int C, long y_bstride, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long t = idx / C;
+    const int j = (int)(t % W), i = (int)((t / W) % H);
+    const long b = t / ((long)W * H);
+    const float* xb = x + b * (long)H * W * C + c;
+    float acc = xb[((long)i * W + j) * C] + (bias ? bias[c] : 0.f);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int ii = i + u - 1;
+        if (ii < 0 || ii >= H) continue;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int jj = j + v - 1;
+            if (jj >= 0 && jj < W) acc = __builtin_fmaf(w[c * 9 + u * 3 + v], xb[((long)ii * W + jj) * C], acc);
+        }
+    }
+    y[b * y_bstride + ((long)i * W + j) * C + c] = acc;
+}
+
 // Top-k mask of every logits row, in place: entries among the k largest of their row become 0, all others -1e30 (an additive
 // attention bias; finite so that an all-masked key tile of the streaming softmax stays NaN-free).  One wave per row; the k-th
 // largest value is found by a 32-step bisection on the order-preserving integer image of the floats (count >= candidate).
@@ -106,6 +150,24 @@ int mi355_qk_logits_fwd(const float* q, const float* k, float* logits, int B, in
                                               ldk, Nkv, (long)Nq * ldq, (long)Nkv * ldk, (long)heads * Nq * Nkv, precision, st);
         if (rc) return rc;
     }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_adaptive_pool_tokens_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0);
+    const long total = (long)B * OH * OW * C;
+    adaptive_pool_tokens_kernel<<<cdiv(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(x, y, H, W, C, OH, OW, total);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_dwconv3x3_tokens_residual_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int H, int W, int C,
+                                        long y_batch_stride, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && weight && y && B > 0 && H > 0 && W > 0 && C > 0 && y_batch_stride >= (long)H * W * C);
+    const long total = (long)B * H * W * C;
+    dwconv3x3_tokens_residual_kernel<<<cdiv(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(x, weight, bias, y, H, W, C, y_batch_stride,
+                                                                                                     total);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

@@ -788,6 +788,31 @@ def dwconv_bn_nchw_tokens(x, conv_w, conv_b, bn):
     return y
 
 
+def pooled_pyramid_tokens(x, H, W, sizes, d_convs):
+    """P2T's key/value source (p2t.py:76-82): for every (oh, ow) in `sizes`, adaptive-average-pool the (H x W) token grid x (B, H*W, C),
+    add the depth-wise 3x3 conv of the pooled grid (`d_convs[i]`, a Conv2d with groups == C) and concatenate along the token axis."""
+    x = require_device_f32(x, "x")
+    B, L, C = x.shape
+    if L != H * W:
+        raise ValueError("pooled_pyramid_tokens: token count does not match (H, W)")
+    total = sum(oh * ow for oh, ow in sizes)
+    out = torch.empty(B, total, C, dtype=torch.float32, device=x.device)
+    off = 0
+    for (oh, ow), conv in zip(sizes, d_convs):
+        if conv.kernel_size != (3, 3) or conv.groups != C or conv.stride != (1, 1) or conv.padding != (1, 1):
+            raise ValueError("pooled_pyramid_tokens: d_convs must be depth-wise 3x3, stride 1, padding 1")
+        pooled = torch.empty(B, oh * ow, C, dtype=torch.float32, device=x.device)
+        check(lib().mi355_adaptive_pool_tokens_fwd(dptr(x), dptr(pooled), B, H, W, C, oh, ow, stream_ptr(x.device)),
+              "mi355_adaptive_pool_tokens_fwd")
+        w = require_device_f32(conv.weight, "d_conv.weight").reshape(C, 9)
+        b = _opt(conv.bias, "d_conv.bias")
+        dst = out[:, off:off + oh * ow]
+        check(lib().mi355_dwconv3x3_tokens_residual_fwd(dptr(pooled), dptr(w), dptr(b), ctypes.c_void_p(dst.data_ptr()), B, oh, ow, C,
+                                                        total * C, stream_ptr(x.device)), "mi355_dwconv3x3_tokens_residual_fwd")
+        off += oh * ow
+    return out
+
+
 def qk_logits(q, k, num_heads, precision=PREC_STRICT):
     """Unscaled logits (B, heads, Nq, Nkv) of (B,Nq,C) queries against (B,Nkv,C) keys (views into fused projections welcome)."""
     q, ldq = _rows3(q, "q")

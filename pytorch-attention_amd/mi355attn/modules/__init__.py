@@ -6,7 +6,7 @@ from .vit import Attention, PatchEmbedding, TransformerEncoder, VisionTransforme
 from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed, PositionalEncodingFourier, XCABlock, XCiT,  # noqa: F401
                    xcit_nano_12_p16)
 from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401
-from .mhsa import (Broad_Attention, ConvAttention, GlobalAttention, KNNAttention, QKVSplitAttention, SRAttention,  # noqa: F401
+from .mhsa import (Broad_Attention, ConvAttention, GlobalAttention, KNNAttention, PoolingAttention, QKVSplitAttention, SRAttention,  # noqa: F401
                    SRAttentionRelPos, SRConvAttention)
 from .se_variants import SELayerBias, SELayerHidden, SqueezeExcite  # noqa: F401
 from .axis import BAM, CAM, PAM, CoordinateAttention, GCModule, SKLayer, TripletAttention  # noqa: F401

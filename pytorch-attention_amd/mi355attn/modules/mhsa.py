@@ -293,3 +293,47 @@ class ConvAttention(nn.Module):
         out, _, _ = _fused_qkv_attention(tokens, self._lin("_pw_lin", pw), self._lin("_proj_lin", self.proj), self.num_heads,
                                          C // self.num_heads, self.scale, self.precision)
         return F.tokens_to_nchw(out, H, W)
+
+
+class PoolingAttention(nn.Module):
+    """p2t.py:46-95: queries from every token, keys / values from a pyramid of adaptively pooled token grids (each refined by a
+    depth-wise 3x3 conv handed in by the enclosing block), LayerNorm, fused kv Linear."""
+
+    def __init__(self, dim, num_heads=2, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., pool_ratios=[1, 2, 3, 6], precision=None):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        _no_dropout(attn_drop, proj_drop)
+        self.dim = dim
+        self.num_heads = num_heads
+        self.num_elements = sum(t * t for t in pool_ratios)
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.q = nn.Sequential(nn.Linear(dim, dim, bias=qkv_bias))
+        self.kv = nn.Sequential(nn.Linear(dim, dim * 2, bias=qkv_bias))
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.pool_ratios = pool_ratios
+        self.pools = nn.ModuleList()
+        self.norm = nn.LayerNorm(dim)
+        self.precision = precision
+
+    def forward(self, x, H, W, d_convs=None):
+        B, N, C = x.shape
+        p, h = self.precision, self.num_heads
+        d = C // h
+        dp = F.attn_head_width(d)
+        sizes = [(round(H / r), round(W / r)) for r in self.pool_ratios]
+        pools = F.pooled_pyramid_tokens(x, H, W, sizes, d_convs)
+        pools = F.layernorm(pools, self.norm.weight, self.norm.bias, self.norm.eps)
+        ql, kvl = self.q[0], self.kv[0]
+        if dp == d:
+            wq, bq, wkv, bkv, wp = ql.weight, ql.bias, kvl.weight, kvl.bias, self.proj.weight
+        else:
+            wq, bq = F.head_padded(ql.weight, ql.bias, h, d, dp, 0)
+            wkv, bkv = F.head_padded(kvl.weight, kvl.bias, 2 * h, d, dp, 0)
+            wp = F.head_padded(self.proj.weight, None, h, d, dp, 1)[0]
+        Cp = h * dp
+        q = F.linear(x, wq, bq, precision=p)
+        kv = F.linear(pools, wkv, bkv, precision=p)
+        ctx = F.sdpa_general(q, kv[..., :Cp], kv[..., Cp:], h, self.scale, precision=p)
+        return F.linear(ctx, wp, self.proj.bias, precision=p)

@@ -176,6 +176,12 @@ CASES = [
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.conv_attention_forward(x, sd, 1, dt)),
     dict(id="cvt_attn_d24", mod="vision_transformers.cvt", cls="Attention", args=(96,), kwargs=dict(num_heads=4, ks=5), shape=(2, 96, 9, 13),
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.conv_attention_forward(x, sd, 4, dt)),
+    dict(id="p2t_attn", mod="vision_transformers.p2t", cls="PoolingAttention", args=(64,), kwargs=dict(num_heads=1, qkv_bias=True,
+         pool_ratios=[12, 16, 20, 24]), shape=(2, 3136, 64), fwd_args=(56, 56, "dconvs:64,4"),
+         oracle=lambda x, sd, dt: O.pooling_attention_forward(x, sd, 56, 56, make_arg("dconvs:64,4"), 1, [12, 16, 20, 24], dt)),
+    dict(id="p2t_attn_d40", mod="vision_transformers.p2t", cls="PoolingAttention", args=(80,), kwargs=dict(num_heads=2),
+         shape=(3, 165, 80), fwd_args=(11, 15, "dconvs:80,4"),
+         oracle=lambda x, sd, dt: O.pooling_attention_forward(x, sd, 11, 15, make_arg("dconvs:80,4"), 2, [1, 2, 3, 6], dt)),
     # ---- squeeze-excite copies inside the CNN files (module level) ----------------------------------------------------
     dict(id="se_effnet", mod="cnns.efficientnet", cls="SELayer", args=(96, 4), shape=(2, 96, 28, 28), small=True,
          oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["fc.0.weight"], sd["fc.0.bias"], sd["fc.2.weight"], sd["fc.2.bias"], "sigmoid", dt)),
@@ -197,6 +203,13 @@ def make_arg(a):
         import torch
         shape = tuple(int(v) for v in a.split(":")[1].split(","))
         return 0.5 * torch.randn(shape, generator=torch.Generator().manual_seed(991))
+    if isinstance(a, str) and a.startswith("dconvs:"):
+        # "dconvs:<C>,<n>": the ModuleList of n depth-wise 3x3 convs that p2t's Block hands to PoolingAttention.forward (p2t.py:127-128)
+        import torch
+        C, n = (int(v) for v in a.split(":")[1].split(","))
+        with torch.random.fork_rng():
+            torch.manual_seed(992)
+            return torch.nn.ModuleList([torch.nn.Conv2d(C, C, 3, 1, 1, groups=C) for _ in range(n)]).eval()
     return a
 
 

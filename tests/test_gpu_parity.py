@@ -39,7 +39,7 @@ def _run(c, precision=None):
         dev = m.to("cuda")
         with torch.no_grad():
             args = [make_arg(a) for a in c.get("fwd_args", ())]
-            y = flat_out(dev(x.to("cuda"), *[a.cuda() if isinstance(a, torch.Tensor) else a for a in args]))
+            y = flat_out(dev(x.to("cuda"), *[a.cuda() if isinstance(a, (torch.Tensor, torch.nn.Module)) else a for a in args]))
         torch.cuda.synchronize()
     finally:
         mi355attn.set_default_precision(old)
