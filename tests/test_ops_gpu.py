@@ -663,3 +663,76 @@ def test_mlp_fused_rejects_other_shapes():
     fc1, fc2 = torch.nn.Linear(256, 1024).cuda(), torch.nn.Linear(1024, 256).cuda()
     with pytest.raises(Mi355Error, match="C = 64"):
         F().mlp_fused(torch.randn(8, 256).cuda(), None, fc1, fc2, precision=1)
+
+
+# ---------------------------------------------------------------------------------------------- glue of the f1 / f2 rows
+@pytest.mark.parametrize("rows,N,k", [(5, 7, 1), (5, 7, 7), (33, 64, 10), (12, 197, 100), (9, 300, 150), (3, 1500, 20), (2, 4096, 4000)])
+def test_topk_mask_matches_torch_topk(rows, N, k):
+    """0 at the k largest entries of every row, -1e30 elsewhere (kvt.py:85-88 as an additive bias)."""
+    torch.manual_seed(rows * N + k)
+    x = torch.randn(rows, N) * 3
+    x[0, : min(N, 4)] = torch.tensor([-0.0, 0.0, -1e-30, 1e-30])[: min(N, 4)]           # sign / denormal ordering
+    want = torch.full_like(x, -1e30)
+    want.scatter_(-1, torch.topk(x, k, dim=-1)[1], 0.0)
+    got = F().topk_mask_(x.clone().cuda(), k).cpu()
+    if not torch.equal(got, want):                                     # -0.0 == 0.0 ties may resolve either way in torch.topk
+        assert int((got == 0).sum(-1).min()) >= k and torch.equal(got[1:], want[1:])
+
+
+@pytest.mark.parametrize("B,H,W,C,oh,ow", [(2, 56, 56, 64, 5, 4), (3, 11, 15, 80, 6, 8), (1, 7, 7, 4, 7, 7), (2, 9, 5, 12, 1, 1), (2, 5, 9, 8, 2, 3)])
+def test_adaptive_pool_and_dwconv_residual_on_tokens(B, H, W, C, oh, ow):
+    torch.manual_seed(H * W + C)
+    x = torch.randn(B, H * W, C)
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, groups=C).eval()
+    grid = x.double().permute(0, 2, 1).reshape(B, C, H, W)
+    pool = torch.nn.functional.adaptive_avg_pool2d(grid, (oh, ow))
+    ref = pool + torch.nn.functional.conv2d(pool, conv.weight.double(), conv.bias.double(), padding=1, groups=C)
+    ref = ref.reshape(B, C, -1).permute(0, 2, 1).float()
+    got = F().pooled_pyramid_tokens(x.cuda(), H, W, [(oh, ow), (oh, ow)], [conv.cuda(), conv.cuda()]).cpu()
+    assert got.shape == (B, 2 * oh * ow, C)
+    assert_parity(got[:, : oh * ow], ref, 1e-5, "pyramid level 0")
+    assert torch.equal(got[:, : oh * ow], got[:, oh * ow:])
+
+
+@pytest.mark.parametrize("B,C,H,W,ks", [(2, 64, 28, 28, 3), (2, 96, 9, 13, 5), (1, 5, 4, 3, 3), (3, 33, 7, 40, 7)])
+def test_dwconv_bn_nchw_to_tokens_and_back(B, C, H, W, ks):
+    torch.manual_seed(C * H + W)
+    x = torch.randn(B, C, H, W)
+    conv = torch.nn.Conv2d(C, C, ks, 1, (ks - 1) // 2, groups=C)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.normal_(1, 0.2); bn.bias.normal_(0, 0.2)
+    conv.eval(); bn.eval()
+    with torch.no_grad():
+        ref = bn.double()(conv.double()(x.double())).float()
+    conv.float(); bn.float()
+    f = F()
+    tok = f.dwconv_bn_nchw_tokens(x.cuda(), conv.weight.cuda(), conv.bias.cuda(), bn.cuda())
+    assert tok.shape == (B, H * W, C)
+    assert_parity(tok.cpu(), ref.reshape(B, C, -1).permute(0, 2, 1), 1e-5, "dwconv + bn -> tokens")
+    back = f.tokens_to_nchw(tok, H, W)
+    assert torch.equal(back.cpu(), tok.cpu().permute(0, 2, 1).reshape(B, C, H, W))
+    alpha = torch.tensor([0.37]).cuda()
+    assert_parity(f.tokens_to_nchw_axpy(tok, x.cuda(), alpha).cpu(), 0.37 * back.cpu() + x, 1e-6, "alpha * tokens^T + x")
+
+
+@pytest.mark.parametrize("B,h,Nq,Nkv,d", [(2, 4, 197, 197, 64), (3, 2, 50, 13, 32), (1, 3, 7, 9, 24)])
+def test_qk_logits(B, h, Nq, Nkv, d):
+    torch.manual_seed(Nq + Nkv)
+    C = h * d
+    qkv = torch.randn(B, Nq, 3 * C)
+    kk = torch.randn(B, Nkv, 2 * C)
+    got = F().qk_logits(qkv.cuda()[..., :C], kk.cuda()[..., C:], h).cpu()
+    q = qkv[..., :C].double().reshape(B, Nq, h, d).permute(0, 2, 1, 3)
+    k = kk[..., C:].double().reshape(B, Nkv, h, d).permute(0, 2, 1, 3)
+    assert_parity(got, (q @ k.transpose(-1, -2)).float(), 5e-5, "unscaled logits (split-bf16)")
+
+
+def test_axis_gates_reject_training_mode_and_bad_shapes():
+    from mi355attn.modules import BAM, CoordinateAttention, TripletAttention
+    x = torch.randn(2, 32, 8, 8).cuda()
+    for m in (BAM(32), TripletAttention(), CoordinateAttention(32, 32)):
+        with pytest.raises(RuntimeError):
+            m.cuda().train()(x)
+    with pytest.raises(ValueError):
+        CoordinateAttention(32, 16).cuda().eval()(x)
