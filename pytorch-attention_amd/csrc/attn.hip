@@ -43,9 +43,19 @@ struct AttnPair {
     int split;
 };
 
-template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW>
-__global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
-    const bool second = (int)blockIdx.x >= pr.split;
+// OCC: workgroups per CU the register allocation is asked to leave room for.  The window kernels are latency-bound (a workgroup does
+// one memory round trip, a few dozen MFMAs, one store), so resident workgroups per CU are the throughput lever.
+template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair pr) {
+    // XCD-aware block order: hardware hands consecutive block ids to the 8 XCDs round-robin, but consecutive LOGICAL ids are the heads
+    // of one window, whose q / k / v slices are adjacent 64-byte (d = 32) pieces of the same token rows -- neighbours that should
+    // meet in one XCD's L2.  XCD k therefore works on the contiguous logical range [k * n/8, (k+1) * n/8) (bijective for any n).
+    int lid;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    }
+    const bool second = lid >= pr.split;
     const AttnArgs a = second ? pr.a1 : pr.a0;
     constexpr int NTHR = NW * 64;             // NW waves share one head's K / V (8 for the 197-token ViT case: 4 waves per SIMD)
     static_assert(!IO16 || PREC != 0, "16-bit I/O exists for the fp16 / bf16 operand modes only");
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
     __shared__ __attribute__((aligned(16))) slab_t s_o[NW * 16 * OP];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int bid = (int)blockIdx.x - (second ? pr.split : 0);
+    int bid = lid - (second ? pr.split : 0);
     const int head = bid % a.heads; bid /= a.heads;
     const int win = bid % a.nwin;
     const int b = bid / a.nwin;
@@ -95,14 +105,12 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
             }
         }
     }
-    float lw[LEPE ? D / 16 : 1][9], lb[LEPE ? D / 16 : 1];
+    // LePE taps + bias of this head's D channels: parked in LDS ([channel][10]) instead of 20 registers per lane
+    __shared__ float s_lw[LEPE ? D * 10 : 1];
     if constexpr (LEPE) {
-#pragma unroll
-        for (int nt = 0; nt < D / 16; ++nt) {
-            const int cidx = head * D + nt * 16 + l15;
-            lb[nt] = a.lepe_b[cidx];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) lw[nt][i] = a.lepe_w[(long)cidx * 9 + i];
+        for (int q = t; q < D * 10; q += NTHR) {
+            const int c = q / 10, i = q - c * 10;
+            s_lw[q] = i < 9 ? a.lepe_w[(long)(head * D + c) * 9 + i] : a.lepe_b[head * D + c];
         }
     }
 
@@ -298,7 +306,8 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
                     if (qslot < T) {
                         const int d = nt * 16 + l15;                              // channel inside this head
                         const int ty = srow(qslot), tx = qslot - ty * a.Wsp;
-                        float acc = lb[nt];
+                        const float* lwp = s_lw + d * 10;
+                        float acc = lwp[9];
 #pragma unroll
                         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void win_attn_kernel(const AttnPair pr) {
                                     const int ss = yy * a.Wsp + xx;
                                     float vv = (float)(*reinterpret_cast<const el*>(s_v + d * VP + ss));
                                     if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(s_v + V_EL + d * VP + ss));
-                                    acc += lw[nt][(dy + 1) * 3 + dx + 1] * vv;
+                                    acc += lwp[(dy + 1) * 3 + dx + 1] * vv;
                                 }
                             }
                         val += acc;
@@ -359,10 +368,11 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
     if (IO16 && precision == MI355_PREC_STRICT)
         return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
 #define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(pr)
+#define GO_OCC(P, KT_, NW_, OCC_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, OCC_><<<grid, NW_ * 64, 0, st>>>(pr)
 #define BYKT(P)                                          \
     do {                                                 \
-        if (a.T <= 64) GO(P, 4, 4);                      \
-        else if (a.T <= 128) GO(P, 8, 4);                \
+        if (a.T <= 64) GO_OCC(P, 4, 4, 6);               \
+        else if (a.T <= 128) GO_OCC(P, 8, 4, 6);         \
         else if (IO16 && P != 0) GO(P, 14, 8);           \
         else GO(P, 14, 4);                               \
     } while (0)
@@ -373,6 +383,7 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
         default: return mi355::fail(MI355_EINVAL, "precision must be 0, 1 or 2 (got %d)", precision);
     }
 #undef BYKT
+#undef GO_OCC
 #undef GO
     return MI355_OK;
 }
