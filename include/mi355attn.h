@@ -69,6 +69,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   mi355_workspace_forget before freeing it).  The library then remembers the buffer, stamps every launch with
  *                   a fresh tag and skips the memset (43 MB per call at the C2 shape of CBAM).
  *   "zoo_single"    1 (default) = SimAM / SRM / GCT / LCT read x once when the shape allows; 0 = always two passes.
+ *   "stem_direct"   1 (default) = mi355_conv2d_tokens_fwd runs the image layer of a narrow stem (NCHW input, Cin <= 4, Cout <= 64,
+ *                   Cin*kh*kw*Cout <= 2048, e.g. 3 -> 16 3x3) on a direct fp32 kernel; 0 = implicit GEMM for every shape.
  *                   Under hipGraph stream capture the granule-exchange kernels are not used at all (a recorded launch replays with the
  *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
  *                   kernels instead, so captured graphs are replay-safe by construction.

@@ -16,6 +16,7 @@ static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, h
 static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
 static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in registers, three granule hops per band (cbam_single.hip)
 static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
+static std::atomic<long> g_stem_direct{1};  // narrow conv stems: direct fp32 kernel (stem_conv.hip) vs implicit GEMM
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
 static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
 
@@ -101,6 +102,7 @@ void ws_forget_range(const void* base, size_t bytes) {
 }
 
 long opt_zoo_single() { return g_zoo_single.load(std::memory_order_relaxed); }
+long opt_stem_direct() { return g_stem_direct.load(std::memory_order_relaxed); }
 long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 }  // namespace mi355
@@ -156,6 +158,11 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_zoo_single.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "stem_direct") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_stem_direct.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "se_occ") == 0) {
         MI355_CHECK_ARG(value == 2 || value == 3);
         mi355::g_se_occ.store(value, std::memory_order_relaxed);
@@ -184,6 +191,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
     if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
+    if (key && std::strcmp(key, "stem_direct") == 0) return mi355::opt_stem_direct();
     if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();
     if (key && std::strcmp(key, "cbam_single") == 0) return mi355::opt_cbam_single();
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");

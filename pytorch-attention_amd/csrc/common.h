@@ -28,6 +28,10 @@ bool  stream_is_capturing(hipStream_t st);      // hipGraph capture in progress 
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
 long  opt_zoo_single();
+long  opt_stem_direct();
+bool  stem_conv_applicable(int Cin, int Cout, int KH, int KW, int in_layout, const float* bias, const float* pos, const float* y);
+int   stem_conv(const float* x, const float* w, const float* bias, const float* pos, float* y, int B, int Cin, int H, int W, int Cout, int KH,
+                int KW, int stride, int pad, int ldw, int in_layout, int act, hipStream_t st);
 size_t zoo_workspace_bytes(int B, int C);
 size_t cbam_single_extra_bytes(int B, int C, int H, int W);
 bool  cbam_single_applicable(int C, int Cr, int H, int W, int ks);

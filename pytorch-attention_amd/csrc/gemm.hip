@@ -386,6 +386,13 @@ int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bi
     MI355_CHECK_ARG(ldw >= K && (ldw & 3) == 0);
     if (!aligned16(x) || !aligned16(weight) || (in_layout == 1 && (Cin & 3)))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_conv2d_tokens_fwd: 16-byte aligned buffers and, for token-major input, Cin %% 4 == 0 (Cin=%d)", Cin);
+    if (mi355::opt_stem_direct() && mi355::stem_conv_applicable(Cin, Cout, KH, KW, in_layout, bias, pos, y)) {
+        const int rc = mi355::stem_conv(x, weight, bias, pos, y, B, Cin, H, W, Cout, KH, KW, stride, pad, ldw, in_layout, act,
+                                        static_cast<hipStream_t>(stream));       // narrow stem layers: direct fp32 kernel (stem_conv.hip)
+        if (rc) return rc;
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     GemmArgs g{};
     g.A = x; g.B = weight; g.C = y; g.bias = bias; g.pos = pos; g.act = act;
     g.P = OH * OW; g.Pout = g.P; g.OW = OW; g.Kreal = Kreal;
