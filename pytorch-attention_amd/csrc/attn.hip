@@ -368,7 +368,7 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
     if (IO16 && precision == MI355_PREC_STRICT)
         return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
 #define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(pr)
-#define GO_OCC(P, KT_, NW_, OCC_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, ((IO16 && P != 0) ? OCC_ : 1)><<<grid, NW_ * 64, 0, st>>>(pr)
+#define GO_OCC(P, KT_, NW_, OCC_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, ((IO16 && P != 0 && D == 32) ? OCC_ : 1)><<<grid, NW_ * 64, 0, st>>>(pr)
 #define BYKT(P)                                          \
     do {                                                 \
         if (a.T <= 64) GO_OCC(P, 4, 4, 6);               \
