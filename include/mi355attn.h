@@ -215,7 +215,7 @@ int mi355_sk_fwd(const float* x, const float* const* params, float* y, int B, in
 
 /* DANet dual attention (dual_attention.py).  CAM :35-42: y = beta * softmax(X X^T) X + x with X = x viewed as (C, HW) per image; beta is
  * a 1-element device array; H*W and C multiples of 4; workspace of mi355_cam_workspace_bytes (the Gram matrices).  The logits are
- * unscaled sums over HW, so precision 0 (fp32-class split-bf16 MFMA) is the mode that meets the parity tolerance.
+ * unscaled sums over HW, so X X^T always runs in the fp32-class split-bf16 mode; `precision` selects the operand format of attn . X.
  * PAM :20-28 is composed by the caller from mi355_conv2d_tokens_fwd (the three 1x1 convs as one token-major GEMM),
  * mi355_sdpa_general_fwd (one head of width C, scale 1) and mi355_tokens_to_nchw_axpy_fwd:
  *   y[b,c,p] = alpha[0] * tokens[b,p,c] + x[b,c,p]      tokens (B,HW,C), x / y (B,C,HW), alpha a 1-element device array;

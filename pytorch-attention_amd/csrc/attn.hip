@@ -50,11 +50,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
     // XCD-aware block order: hardware hands consecutive block ids to the 8 XCDs round-robin, but consecutive LOGICAL ids are the heads
     // of one window, whose q / k / v slices are adjacent 64-byte (d = 32) pieces of the same token rows -- neighbours that should
     // meet in one XCD's L2.  XCD k therefore works on the contiguous logical range [k * n/8, (k+1) * n/8) (bijective for any n).
-    int lid;
-    {
-        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    }
+    const int lid = xcd_contiguous_block();
     const bool second = lid >= pr.split;
     const AttnArgs a = second ? pr.a1 : pr.a0;
     constexpr int NTHR = NW * 64;             // NW waves share one head's K / V (8 for the 197-token ViT case: 4 waves per SIMD)

@@ -488,8 +488,76 @@ __global__ __launch_bounds__(256) void gate_conv_kernel(const float* __restrict_
         if (s0 + e < S) op[e] = sigmoidf_(fmaxf(acc[e] * aff[0] + aff[1], 0.f));
 }
 
+// The same gate with the input tile staged in LDS: a workgroup owns TR rows x all S columns of one image's map; both planes are parked
+// with a zero halo (KS - 1 rows, 4 columns to the left so that a thread's 12-float window starts 16-byte aligned); a thread computes four
+// consecutive outputs of a row from 3 aligned 16-byte reads per plane and input row.
+template <int KS>
+__global__ __launch_bounds__(256) void gate_conv_lds_kernel(const float* __restrict__ in0, const float* __restrict__ in1, long bs, const float* __restrict__ w,
+                                                           const float* __restrict__ aff, float* __restrict__ out, int R, int S, int TR, int PW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PAD = (KS - 1) / 2, OFF = 4 - PAD;
+    const int rows = TR + KS - 1, plane = rows * PW;
+    float* wl = lds + 2 * plane;                                  // 2 * KS * KS weights
+    const int t = threadIdx.x, b = blockIdx.y, r0 = blockIdx.x * TR;
+    for (int q = t; q < 2 * plane; q += 256) lds[q] = 0.f;
+    for (int q = t; q < 2 * KS * KS; q += 256) wl[q] = w[q];
+    __syncthreads();
+    const float* p0 = in0 + (long)b * bs;
+    const float* p1 = in1 + (long)b * bs;
+    for (int q = t; q < rows * S; q += 256) {
+        const int rr = q / S, col = q - rr * S, r = r0 - PAD + rr;
+        if (r >= 0 && r < R) {
+            lds[rr * PW + 4 + col] = p0[(long)r * S + col];
+            lds[plane + rr * PW + 4 + col] = p1[(long)r * S + col];
+        }
+    }
+    __syncthreads();
+    const int s4 = (S + 3) >> 2;
+    const int tr = t / s4, q4 = t - tr * s4;
+    if (tr >= TR || r0 + tr >= R) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u = 0; u < KS; ++u) {
+        const float* ra = lds + (tr + u) * PW + q4 * 4;
+        const float* rm = ra + plane;
+        float a[12], m[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f4 va = *reinterpret_cast<const f4*>(ra + c * 4), vm = *reinterpret_cast<const f4*>(rm + c * 4);
+            a[c * 4] = va.x; a[c * 4 + 1] = va.y; a[c * 4 + 2] = va.z; a[c * 4 + 3] = va.w;
+            m[c * 4] = vm.x; m[c * 4 + 1] = vm.y; m[c * 4 + 2] = vm.z; m[c * 4 + 3] = vm.w;
+        }
+#pragma unroll
+        for (int v = 0; v < KS; ++v) {
+            const float w0 = wl[u * KS + v], w1 = wl[KS * KS + u * KS + v];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(w1, m[OFF + e + v], __builtin_fmaf(w0, a[OFF + e + v], acc[e]));
+        }
+    }
+    float* op = out + (long)b * R * S + (long)(r0 + tr) * S + q4 * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q4 * 4 + e < S) op[e] = sigmoidf_(fmaxf(acc[e] * aff[0] + aff[1], 0.f));
+}
+
+template <int KS>
+bool try_gate_conv_lds(const float* in0, const float* in1, long bs, const float* w, const float* aff, float* out, int B, int R, int S, hipStream_t st) {
+    const int s4 = (S + 3) >> 2;
+    if (s4 > 256) return false;
+    int TR = 256 / s4;
+    if (TR > R) TR = R;
+    const int PW = s4 * 4 + 8;                                    // 4 columns of halo on the left, >= 4 + PAD readable on the right
+    const size_t lds = ((size_t)2 * (TR + KS - 1) * PW + 2 * KS * KS) * sizeof(float);
+    if (lds > 65536) return false;
+    gate_conv_lds_kernel<KS><<<dim3(cdiv(R, TR), B), 256, lds, st>>>(in0, in1, bs, w, aff, out, R, S, TR, PW);
+    return true;
+}
+
 void launch_gate_conv(const float* in0, const float* in1, long bs, const float* w, const float* aff, float* out, int B, int R, int S, int k,
                       hipStream_t st) {
+    if (k == 7 && try_gate_conv_lds<7>(in0, in1, bs, w, aff, out, B, R, S, st)) return;
+    if (k == 5 && try_gate_conv_lds<5>(in0, in1, bs, w, aff, out, B, R, S, st)) return;
+    if (k == 3 && try_gate_conv_lds<3>(in0, in1, bs, w, aff, out, B, R, S, st)) return;
     const dim3 grid(cdiv((long)R * ((S + 3) >> 2), 256), B);
     if (k == 7)      gate_conv_kernel<7><<<grid, 256, 0, st>>>(in0, in1, bs, w, aff, out, R, S, k);
     else if (k == 3) gate_conv_kernel<3><<<grid, 256, 0, st>>>(in0, in1, bs, w, aff, out, R, S, k);
@@ -580,6 +648,60 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const float* __restrict
 #pragma unroll
             for (int e = 0; e < PIX; ++e)
                 if (p0 + e < HW) op[(long)o * HW + e] = fmaxf(acc[o][e] * sc[o] + sh[o], 0.f);
+        }
+}
+
+// The same convolution when W % 4 == 0 and dilation % 4 == 0 (BAM's default: dilation 4): the three taps of a row sit exactly one
+// aligned pixel quad to the left, at, and to the right of the thread's own quad, so a tap is ONE 16-byte load that is either
+// fully inside the image or fully outside -- 9 loads per input channel instead of 36 bounds-checked scalars.
+template <int CMAX>
+__global__ __launch_bounds__(256) void small_conv_quad_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ sc,
+                                                             const float* __restrict__ sh, float* __restrict__ out, int Cr, int H, int W, int dil) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [ci][3][3][CMAX], zero past Cr
+    for (int q = threadIdx.x; q < Cr * 9 * CMAX; q += 256) {
+        const int o = q % CMAX, tap = (q / CMAX) % 9, ci = q / (CMAX * 9);
+        wl[q] = o < Cr ? w[((long)o * Cr + ci) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+    const long HW = (long)H * W;
+    const int w4 = W >> 2;
+    const long qid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (qid >= (long)H * w4) return;
+    const int b = blockIdx.y, i = (int)(qid / w4), j = (int)(qid - (long)i * w4) * 4;
+    const float* ip = in + (long)b * Cr * HW;
+    f4 acc[CMAX];
+#pragma unroll
+    for (int o = 0; o < CMAX; ++o) acc[o] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < Cr; ++ci) {
+        f4 xv[9];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ii = i + (u - 1) * dil;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int jj = j + (v - 1) * dil;
+                const bool in_img = ii >= 0 && ii < H && jj >= 0 && jj < W;
+                xv[u * 3 + v] = *reinterpret_cast<const f4*>(ip + (long)ci * HW + (long)(in_img ? ii : i) * W + (in_img ? jj : j));
+                if (!in_img) xv[u * 3 + v] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const f4* wr = reinterpret_cast<const f4*>(wl + (ci * 9 + tap) * CMAX);
+#pragma unroll
+            for (int o4 = 0; o4 < CMAX / 4; ++o4) {
+                const f4 wk = wr[o4];
+                acc[o4 * 4 + 0] += wk.x * xv[tap]; acc[o4 * 4 + 1] += wk.y * xv[tap];
+                acc[o4 * 4 + 2] += wk.z * xv[tap]; acc[o4 * 4 + 3] += wk.w * xv[tap];
+            }
+        }
+    }
+    float* op = out + (long)b * Cr * HW + (long)i * W + j;
+#pragma unroll
+    for (int o = 0; o < CMAX; ++o)
+        if (o < Cr) {
+            const f4 r = acc[o] * sc[o] + sh[o];
+            *reinterpret_cast<f4*>(op + (long)o * HW) = f4{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
         }
 }
 
@@ -708,12 +830,23 @@ int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C,
     CR_DISPATCH(RED);
 #undef RED
     const dim3 grid(cdiv(cdiv(HW, Cr > 16 ? 2 : 4), 256), B);
+    const bool quad = (W & 3) == 0 && (dilation & 3) == 0 && Cr <= 16;
+#define SCQ(IN_, W_, SC_, SH_, OUT_)                                                                                                \
+    do {                                                                                                                           \
+        const dim3 qgrid(cdiv((long)H * (W >> 2), 256), B);                                                                        \
+        if (Cr <= 4)      small_conv_quad_kernel<4><<<qgrid, 256, (size_t)Cr * 9 * 4 * sizeof(float), st>>>(IN_, W_, SC_, SH_, OUT_, Cr, H, W, dilation);  \
+        else if (Cr <= 8) small_conv_quad_kernel<8><<<qgrid, 256, (size_t)Cr * 9 * 8 * sizeof(float), st>>>(IN_, W_, SC_, SH_, OUT_, Cr, H, W, dilation);  \
+        else              small_conv_quad_kernel<16><<<qgrid, 256, (size_t)Cr * 9 * 16 * sizeof(float), st>>>(IN_, W_, SC_, SH_, OUT_, Cr, H, W, dilation); \
+    } while (0)
 #define SC1(K_) small_conv_kernel<K_><<<grid, 256, (size_t)Cr * 9 * K_ * sizeof(float), st>>>(t0, p[MI355_BAM_DCONV1_W], p[MI355_BAM_DCONV1_SCALE], p[MI355_BAM_DCONV1_SHIFT], t1, Cr, H, W, dilation)
-    CR_DISPATCH(SC1);
+    if (quad) SCQ(t0, p[MI355_BAM_DCONV1_W], p[MI355_BAM_DCONV1_SCALE], p[MI355_BAM_DCONV1_SHIFT], t1);
+    else      CR_DISPATCH(SC1);
 #undef SC1
 #define SC2(K_) small_conv_kernel<K_><<<grid, 256, (size_t)Cr * 9 * K_ * sizeof(float), st>>>(t1, p[MI355_BAM_DCONV2_W], p[MI355_BAM_DCONV2_SCALE], p[MI355_BAM_DCONV2_SHIFT], t0, Cr, H, W, dilation)
-    CR_DISPATCH(SC2);
+    if (quad) SCQ(t1, p[MI355_BAM_DCONV2_W], p[MI355_BAM_DCONV2_SCALE], p[MI355_BAM_DCONV2_SHIFT], t0);
+    else      CR_DISPATCH(SC2);
 #undef SC2
+#undef SCQ
 #undef CR_DISPATCH
     launch_chan_reduce<0, 1>(t0, p[MI355_BAM_CONV3_W], p[MI355_BAM_CONV3_B], sg, B, Cr, HW, 1, st);
     ApplyArgs g{};

@@ -94,6 +94,13 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
     return v;
 }
+// Logical workgroup id of a 1-D grid such that each XCD works on one CONTIGUOUS range of logical ids (the hardware deals consecutive
+// blockIdx.x to the 8 XCDs round-robin): neighbours in the logical order -- heads of one image, query blocks of one head -- then share
+// an L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous_block() {
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 __device__ __forceinline__ float se_gate(float z, int kind) { return kind ? fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f : sigmoidf_(z); }
 // exact-erf GELU (nn.GELU() default), library erff: used off the hot path (LPI)

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     const int nqb = (a.Nq + 63) >> 6;
-    int bid = blockIdx.x;
+    int bid = xcd_contiguous_block();                       // query blocks of one head (same K / V) and neighbouring heads share an L2
     const int qb = bid % nqb; bid /= nqb;
     const int head = bid % a.heads;
     const int b = bid / a.heads;

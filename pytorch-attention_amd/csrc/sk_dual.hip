@@ -369,7 +369,10 @@ int mi355_cam_fwd(const float* x, const float* beta, float* y, int B, int C, int
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_cam_fwd: H*W and C must be multiples of 4 (HW=%ld C=%d)", HW, C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* G = static_cast<float*>(workspace);                  // x_ x_^T: dual_attention.py:38
-    int rc = mi355::gemm_nt_batched(x, x, G, B, C, C, (int)HW, (int)HW, (int)HW, C, (long)C * HW, (long)C * HW, (long)C * C, precision, st);
+    // the logits are unscaled sums over HW (O(HW) on the diagonal): always the fp32-class split-bf16 mode; `precision` selects the
+    // operand format of the second product only (softmax weights in [0, 1], residual added in fp32)
+    int rc = mi355::gemm_nt_batched(x, x, G, B, C, C, (int)HW, (int)HW, (int)HW, C, (long)C * HW, (long)C * HW, (long)C * C,
+                                    MI355_PREC_STRICT, st);
     if (rc) return rc;
     softmax_rows_scaled_kernel<<<cdiv((long)B * C, 4), 256, 0, st>>>(G, C, (long)B * C, beta);      // softmax: :39, beta: :41
     rc = mi355::gemm_kn_batched(G, x, nullptr, x, y, B, C, (int)HW, C, C, (int)HW, (int)HW, (long)C * C, (long)C * HW, (long)C * HW,

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv,
     __shared__ float s_g[D * P];             // G, then A = softmax(G)
     __shared__ float s_n[2 * D];             // squared column norms of q and k (running), then the norms
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x % heads, b = blockIdx.x / heads;
+    const int lid = xcd_contiguous_block();                 // the heads of an image read adjacent column blocks of the same rows
+    const int h = lid % heads, b = lid / heads;
     const int C = heads * D;
     const long row3 = 3L * C;
     const float* base = qkv + (long)b * N * row3 + h * D;

@@ -158,7 +158,7 @@ def sk_forward(x, params, planes, groups, d):
     return y
 
 
-def cam_forward(x, beta, precision=PREC_STRICT):
+def cam_forward(x, beta, precision=None):
     x = require_device_f32(x, "x")
     B, C, H, W = x.shape
     beta = require_device_f32(beta, "beta").reshape(1)

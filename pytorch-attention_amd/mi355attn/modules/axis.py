@@ -254,7 +254,7 @@ class CAM(nn.Module):
     def __init__(self):
         super().__init__()
         self.beta = nn.Parameter(torch.zeros(1))
-        self.precision = F.PREC_STRICT
+        self.precision = None          # operand format of attn @ x; the Gram logits always run in the fp32-class mode
 
     def forward(self, x):
         return F.cam_forward(x, self.beta, self.precision)
