@@ -77,6 +77,40 @@ __global__ __launch_bounds__(256) void softmax_cols_reg_kernel(float* __restrict
 
 inline size_t r16(size_t n) { return (n + 15) & ~(size_t)15; }
 
+// x (B, C, HW) fp32 -> xt (B, HW, C) in the 16-bit operand type: the token-major activation the fast GEMM engine wants as its row operand
+// (64 x 64 tiles through LDS: 256-byte runs in, 128-byte runs out).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_tokens16_kernel(const float* __restrict__ x, T* __restrict__ xt, int C, int HW) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, t = threadIdx.x;
+    {
+        const int tx = t & 63, ty = t >> 6;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = ty * 16 + r, c = c0 + cl, p = p0 + tx;
+            tile[cl][tx] = (c < C && p < HW) ? x[((long)b * C + c) * HW + p] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int pl = t >> 2, cq = t & 3, p = p0 + pl;
+    if (p >= HW) return;
+    T* dst = xt + ((long)b * HW + p) * C + c0 + cq * 16;
+    if (c0 + cq * 16 + 16 <= C && (C & 7) == 0) {                 // two 16-byte stores of eight elements
+        typedef T v8t __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v8t o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (T)tile[cq * 16 + h * 8 + k][pl];
+            *reinterpret_cast<v8t*>(dst + h * 8) = o;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (c0 + cq * 16 + k < C) dst[k] = (T)tile[cq * 16 + k][pl];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -84,7 +118,8 @@ extern "C" {
 // workspace: Wcat (M3 x C) | bcat (M3) | ABV (B, M3, HW) | G (B, cm, cn) | M' (B, C, cn)
 size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, int W) {
     const size_t M3 = (size_t)cm + 2 * (size_t)cn, HW = (size_t)H * W;
-    return r16(M3 * C * 4) + r16(M3 * 4) + r16((size_t)B * M3 * HW * 4) + r16((size_t)B * cm * cn * 4) + r16((size_t)B * C * cn * 4);
+    return r16(M3 * C * 4) + r16(M3 * 4) + r16((size_t)B * M3 * HW * 4) + r16((size_t)B * cm * cn * 4) + r16((size_t)B * C * cn * 4) +
+           r16((size_t)B * HW * C * 2) + r16(M3 * C * 2);      // token-major 16-bit copy of x and the 16-bit weights of the fast first product
 }
 
 int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV,
@@ -111,9 +146,25 @@ int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, cons
     MI355_HIP(hipMemcpyAsync(bcat + cm, bB, (size_t)cn * 4, hipMemcpyDeviceToDevice, st));
     MI355_HIP(hipMemcpyAsync(bcat + cm + cn, bV, (size_t)cn * 4, hipMemcpyDeviceToDevice, st));
     const long sABV = (long)M3 * HW;
-    int rc = mi355::gemm_kn_batched(Wcat, x, bcat, nullptr, ABV, B, M3, HW, C, C, HW, HW, 0, (long)C * HW, sABV, MI355_ACT_NONE,
-                                    precision, st);
-    if (rc) return rc;
+    int rc;
+    if (precision != MI355_PREC_STRICT && (C & 63) == 0) {
+        // The three 1x1 convs on the 16-bit GEMM engine: x is copied once to token-major 16-bit (the engine's row operand), and the
+        // product is written back CHANNEL-major by the transposing epilogue of mi355_linear16_tr_fwd (rows per image = HW) -- the
+        // same (B, M3, HW) ABV tensor as the fp32-in path below, at a third of its time.
+        char* q = reinterpret_cast<char*>(Z) + r16((size_t)B * C * cn * 4);
+        void* xt16 = q; q += r16((size_t)B * HW * C * 2);
+        void* w16 = q;
+        const dim3 tgrid(cdiv(HW, 64), cdiv(C, 64), B);
+        if (precision == MI355_PREC_FP16) nchw_to_tokens16_kernel<_Float16><<<tgrid, 256, 0, st>>>(x, static_cast<_Float16*>(xt16), C, HW);
+        else                              nchw_to_tokens16_kernel<__bf16><<<tgrid, 256, 0, st>>>(x, static_cast<__bf16*>(xt16), C, HW);
+        rc = mi355_cast16_fwd(Wcat, w16, (size_t)M3 * C, precision, stream);
+        if (rc) return rc;
+        rc = mi355_linear16_tr_fwd(xt16, w16, bcat, nullptr, ABV, B * HW, M3, C, C, HW, precision, stream);
+        if (rc) return rc;
+    } else {
+        rc = mi355::gemm_kn_batched(Wcat, x, bcat, nullptr, ABV, B, M3, HW, C, C, HW, HW, 0, (long)C * HW, sABV, MI355_ACT_NONE, precision, st);
+        if (rc) return rc;
+    }
     {
         const long rows = (long)B * cn;
         const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
     if constexpr (TR) {
         // lane (l15, g) holds column n = j*16 + l15 and four CONSECUTIVE rows m = i*16 + g*4 + [0,4) -- consecutive channels of
         // one image (tr_rows % 4 == 0), i.e. 16 contiguous bytes of the token-major output; the four lane groups and the MF
-        // row tiles of a wave complete a 256-byte run per token
+        // row tiles of a wave complete a 256-byte run per token.  (Routing the tile through a per-wave LDS slab so that every
+        // store instruction covers whole 256-byte runs was measured SLOWER: 494 -> 647 us on the K = 256 DoubleAttention product.)
         float* Cf = static_cast<float*>(g.C);
         const int l15 = lane & 15, g4 = (lane >> 4) * 4;
 #pragma unroll
@@ -664,7 +665,7 @@ int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, c
     g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = N; g.act = MI355_ACT_NONE; g.tr_rows = rows_per_image;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool wide = N > 128;
+    const bool wide = N > 128 && ((N & 255) == 0 || (N & 127) != 0);    // N = 384: three exact 128-wide tiles instead of 256 + half-empty 256
 #define TRL(T_, BN_, WN_) gemm16_kernel<T_, false, 128, BN_, 2, WN_, true, 1, true><<<cdiv(M, 128) * cdiv(N, BN_), 2 * WN_ * 64, 0, st>>>(g)
     if (precision == MI355_PREC_FP16) { if (wide) TRL(_Float16, 256, 4); else TRL(_Float16, 128, 2); }
     else                              { if (wide) TRL(__bf16, 256, 4); else TRL(__bf16, 128, 2); }
