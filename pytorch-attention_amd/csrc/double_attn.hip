@@ -28,6 +28,39 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ p
     }
 }
 
+// The same with the row held in registers (one read + one write of the tensor instead of three reads + one write): cols % 4 == 0,
+// cols <= 256 * NV4, one wave per row, NV4 16-byte groups per lane.
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict__ p, int rows_per_img, int cols, long img_stride, long total_rows) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= total_rows) return;
+    float* row = p + (r / rows_per_img) * img_stride + (r % rows_per_img) * (long)cols;
+    const int n4 = cols >> 2;
+    f4_t v[NV4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < n4 ? *reinterpret_cast<const f4_t*>(row + i * 4) : f4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+        v[k] = f4_t{expf(v[k].x - m), expf(v[k].y - m), expf(v[k].z - m), expf(v[k].w - m)};
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n4) *reinterpret_cast<f4_t*>(row + i * 4) = v[k] / s;
+    }
+}
+
 // in-place softmax over the channel axis: element (b, j, p) at base + b*img_stride + j*HW + p, j < cn
 __global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ p, int cn, int HW, long img_stride, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -168,7 +201,11 @@ int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, cons
     {
         const long rows = (long)B * cn;
         const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
-        softmax_rows_kernel<<<grid, 256, 0, st>>>(ABV + (long)cm * HW, cn, HW, sABV, rows);
+        float* Bp = ABV + (long)cm * HW;
+        if (HW <= 1024)      softmax_rows_reg_kernel<4><<<cdiv(rows, 4), 256, 0, st>>>(Bp, cn, HW, sABV, rows);      // HW % 4 == 0 checked above
+        else if (HW <= 2048) softmax_rows_reg_kernel<8><<<cdiv(rows, 4), 256, 0, st>>>(Bp, cn, HW, sABV, rows);
+        else if (HW <= 4096) softmax_rows_reg_kernel<16><<<cdiv(rows, 4), 256, 0, st>>>(Bp, cn, HW, sABV, rows);
+        else                 softmax_rows_kernel<<<grid, 256, 0, st>>>(Bp, cn, HW, sABV, rows);
         const long total = (long)B * HW;
         float* Vp = ABV + (long)(cm + cn) * HW;
         if (cn <= 64)       softmax_cols_reg_kernel<16><<<cdiv(total, 64), 256, 0, st>>>(Vp, cn, HW, sABV, total);
