@@ -180,6 +180,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         }
     }
     }
+    if constexpr (LEPE) {                                         // the zero column that out-of-window LePE taps read (VP = TK + 4)
+        for (int q = t; q < NS * D; q += NTHR) s_v[(q / D) * V_EL + (q % D) * VP + TK] = 0;
+    }
     __syncthreads();
 
     // ---- phase B: each wave owns 16-query tiles ------------------------------------------------------------------------
@@ -292,36 +295,46 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
 #pragma unroll
         for (int r = 0; r < 4; ++r) inv[r] = 1.0f / __shfl(sum, g * 4 + r, WAVE);
 #pragma unroll
-        for (int nt = 0; nt < D / 16; ++nt)
+        for (int r = 0; r < 4; ++r) {
+            // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo.  The nine tap positions
+            // of a query slot do not depend on the channel: they are resolved once per slot, a tap outside the window pointing at the
+            // zero column TK of the V^T tile (written during staging) -- no bounds logic in the per-channel loop.
+            int off[LEPE ? 9 : 1];
+            bool qlive = false;
+            if constexpr (LEPE) {
+                const int qslot = qt * 16 + g * 4 + r;
+                qlive = qslot < T;
+                const int ty = srow(qlive ? qslot : 0), tx = (qlive ? qslot : 0) - ty * a.Wsp;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int yy = ty + dy, xx = tx + dx;
+                        off[(dy + 1) * 3 + dx + 1] = (yy >= 0 && yy < a.Hsp && xx >= 0 && xx < a.Wsp) ? yy * a.Wsp + xx : TK;
+                    }
+            }
+#pragma unroll
+            for (int nt = 0; nt < D / 16; ++nt) {
                 float val = o[nt][r] * inv[r];
                 if constexpr (LEPE) {
-                    // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo
-                    const int qslot = qt * 16 + g * 4 + r;
-                    if (qslot < T) {
+                    if (qlive) {
                         const int d = nt * 16 + l15;                              // channel inside this head
-                        const int ty = srow(qslot), tx = qslot - ty * a.Wsp;
                         const float* lwp = s_lw + d * 10;
+                        const unsigned short* vrow = s_v + d * VP;
                         float acc = lwp[9];
 #pragma unroll
-                        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                            for (int dx = -1; dx <= 1; ++dx) {
-                                const int yy = ty + dy, xx = tx + dx;
-                                if (yy >= 0 && yy < a.Hsp && xx >= 0 && xx < a.Wsp) {
-                                    const int ss = yy * a.Wsp + xx;
-                                    float vv = (float)(*reinterpret_cast<const el*>(s_v + d * VP + ss));
-                                    if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(s_v + V_EL + d * VP + ss));
-                                    acc += lwp[(dy + 1) * 3 + dx + 1] * vv;
-                                }
-                            }
+                        for (int i = 0; i < 9; ++i) {
+                            float vv = (float)(*reinterpret_cast<const el*>(vrow + off[i]));
+                            if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(vrow + V_EL + off[i]));
+                            acc += lwp[i] * vv;
+                        }
                         val += acc;
                     }
                 }
                 if constexpr (IO16) *reinterpret_cast<el*>(slab + (g * 4 + r) * OP + nt * 16 + l15) = M_::cvt1(val);
                 else slab[(g * 4 + r) * OP + nt * 16 + l15] = val;
             }
+        }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // row-contiguous stores: 16 bytes per lane
