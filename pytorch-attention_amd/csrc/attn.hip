@@ -18,6 +18,7 @@
 // HBM traffic per call = read qkv once + write out once (the isolated core is HBM-bound: SURVEY.md 8d).
 #include "common.h"
 #include "mma.h"
+#include "bufops.h"
 #include <type_traits>
 
 namespace {
@@ -89,16 +90,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
     // ---- everything this wave will need from HBM is requested up front (one memory latency per workgroup): its Q fragments
     //      (16-bit I/O path), its LePE taps, then the K / V staging loads below --------------------------------------------------
     constexpr int NQ = (KT + NW - 1) / NW;                         // query tiles per wave
+    // 16-bit I/O: q / k / v of this image go through one raw buffer descriptor; slots past T get an out-of-range offset and come back
+    // as zeros from the hardware range check (no zero-fill moves, no branches around the loads)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const rsrc_t img_rs = make_rsrc(IO16 ? static_cast<const void*>(base) : nullptr, IO16 ? (bufops_u32)((long)a.L * row3 * sizeof(gel)) : 0u);
+    auto ld16 = [&](bool live, int token, int el_off) -> v8 {      // 8 elements of a token row, el_off relative to this head's q slice
+        const bufops_u32 off = live ? (bufops_u32)((token * (int)row3 + el_off) * 2) : OOB;
+        return __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(img_rs, off, 0, 0));
+    };
     v8 qraw[IO16 ? NQ : 1][D / 32];
     if constexpr (IO16) {
 #pragma unroll
         for (int iq = 0; iq < NQ; ++iq) {
             const int qs = (wave + iq * NW) * 16 + l15;
+            const int tq = tok(qs < T ? qs : 0);
 #pragma unroll
-            for (int ks = 0; ks < D / 32; ++ks) {
-                qraw[iq][ks] = v8{};
-                if (qs < T) qraw[iq][ks] = *reinterpret_cast<const v8*>(base + (long)tok(qs) * row3 + ks * 32 + g * 8);
-            }
+            for (int ks = 0; ks < D / 32; ++ks) qraw[iq][ks] = ld16(qs < T, tq, ks * 32 + g * 8);
         }
     }
     // LePE taps + bias of this head's D channels: parked in LDS ([channel][10]) instead of 20 registers per lane
@@ -117,14 +124,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         // then written to LDS: K as is, V through a 4(key) x 8(d) register transpose
         constexpr int D8 = D / 8;
         constexpr int NKI = (TK * D8 + NTHR - 1) / NTHR, NVI = ((TK / 4) * D8 + NTHR - 1) / NTHR;
-        const v8 zero8 = {};
         v8 kreg[NKI];
         v8 vreg[NVI][4];
 #pragma unroll
         for (int it = 0; it < NKI; ++it) {
             const int idx = t + it * NTHR, key = idx / D8, d8 = idx % D8;
-            kreg[it] = zero8;
-            if (idx < TK * D8 && key < T) kreg[it] = *reinterpret_cast<const v8*>(base + (long)tok(key) * row3 + a.Ctot + d8 * 8);
+            const bool live = idx < TK * D8 && key < T;
+            kreg[it] = ld16(live, tok(live ? key : 0), a.Ctot + d8 * 8);
         }
 #pragma unroll
         for (int it = 0; it < NVI; ++it) {
@@ -132,9 +138,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int key = kg * 4 + j;
-                vreg[it][j] = zero8;
-                if (idx < (TK / 4) * D8 && key < T)
-                    vreg[it][j] = *reinterpret_cast<const v8*>(base + (long)tok(key) * row3 + 2 * a.Ctot + d8 * 8);
+                const bool live = idx < (TK / 4) * D8 && key < T;
+                vreg[it][j] = ld16(live, tok(live ? key : 0), 2 * a.Ctot + d8 * 8);
             }
         }
 #pragma unroll
@@ -219,9 +224,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         }
         // S^T tiles: lane holds S^T[key = kt*16 + g*4 + r][q = l15]
         f4 s[KT];
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            s[kt] = f4{0.f, 0.f, 0.f, 0.f};
+            f4 acc = zero4;                                       // first MFMA of the chain takes the constant as its C operand
             if (kt * 16 < T) {
 #pragma unroll
                 for (int ks = 0; ks < D / 32; ++ks) {
@@ -229,12 +235,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
 #pragma unroll
                     for (int sp = 0; sp < NS; ++sp)
                         kf[sp] = *reinterpret_cast<const v8*>(s_k + sp * K_EL + (kt * 16 + l15) * KP + ks * 32 + g * 8);
-                    s[kt] = mma_step<PREC>(kf, qf[ks], s[kt]);
+                    acc = mma_step<PREC>(kf, qf[ks], acc);
                 }
             }
+            s[kt] = acc;
         }
         // softmax over keys (masked beyond T)
-        // logits are kept in log2 units: p = 2^(s*scale*log2(e) - max) == exp(s*scale - max) on the v_exp_f32 unit
+        // logits are kept in log2 units: p = 2^(s*scale*log2(e) - max) == exp(s*scale - max) on the v_exp_f32 unit.  The product is
+        // rounded BEFORE the maximum is subtracted (not fused into one FMA): the row maximum then maps to exactly 2^0, which the
+        // bit-exact index tests rely on (one-hot attention must reproduce V rows exactly).
         const float post = (a.pre_scale ? 1.0f : a.scale) * 1.44269504088896340736f;
         float m = -INFINITY;
 #pragma unroll
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         // O = P.V : A = P (row q = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = V^T same enumeration
         f4 o[D / 16];
 #pragma unroll
-        for (int nt = 0; nt < D / 16; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < D / 16; ++nt) o[nt] = zero4;
 #pragma unroll
         for (int kb = 0; kb < KT / 2; ++kb) {
             if (kb * 32 < T) {
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         // normalise: o[nt][r] belongs to query row g*4 + r, whose row sum lives in lanes with l15 == g*4 + r
         float inv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) inv[r] = 1.0f / __shfl(sum, g * 4 + r, WAVE);
+        for (int r = 0; r < 4; ++r) inv[r] = __builtin_amdgcn_rcpf(__shfl(sum, g * 4 + r, WAVE));   // 1 ulp; the result is rounded to 16 bit or scaled once
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo.  The nine tap positions
