@@ -44,7 +44,9 @@ __device__ __forceinline__ bool gran_get(rsrc_t g, u32 idx, float& v0, float& v1
 // row_ror for the rotations inside a row of 16 lanes.
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    // old = the source itself and bound_ctrl set: every lane of these permutations has a valid source, so no "old" value has to be
+    // materialised and the compiler can fold the permutation into the consuming add / max as a DPP modifier
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float rdlane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -56,11 +58,10 @@ __device__ __forceinline__ void seg_reduce(float& s, float& m, int lane) {
     s += dpp<0x4E>(s);  m = fmaxf(m, dpp<0x4E>(m));                   // xor 2
     s += dpp<0x124>(s); m = fmaxf(m, dpp<0x124>(m));                  // row_ror 4
     s += dpp<0x128>(s); m = fmaxf(m, dpp<0x128>(m));                  // row_ror 8: every lane of the row holds the row total
-    if (SEG == 32) {                                                  // rows 0+1 -> lane 0, rows 2+3 -> lane 32
-        const float s0 = rdlane(s, 0), s1 = rdlane(s, 16), s2 = rdlane(s, 32), s3 = rdlane(s, 48);
-        const float m0 = rdlane(m, 0), m1 = rdlane(m, 16), m2 = rdlane(m, 32), m3 = rdlane(m, 48);
-        s = (lane < 32) ? (s0 + s1) : (s2 + s3);
-        m = (lane < 32) ? fmaxf(m0, m1) : fmaxf(m2, m3);
+    if (SEG == 32) {                                                  // rows 0+1 -> lane 0, rows 2+3 -> lane 32 (only those two lanes are used)
+        const float s1 = rdlane(s, 16), s3 = rdlane(s, 48), m1 = rdlane(m, 16), m3 = rdlane(m, 48);
+        s += (lane < 32) ? s1 : s3;
+        m = fmaxf(m, (lane < 32) ? m1 : m3);
     }
 }
 
