@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                         for (int i = 0; i < 9; ++i) {
                             float vv = (float)(*reinterpret_cast<const el*>(vrow + off[i]));
                             if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(vrow + V_EL + off[i]));
-                            acc += lwp[i] * vv;
+                            acc = __builtin_fmaf(lwp[i], vv, acc);
                         }
                         val += acc;
                     }
