@@ -185,8 +185,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         }
     }
     }
-    if constexpr (LEPE) {                                         // the zero column that out-of-window LePE taps read (VP = TK + 4)
+    // LePE geometry, resolved ONCE per workgroup: byte offset (inside a V^T row) of each of the nine taps of every query slot; a tap
+    // outside the window points at the zero column TK (VP = TK + 4), so the per-channel loop below carries no bounds logic
+    __shared__ unsigned short s_tap[LEPE ? TK * 9 : 1];
+    if constexpr (LEPE) {
         for (int q = t; q < NS * D; q += NTHR) s_v[(q / D) * V_EL + (q % D) * VP + TK] = 0;
+        for (int q = t; q < T * 9; q += NTHR) {
+            const int slot = q / 9, tap = q - slot * 9;
+            const int ty = srow(slot), tx = slot - ty * a.Wsp;
+            const int yy = ty + tap / 3 - 1, xx = tx + tap % 3 - 1;
+            s_tap[q] = (unsigned short)(((yy >= 0 && yy < a.Hsp && xx >= 0 && xx < a.Wsp) ? yy * a.Wsp + xx : TK) * 2);
+        }
     }
     __syncthreads();
 
@@ -305,22 +314,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         for (int r = 0; r < 4; ++r) inv[r] = __builtin_amdgcn_rcpf(__shfl(sum, g * 4 + r, WAVE));   // 1 ulp; the result is rounded to 16 bit or scaled once
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo.  The nine tap positions
-            // of a query slot do not depend on the channel: they are resolved once per slot, a tap outside the window pointing at the
-            // zero column TK of the V^T tile (written during staging) -- no bounds logic in the per-channel loop.
+            // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo; tap offsets from s_tap
             int off[LEPE ? 9 : 1];
             bool qlive = false;
             if constexpr (LEPE) {
                 const int qslot = qt * 16 + g * 4 + r;
                 qlive = qslot < T;
-                const int ty = srow(qlive ? qslot : 0), tx = (qlive ? qslot : 0) - ty * a.Wsp;
+                const unsigned short* tp = s_tap + (qlive ? qslot : 0) * 9;
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int yy = ty + dy, xx = tx + dx;
-                        off[(dy + 1) * 3 + dx + 1] = (yy >= 0 && yy < a.Hsp && xx >= 0 && xx < a.Wsp) ? yy * a.Wsp + xx : TK;
-                    }
+                for (int i = 0; i < 9; ++i) off[i] = tp[i];
             }
 #pragma unroll
             for (int nt = 0; nt < D / 16; ++nt) {
@@ -329,12 +331,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                     if (qlive) {
                         const int d = nt * 16 + l15;                              // channel inside this head
                         const float* lwp = s_lw + d * 10;
-                        const unsigned short* vrow = s_v + d * VP;
+                        const char* vrow = reinterpret_cast<const char*>(s_v + d * VP);
                         float acc = lwp[9];
 #pragma unroll
                         for (int i = 0; i < 9; ++i) {
                             float vv = (float)(*reinterpret_cast<const el*>(vrow + off[i]));
-                            if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(vrow + V_EL + off[i]));
+                            if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(vrow + V_EL * 2 + off[i]));
                             acc = __builtin_fmaf(lwp[i], vv, acc);
                         }
                         val += acc;
