@@ -130,6 +130,11 @@ CONVS = [  # B, Cin, H, W, Cout, k, stride, pad
     (3, 256, 14, 14, 512, 3, 2, 1),       # Merge_Block 3: 14 -> 7
     (1, 5, 9, 11, 20, 3, 1, 1),           # ragged: odd sizes, stride 1, Cin not a multiple of 4
     (2, 8, 6, 6, 12, 3, 2, 0),            # no padding
+    # the image layer of a narrow stem runs on the direct fp32 kernel (stem_conv.hip) when the input is NCHW
+    (2, 3, 224, 224, 16, 3, 2, 1),        # XCiT ConvPatchEmbed layer 1 (xcit.py:97)
+    (3, 3, 17, 23, 24, 3, 1, 1),          # odd output width (second pixel of the last pair missing), COUT = 32 template
+    (1, 4, 9, 9, 20, 5, 2, 2),            # 4 input channels, 5x5
+    (2, 1, 12, 10, 64, 3, 1, 0),          # single channel, 64 outputs, no padding
 ]
 
 
@@ -736,3 +741,23 @@ def test_axis_gates_reject_training_mode_and_bad_shapes():
             m.cuda().train()(x)
     with pytest.raises(ValueError):
         CoordinateAttention(32, 16).cuda().eval()(x)
+
+
+def test_stem_direct_option_switches_between_two_agreeing_paths():
+    import mi355attn
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, 40, 36).cuda()
+    w = torch.nn.Parameter((torch.randn(16, 3, 3, 3) / 5).cuda())
+    b, pos = torch.randn(16).cuda(), torch.randn(20 * 18, 16).cuda()
+    f = F()
+    assert mi355attn.get_option("stem_direct") == 1
+    direct, _ = f.conv2d_tokens(x, w, b, 3, 2, 1, 0, precision=0, act=f.ACT_GELU, pos=pos)
+    mi355attn.set_option("stem_direct", 0)
+    try:
+        gemm, _ = f.conv2d_tokens(x, w, b, 3, 2, 1, 0, precision=0, act=f.ACT_GELU, pos=pos)
+    finally:
+        mi355attn.set_option("stem_direct", 1)
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=2, padding=1).flatten(2).transpose(1, 2)
+    ref = gelu64(ref + pos.double().cpu())
+    assert_parity(direct.cpu(), ref.float(), 5e-6, "direct stem conv")
+    assert_parity(gemm.cpu(), ref.float(), TOL[0], "implicit-GEMM stem conv")
