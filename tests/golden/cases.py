@@ -116,6 +116,16 @@ CASES = [
          prep="perturb_all", oracle=lambda x, sd, dt: O.bam_forward(x, sd, 4, dt)),
     dict(id="triplet_tall", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", kwargs=dict(kernel_size=3),
          shape=(2, 12, 70, 6), prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    # fallback paths of the axis kernels: planes too large for the LDS pooling kernel, kernel sizes without a specialisation, the widest
+    # reduced width of BAM, SK groups wider than the LDS-tiled kernel takes
+    dict(id="coord_bigplane", mod="attention_mechanisms.coordatten", cls="CoordinateAttention", args=(32, 32), shape=(1, 32, 130, 132),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.coordatt_forward(x, sd, dt)),
+    dict(id="triplet_bigplane_k9", mod="attention_mechanisms.triplet_attention", cls="TripletAttention", kwargs=dict(kernel_size=9),
+         shape=(1, 8, 132, 130), prep="perturb_all", oracle=lambda x, sd, dt: O.triplet_forward(x, sd, dt)),
+    dict(id="bam512", mod="attention_mechanisms.bam", cls="BAM", args=(512,), shape=(2, 512, 12, 12),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.bam_forward(x, sd, 4, dt)),
+    dict(id="sk_wide_groups", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(64, 512), shape=(2, 64, 8, 12),
+         prep="perturb_all", oracle=lambda x, sd, dt: O.sk_forward(x, sd, 32, dt)),
     dict(id="sk64", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(64, 64), shape=(2, 64, 32, 32), small=True,
          prep="perturb_all", oracle=lambda x, sd, dt: O.sk_forward(x, sd, 32, dt)),
     dict(id="sk256", mod="attention_mechanisms.sk_module", cls="SKLayer", args=(256, 256), shape=(4, 256, 56, 56),

@@ -21,7 +21,8 @@ VECTOR_ONLY = {"se64", "cbam64", "eca64", "se256", "cbam256", "eca256", "simam64
                "simam256", "srm256", "gctg256", "lct256", "gct256", "se_effnet", "se_mnasnet", "se_mbv3", "se_ghost"}
 # fp32 vector math as well, but with longer dependent chains (convolutions, LayerNorm / BatchNorm of reduced vectors): 3e-5
 VECTOR_CHAINS = {"gc64", "coord64", "triplet64", "triplet_k5", "bam64", "gc256", "coord256", "coord_ragged", "triplet256", "bam256",
-                 "gc_ragged", "bam_ragged", "triplet_tall", "sk64", "sk256", "sk_ragged"}
+                 "gc_ragged", "bam_ragged", "triplet_tall", "sk64", "sk256", "sk_ragged", "coord_bigplane", "triplet_bigplane_k9",
+                 "bam512", "sk_wide_groups"}
 # DANet's position attention uses UNSCALED dot-product logits (dual_attention.py:26): operand rounding is amplified by the logit
 # magnitude, so even the split-bf16 mode is only held to the 1e-3 parity tolerance
 UNSCALED_LOGITS = {"pam64", "pam64_ragged"}
