@@ -46,7 +46,10 @@ struct AttnPair {
 
 // OCC: workgroups per CU the register allocation is asked to leave room for.  The window kernels are latency-bound (a workgroup does
 // one memory round trip, a few dozen MFMAs, one store), so resident workgroups per CU are the throughput lever.
-template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW, int OCC = 1>
+// TFULL: number of key tiles known at compile time to lie entirely below T (the hot shapes are dispatched with it: 197 -> 12,
+// 98 -> 6, 56 / 49 -> 3); their scores skip the key-validity mask (two of ~17 VALU instructions per score in a VALU-bound kernel).
+// -1 = unknown, every tile is masked.
+template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW, int OCC = 1, int TFULL = -1>
 __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair pr) {
     // XCD-aware block order: hardware hands consecutive block ids to the 8 XCDs round-robin, but consecutive LOGICAL ids are the heads
     // of one window, whose q / k / v slices are adjacent 64-byte (d = 32) pieces of the same token rows -- neighbours that should
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + g * 4 + r;
-                const float v = (key < T) ? s[kt][r] * post : -INFINITY;
+                const float v = (kt < TFULL || key < T) ? s[kt][r] * post : -INFINITY;      // kt < TFULL folds at compile time
                 s[kt][r] = v;
                 m = fmaxf(m, v);
             }
@@ -389,11 +392,14 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
         return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
 #define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(pr)
 #define GO_OCC(P, KT_, NW_, OCC_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, ((IO16 && P != 0 && D == 32) ? OCC_ : 1)><<<grid, NW_ * 64, 0, st>>>(pr)
+#define GO_FULL(P, KT_, NW_, OCC_, TF_) \
+    win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, ((IO16 && P != 0 && D == 32) ? OCC_ : 1), TF_><<<grid, NW_ * 64, 0, st>>>(pr)
+    const bool hot = IO16 && (!other || other->T == a.T);        // 16-bit I/O shapes of the models: compile-time count of full key tiles
 #define BYKT(P)                                          \
     do {                                                 \
-        if (a.T <= 64) GO_OCC(P, 4, 4, 6);               \
-        else if (a.T <= 128) GO_OCC(P, 8, 4, 6);         \
-        else if (IO16 && P != 0) GO(P, 14, 8);           \
+        if (a.T <= 64) { if (hot && P != 0 && a.T >= 48) GO_FULL(P, 4, 4, 6, 3); else GO_OCC(P, 4, 4, 6); }          \
+        else if (a.T <= 128) { if (hot && P != 0 && a.T >= 96) GO_FULL(P, 8, 4, 6, 6); else GO_OCC(P, 8, 4, 6); }    \
+        else if (IO16 && P != 0) { if (a.T >= 192) GO_FULL(P, 14, 8, 1, 12); else GO(P, 14, 8); }                    \
         else GO(P, 14, 4);                               \
     } while (0)
     switch (precision) {
@@ -403,6 +409,7 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
         default: return mi355::fail(MI355_EINVAL, "precision must be 0, 1 or 2 (got %d)", precision);
     }
 #undef BYKT
+#undef GO_FULL
 #undef GO_OCC
 #undef GO
     return MI355_OK;
