@@ -288,6 +288,12 @@ int mi355_layernorm16_t_fwd(const float* x, const float* weight, const float* bi
                             int precision, mi355_stream_t stream);
 int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K,
                           int ldx, int rows_per_image, int precision, mi355_stream_t stream);
+/* LayerNorm + Linear in one pass for narrow rows (K = 64 or 128 = the normalised width; CSWin stage 1 / 2 and XCiT-nano qkv):
+ *   Y = act( ((x - mean) / sqrt(var + eps)) . W16^T + bias ),  x (M,K) fp32 with row stride ldx floats, Y fp32 or 16-bit (out16).
+ * The LayerNorm affine part must be folded into W16 / bias by the caller (W' = W diag(ln_weight), b' = b + W ln_bias).  The rows are
+ * normalised on their way into LDS, so the 16-bit LayerNorm output never exists in HBM.  N % 8 == 0. */
+int mi355_ln_linear16_fwd(const float* X, const void* W16, const float* bias, void* Y, int M, int N, int K, int ldx, int ldy, float eps,
+                          int act, int out16, int precision, mi355_stream_t stream);
 /* mi355_sdpa_fwd / mi355_cswin_lepe_attn_fwd with 16-bit qkv and out buffers (same layouts). */
 int mi355_sdpa16_fwd(const void* qkv16, void* out16, int B, int N, int heads, int d, float scale, int precision,
                      mi355_stream_t stream);

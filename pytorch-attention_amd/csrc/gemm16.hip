@@ -25,6 +25,8 @@ struct G16Args {
     int M, N, K, lda, ldb, ldc;
     int act;
     int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
+    const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
+    float ln_eps;
 };
 
 template <typename T> struct Vec8;
@@ -413,8 +415,11 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
 // 8 waves; wave grid (8/WN) x WN with WN = BN/64, i.e. every wave owns (128*WN/8) rows x 64 columns.
 // LDS images are [k-chunk of 64][row][64] panels with the same source-side XOR swizzle as above.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <typename T, bool OUT16, int BN, int KK>
-__global__ __launch_bounds__(512, (KK == 64 ? 4 : 2)) void gemm16_ws_kernel(const G16Args g, int workers) {
+// LNA = true: the row operand is the LayerNorm of fp32 rows (K = the normalised width): a thread loads a quarter of a row, the four
+// lanes of a row reduce mean and variance, and the normalised 16-bit values go into the same swizzled LDS image the DMA would have
+// produced.  The LayerNorm affine part is expected folded into W / bias by the caller (W' = W diag(gamma), b' = b + W beta).
+template <typename T, bool OUT16, int BN, int KK, bool LNA = false>
+__global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws_kernel(const G16Args g, int workers) {
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
     constexpr int BM = 128, KC = KK / 64;
@@ -454,17 +459,60 @@ __global__ __launch_bounds__(512, (KK == 64 ? 4 : 2)) void gemm16_ws_kernel(cons
         }
     };
 
+    // LNA staging: thread -> (row = t / 4, quarter of the row); PT floats per thread
+    constexpr int PT = BM * KK / 512;
+    const int arow = t >> 2, aq = t & 3;
+    f4 xr[LNA ? PT / 4 : 1];
+    auto load_a = [&](int mt) {
+        int ma = mt * BM + arow; if (ma >= g.M) ma = g.M - 1;
+        const float* p = g.Af + (long)ma * g.lda + aq * PT;
+#pragma unroll
+        for (int i = 0; i < PT / 4; ++i) xr[i] = *reinterpret_cast<const f4*>(p + i * 4);
+    };
+    auto commit_a = [&](int buf) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PT / 4; ++i) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+        s += __shfl_xor(s, 1, WAVE);
+        s += __shfl_xor(s, 2, WAVE);
+        const float mean = s * (1.0f / (float)KK);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < PT / 4; ++i) {
+            const f4 d = xr[i] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        q += __shfl_xor(q, 1, WAVE);
+        q += __shfl_xor(q, 2, WAVE);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / (float)KK) + g.ln_eps);
+#pragma unroll
+        for (int j = 0; j < PT / 8; ++j) {
+            const int k0 = aq * PT + j * 8, kc = k0 / 64, ch = (k0 % 64) / 8;
+            const f4 a0 = (xr[2 * j] - mean) * rstd, a1 = (xr[2 * j + 1] - mean) * rstd;
+            *reinterpret_cast<v8*>(sAb + buf * A_EL + (kc * BM + arow) * 64 + ((ch ^ (arow & 7)) * 8)) =
+                v8{(T)a0.x, (T)a0.y, (T)a0.z, (T)a0.w, (T)a1.x, (T)a1.y, (T)a1.z, (T)a1.w};
+        }
+    };
+
     const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7, l15 = frow, g4 = fq * 4;
     float* Cf = static_cast<float*>(g.C);
     T* Ch = static_cast<T*>(g.C);
 
     int mt = worker;
-    if (mt < tiles_m) issue_a(0, mt);
+    if constexpr (LNA) {
+        if (mt < tiles_m) { load_a(mt); commit_a(0); }
+    } else {
+        if (mt < tiles_m) issue_a(0, mt);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int it = 0; mt < tiles_m; mt += workers, ++it) {
         const int cur = it & 1;
-        if (mt + workers < tiles_m) issue_a(cur ^ 1, mt + workers);          // next tile flies under this tile's math
+        if constexpr (LNA) {
+            if (mt + workers < tiles_m) load_a(mt + workers);                    // next tile's rows fly into registers under this tile's math
+        } else {
+            if (mt + workers < tiles_m) issue_a(cur ^ 1, mt + workers);          // next tile flies under this tile's math
+        }
         f4 acc[MF][NF];
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -487,6 +535,9 @@ __global__ __launch_bounds__(512, (KK == 64 ? 4 : 2)) void gemm16_ws_kernel(cons
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[i][j] = mma16<T>(fb[j], fa[i], acc[i][j]);   // transposed tiles, see above
             }
+        }
+        if constexpr (LNA) {
+            if (mt + workers < tiles_m) commit_a(cur ^ 1);                        // normalise + park the next tile (buffer cur^1 was last read one barrier ago)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // next A tile landed (and older stores retired)
         __syncthreads();                                                      // ... for every wave; buffer `cur` is free again
@@ -670,6 +721,40 @@ int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, c
     if (precision == MI355_PREC_FP16) { if (wide) TRL(_Float16, 256, 4); else TRL(_Float16, 128, 2); }
     else                              { if (wide) TRL(__bf16, 256, 4); else TRL(__bf16, 128, 2); }
 #undef TRL
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+int mi355_ln_linear16_fwd(const float* X, const void* W16, const float* bias, void* Y, int M, int N, int K, int ldx, int ldy, float eps,
+                          int act, int out16, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X && W16 && Y && M > 0 && N > 0 && ldx >= K && ldy >= N);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!(K == 64 || K == 128) || (N & 7) || (ldx & 3) || (ldy & 7) || !aligned16(X) || !aligned16(W16) || !aligned16(Y) || (bias && !aligned16(bias)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_ln_linear16_fwd: built for K = 64 / 128, N %% 8 == 0, 16-byte aligned rows (K=%d N=%d)", K, N);
+    G16Args g{};
+    g.Af = X; g.B = W16; g.C = Y; g.bias = bias; g.ln_eps = eps;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int ncu = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int bn = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    const int tiles_n = cdiv(N, bn), tiles_m = cdiv(M, 128);
+    int workers = (ncu * 2) / tiles_n;
+    if (workers < 1) workers = 1;
+    if (workers > tiles_m) workers = tiles_m;
+    const int grid = tiles_n * workers;
+#define WSL(T_, O_, BN_, KK_) gemm16_ws_kernel<T_, O_, BN_, KK_, true><<<grid, 512, 0, st>>>(g, workers)
+#define WSL_BY_SHAPE(T_, O_)                                                   \
+    do {                                                                       \
+        if (K == 64) { if (bn == 256) WSL(T_, O_, 256, 64); else if (bn == 128) WSL(T_, O_, 128, 64); else WSL(T_, O_, 64, 64); }    \
+        else         { if (bn == 256) WSL(T_, O_, 256, 128); else if (bn == 128) WSL(T_, O_, 128, 128); else WSL(T_, O_, 64, 128); } \
+    } while (0)
+    if (precision == MI355_PREC_FP16) { if (out16) WSL_BY_SHAPE(_Float16, true); else WSL_BY_SHAPE(_Float16, false); }
+    else                              { if (out16) WSL_BY_SHAPE(__bf16, true); else WSL_BY_SHAPE(__bf16, false); }
+#undef WSL_BY_SHAPE
+#undef WSL
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

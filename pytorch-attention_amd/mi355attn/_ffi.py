@@ -55,6 +55,7 @@ SIGNATURES = {
     "mi355_patch_embed_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
     "mi355_cast16_fwd": (c_int, [c_vp, c_vp, c_size, c_int, c_vp]),
     "mi355_layernorm16_fwd": (c_int, [c_vp] * 4 + [c_int, c_int, c_float, c_int, c_vp]),
+    "mi355_ln_linear16_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_float, c_int, c_int, c_int, c_vp]),
     "mi355_layernorm16_t_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [c_float, c_int, c_vp]),
     "mi355_linear16_tr_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),
     "mi355_linear16_fwd": (c_int, [c_vp] * 6 + [c_int] * 8 + [c_vp]),

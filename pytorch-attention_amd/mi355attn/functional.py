@@ -488,6 +488,35 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None):
     return y
 
 
+def ln_linear16_ok(K, N, precision=None):
+    """Shape / precision envelope of mi355_ln_linear16_fwd."""
+    return _prec(precision) in (PREC_FP16, PREC_BF16) and K in (64, 128) and N % 8 == 0
+
+
+def ln_linear16(x, ln, lin, act=ACT_NONE, out16=True, precision=None):
+    """act(lin(ln(x))) with the LayerNorm applied on the way into the GEMM (no 16-bit LayerNorm tensor in HBM).  The LayerNorm affine
+    part is folded into the Linear here (W' = W diag(ln.weight), b' = b + W ln.bias), cached per parameter version."""
+    p = _prec(precision)
+    x = require_device_f32(x, "x")
+    K = x.shape[-1]
+    N = lin.weight.shape[0]
+
+    def build():
+        w = lin.weight.detach()
+        b = lin.bias.detach() if lin.bias is not None else torch.zeros(N, dtype=torch.float32, device=w.device)
+        b = b + w @ ln.bias.detach()
+        return cast16((w * ln.weight.detach()[None, :]).contiguous(), p), b.contiguous()
+
+    parts = [lin.weight] + ([] if lin.bias is None else [lin.bias]) + [ln.weight, ln.bias]
+    tag = tuple((t._version, t.data_ptr()) for t in parts)
+    w16, b = _derived_get((lin, ln), ("ln_linear16", p), tag, build)
+    M = x.numel() // K
+    y = torch.empty(*x.shape[:-1], N, dtype=dtype16(p) if out16 else torch.float32, device=x.device)
+    check(lib().mi355_ln_linear16_fwd(dptr(x), dptr(w16), dptr(b), dptr(y), M, N, K, K, N, float(ln.eps), act, 1 if out16 else 0, p,
+                                      stream_ptr(x.device)), "mi355_ln_linear16_fwd")
+    return y
+
+
 def layernorm16(x, weight, bias, eps=1e-5, precision=None):
     x = require_device_f32(x, "x")
     weight = require_device_f32(weight, "weight")

@@ -96,8 +96,11 @@ class CSWinBlock(nn.Module):
         p = F._prec(self.precision)
         fast = _fast(p, self.qkv, self.proj, self.mlp.fc1, self.mlp.fc2) and self.attns[0].dim // self.attns[0].num_heads == 32
         if fast:                     # LN -> qkv -> attention -> proj with every GEMM operand kept 16-bit in HBM
-            u = F.layernorm16(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
-            qkv = F.linear16(u, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
+            if F.ln_linear16_ok(C, 3 * C, p):        # narrow stages: LayerNorm applied on the way into the qkv GEMM
+                qkv = F.ln_linear16(x, self.norm1, self.qkv, out16=True, precision=p)
+            else:
+                u = F.layernorm16(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
+                qkv = F.linear16(u, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
             att = torch.empty(B, L, C, dtype=qkv.dtype, device=x.device)
         else:
             u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)

@@ -61,11 +61,16 @@ class XCA(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.precision = precision
 
-    def forward(self, x, gamma=None, resid=None):
+    def forward(self, x, gamma=None, resid=None, ln=None):
+        """`ln`: the LayerNorm in front of the block (XCABlock passes norm1 with the un-normalised x) -- applied on the way into the qkv
+        GEMM when the width allows (functional.ln_linear16), else by the caller."""
         if _fast(self.precision, self.qkv, self.proj):
             p = F._prec(self.precision)      # GEMMs on 16-bit operands; the d x d covariance core itself is exact fp32
-            x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
-            qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, precision=p)
+            if ln is not None:
+                qkv = F.ln_linear16(x, ln, self.qkv, out16=False, precision=p)
+            else:
+                x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
+                qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, precision=p)
             ctx = F.xca_core(qkv, self.temperature, self.num_heads, precision=p)
             return F.linear16(F.cast16(ctx, p), F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid,
                               precision=p)
@@ -102,7 +107,10 @@ class XCABlock(nn.Module):
                 return F.layernorm16(t, ln.weight, ln.bias, ln.eps, p)
             return F.layernorm(t, ln.weight, ln.bias, ln.eps)
 
-        x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
+        if fast and F.ln_linear16_ok(x.shape[-1], 3 * x.shape[-1], p):
+            x = self.attn(x, gamma=self.gamma1, resid=x, ln=self.norm1)               # LayerNorm fused into the qkv GEMM
+        else:
+            x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
         x = self.local_mp(norm(self.norm3, x, False), H, W, gamma=self.gamma3, resid=x)
         if fast and F.mlp_fused_ok(x.shape[-1], self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
             return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, gamma=self.gamma2, precision=p)   # LN2 + MLP + LayerScale + residual

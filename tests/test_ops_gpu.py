@@ -761,3 +761,30 @@ def test_stem_direct_option_switches_between_two_agreeing_paths():
     ref = gelu64(ref + pos.double().cpu())
     assert_parity(direct.cpu(), ref.float(), 5e-6, "direct stem conv")
     assert_parity(gemm.cpu(), ref.float(), TOL[0], "implicit-GEMM stem conv")
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K,out16,act", [(3136, 192, 64, True, 0), (5000, 384, 128, True, 0), (130, 64, 64, False, 1), (2049, 264, 128, False, 0),
+                                             (1, 8, 64, True, 1)])
+def test_ln_linear16(M, N, K, out16, act, prec):
+    """LayerNorm applied on the way into the GEMM == layernorm16 followed by linear16 up to the rounding of the folded weights."""
+    torch.manual_seed(M + N + K)
+    f = F()
+    x = (torch.randn(M, K) * 1.7 + 0.3).cuda()
+    ln = torch.nn.LayerNorm(K).cuda()
+    lin = torch.nn.Linear(K, N).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2); ln.bias.normal_(0, 0.2)
+    got = f.ln_linear16(x, ln, lin, act=f.ACT_GELU if act else f.ACT_NONE, out16=out16, precision=prec)
+    z = torch.nn.functional.layer_norm(x.double().cpu(), (K,), ln.weight.double().cpu(), ln.bias.double().cpu(), ln.eps)
+    z = z @ lin.weight.double().cpu().t() + lin.bias.double().cpu()
+    ref = gelu64(z) if act else z
+    assert got.dtype == (f.dtype16(prec) if out16 else torch.float32)
+    assert_parity(got.float().cpu(), ref.float(), 1.5e-3 if prec == 1 else 1.5e-2, f"ln_linear16{(M, N, K)} p{prec}")
+
+
+def test_ln_linear16_rejects_other_widths():
+    from mi355attn import Mi355Error
+    f = F()
+    with pytest.raises(Mi355Error):
+        f.ln_linear16(torch.randn(16, 96).cuda(), torch.nn.LayerNorm(96).cuda(), torch.nn.Linear(96, 64).cuda(), precision=1)
