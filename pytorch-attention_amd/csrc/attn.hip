@@ -29,6 +29,7 @@ struct AttnArgs {
     const float* lepe_w;   // (Cb, 3, 3) or null
     const float* lepe_b;   // (Cb)
     int L, Ctot, c0, heads;
+    int koff, voff, oc0;   // element offsets from a head's q slice to its k / v slices inside a token row; first output channel of the branch
     int reso, Hsp, Wsp, nWx, nwin;   // window geometry on the token grid
     int T;                 // tokens per window
     unsigned wsp_magic;    // ceil(2^32 / Wsp): slot / Wsp == umulhi(slot, magic) for slot, Wsp < 2^16 (no integer divide in the kernel)
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
     const int b = bid / a.nwin;
     const int T = a.T;
     const int wy0 = (win / a.nWx) * a.Hsp, wx0 = (win % a.nWx) * a.Wsp;
-    const int ch0 = a.c0 + head * D;                                  // first channel of this head inside a q/k/v row
+    const int ch0 = a.c0 + head * D;                                  // first element of this head's q slice inside a token row
+    const int och0 = a.oc0 + head * D;                                // first channel of this head in the output row
     const long row3 = 3L * a.Ctot;
     using gel = typename std::conditional<IO16, el, float>::type;        // element type in HBM
     const gel* base = static_cast<const gel*>(a.qkv) + (long)b * a.L * row3 + ch0;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         for (int it = 0; it < NKI; ++it) {
             const int idx = t + it * NTHR, key = idx / D8, d8 = idx % D8;
             const bool live = idx < TK * D8 && key < T;
-            kreg[it] = ld16(live, tok(live ? key : 0), a.Ctot + d8 * 8);
+            kreg[it] = ld16(live, tok(live ? key : 0), a.koff + d8 * 8);
         }
 #pragma unroll
         for (int it = 0; it < NVI; ++it) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
             for (int j = 0; j < 4; ++j) {
                 const int key = kg * 4 + j;
                 const bool live = idx < (TK / 4) * D8 && key < T;
-                vreg[it][j] = ld16(live, tok(live ? key : 0), 2 * a.Ctot + d8 * 8);
+                vreg[it][j] = ld16(live, tok(live ? key : 0), a.voff + d8 * 8);
             }
         }
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
     for (int idx = t; idx < TK * D4; idx += NTHR) {
         const int key = idx / D4, d4 = idx % D4;
         f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (key < T) v = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + a.Ctot + d4 * 4);
+        if (key < T) v = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + a.koff + d4 * 4);
         const v4 h = M_::cvt(v);
         *reinterpret_cast<v4*>(s_k + key * KP + d4 * 4) = h;
         if constexpr (NS == 2) *reinterpret_cast<v4*>(s_k + K_EL + key * KP + d4 * 4) = M_::cvt_lo(v, h);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         for (int j = 0; j < 4; ++j) {
             const int key = kg * 4 + j;
             r[j] = f4{0.f, 0.f, 0.f, 0.f};
-            if (key < T) r[j] = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + 2 * a.Ctot + d4 * 4);
+            if (key < T) r[j] = *reinterpret_cast<const f4*>(base + (long)tok(key) * row3 + a.voff + d4 * 4);
         }
         const f4 c[4] = {{r[0].x, r[1].x, r[2].x, r[3].x}, {r[0].y, r[1].y, r[2].y, r[3].y},
                          {r[0].z, r[1].z, r[2].z, r[3].z}, {r[0].w, r[1].w, r[2].w, r[3].w}};
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                 const int r = it * RPI + lane / LPR, c8 = (lane % LPR) * 8;
                 const int qslot = qt * 16 + r;
                 if (qslot < T)
-                    *reinterpret_cast<v8*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c8) =
+                    *reinterpret_cast<v8*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + och0 + c8) =
                         *reinterpret_cast<const v8*>(slab + r * OP + c8);
             }
         } else {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                 const int r = it * RPI + lane / LPR, c4 = (lane % LPR) * 4;
                 const int qslot = qt * 16 + r;
                 if (qslot < T)
-                    *reinterpret_cast<f4*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + ch0 + c4) =
+                    *reinterpret_cast<f4*>(static_cast<gel*>(a.out) + ((long)b * a.L + tok(qslot)) * a.Ctot + och0 + c4) =
                         *reinterpret_cast<const f4*>(slab + r * OP + c4);
             }
         }
@@ -421,6 +423,7 @@ static int sdpa_common(const void* qkv, void* out, int B, int N, int heads, int 
                        hipStream_t st) {
     AttnArgs a{};
     a.qkv = qkv; a.out = out; a.L = N; a.Ctot = heads * d; a.c0 = 0; a.heads = heads;
+    a.koff = a.Ctot; a.voff = 2 * a.Ctot; a.oc0 = 0;
     a.reso = N; a.Hsp = 1; a.Wsp = N; a.nWx = 1; a.nwin = 1; a.T = N; a.scale = scale; a.pre_scale = 0;
     a.wsp_magic = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
     if (d == 64) return io16 ? launch_attn<64, false, true>(a, B, precision, st) : launch_attn<64, false, false>(a, B, precision, st);
@@ -432,6 +435,7 @@ static AttnArgs lepe_args(const void* qkv, const float* getv_w, const float* get
     AttnArgs a{};
     a.qkv = qkv; a.out = out; a.lepe_w = getv_w; a.lepe_b = getv_b;
     a.L = reso * reso; a.Ctot = Ctot; a.c0 = c0; a.heads = heads;
+    a.koff = Ctot; a.voff = 2 * Ctot; a.oc0 = c0;              // reference column order of the qkv projection: [q | k | v]
     a.reso = reso; a.Hsp = Hsp; a.Wsp = Wsp; a.nWx = reso / Wsp; a.nwin = (reso / Hsp) * (reso / Wsp); a.T = Hsp * Wsp;
     a.scale = scale; a.pre_scale = 1;
     a.wsp_magic = (unsigned)(((1ull << 32) + (unsigned)Wsp - 1) / (unsigned)Wsp);
