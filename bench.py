@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- forward throughput of the MI355X hot path, one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|mixer|da] [--no-cpu]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5|mixer|da|...] [--no-cpu]
 
-Default workload = BASELINE.json configs[1] ("c2"): SELayer + CBAM + ECALayer, x = (256,256,56,56) fp32 per GPU.
-One "step" = one forward of each block of the workload over the per-GPU batch (inputs resident in HBM,
-H2D excluded).  `value` = images/s through the whole step, aggregated over all ranks (weak scaling: per-GPU
-batch fixed, batch-sharded, no data-path collective for block workloads; c5 all-gathers the logits over RCCL).
-`roofline` describes the dominant (slowest) block of the step: achieved = algorithmic bytes (or FLOPs) of
-that block / its average duration measured with HIP events on the launch stream.
-`cpu_baseline` = the oracle (torch-CPU restatement of the reference forward) timed on this host's cores on a
-bounded sample of the same workload (rank 0, N=1 only).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one rank per GPU over RCCL); launched that way by somebody else it just reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Default workload "all" = every north-star target in ONE step (BASELINE.json configs[1..4] at B = 256 images per GPU):
+  C2  SELayer(256), CBAM(256), ECALayer(256)        x = (256,256,56,56) fp32                      HBM-bound
+  C3  ViT Attention(768, heads 12)                  x = (256,197,768)                              MFMA-bound
+  C4  CSWinBlock s1..s4, XCABlock(384,8), XCA       x = (256,3136,64) ... (256,49,512), (256,196,384)
+  C5  VisionTransformer ViT-Base/16                 x = (256,3,224,224); logits all-gathered over RCCL when N > 1
+One "step" = one forward of each block over the per-GPU batch (inputs resident in HBM, H2D excluded).  `value` = images/s through
+the whole step, aggregated over all ranks (weak scaling: per-GPU batch fixed, batch-sharded, no data-path collective except the
+end-of-forward all-gather of the ViT logits).  Every block gets its own roofline entry in `config.blocks` (achieved = algorithmic
+bytes or FLOPs of the block / its average duration measured with HIP events on the launch stream); the top-level
+`roofline` is the one of the slowest block of the step.  `cpu_baseline` = the oracle (torch-CPU restatement of the reference
+forward; /root/reference does not exist on the GPU box) timed on this host's cores on a bounded sample of the same step
+(rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,22 +32,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-attention_amd"))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="all")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="override the per-block CPU-baseline sample size (images)")
+    ap.add_argument("--chunk-images", type=int, default=None, help="override the Infinity-Cache chunk size")
+    ap.add_argument("--nt", type=int, default=None, help="channel-attention final pass: bit0 NT loads, bit1 NT stores")
+    ap.add_argument("--reverse", type=int, default=None, help="channel-attention final pass walks the batch backwards")
+    ap.add_argument("--precision", type=int, default=None, help="MFMA operand precision 0 strict / 1 fp16 / 2 bf16")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="mi355_set_option override (tuning experiments)")
+    ap.add_argument("--only", default=None, help="keep only the blocks of the workload whose name contains this text (profiling aid)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + barrier + max-reduce of an empty step on the gloo backend, no GPU work: what the CPU tests "
+                         "use to check that --gpus N really runs N ranks")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 outside a torchrun environment: become the launcher (one rank per GPU) instead of measuring one GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def host_cpu_info():
+    """(physical cores, hardware threads, model name) of this host."""
+    threads = os.cpu_count() or 1
+    cores, model = set(), None
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model is None:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or threads), threads, model
+
+
 def _seeded(ctor, seed=1234):
+    import torch
     torch.manual_seed(seed)
     return ctor().eval()
 
 
 # ------------------------------------------------------------------------------------------------------------
-# workloads: each returns dict(name, blocks, gather, dtype); a block = dict(name, module, x, fwd_args,
-#            bound "hbm"|"mfma", work = algorithmic bytes or FLOPs per call, cpu(callable on a host sample))
+# workloads: each returns dict(name, blocks, dtype); a block = dict(name, module, x, fwd_args, bound "hbm"|"mfma",
+#            work = algorithmic bytes or FLOPs per call, cpu(callable on a host sample), cpu_n, gather)
 # ------------------------------------------------------------------------------------------------------------
 def workload_c2(B, dev):
+    import torch
     from mi355attn.modules import CBAM, ECALayer, SELayer
     import oracle as O
     C, H, W = 256, 56, 56
@@ -58,50 +128,84 @@ def workload_c2(B, dev):
         return O.eca_forward(xs, m.conv.weight.cpu())
 
     blocks = [
-        dict(name="SELayer(256)", module=se.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_se),
-        dict(name="CBAM(256)", module=cb.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_cb),
-        dict(name="ECALayer(256)", module=ec.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_ec),
+        dict(name="SELayer(256)", module=se.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_se, cpu_n=64),
+        dict(name="CBAM(256)", module=cb.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_cb, cpu_n=64),
+        dict(name="ECALayer(256)", module=ec.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_ec, cpu_n=64),
     ]
     return dict(name="SELayer+CBAM+ECALayer fwd, x=(%d,256,56,56) fp32 per GPU (BASELINE configs[1])" % B,
-                blocks=blocks, gather=None, dtype="f32")
+                blocks=blocks, dtype="f32")
 
 
-WORKLOADS = {"c2": workload_c2}
+def workload_all(B, dev):
+    """BASELINE.json configs[1..4] in one step: C2 + C3 + C4 + C5 (module docstring)."""
+    import bench_workloads as W
+    parts = [workload_c2(B, dev), W.workload_c3(B, dev), W.workload_c4(B, dev), W.workload_c5(B, dev)]
+    blocks = [b for p in parts for b in p["blocks"]]
+    return dict(name="north-star step: SELayer+CBAM+ECALayer (C2) + ViT Attention (C3) + CSWinBlock s1-s4 + XCABlock/XCA (C4) + "
+                     "ViT-Base/16 full forward with logits all-gather (C5), B=%d per GPU (BASELINE configs[1..4])" % B,
+                blocks=blocks, dtype="f32/f16")
+
+
+WORKLOADS = {"c2": workload_c2, "all": workload_all}
 
 
 def _extra_workloads():
-    try:
-        import bench_workloads  # noqa: F401  (registers c3/c4/c5/... when present)
-        WORKLOADS.update(bench_workloads.WORKLOADS)
-    except ImportError:
+    import bench_workloads
+    for k, v in bench_workloads.WORKLOADS.items():
+        WORKLOADS.setdefault(k, v)
+
+
+def launch_check(args, rank, world):
+    """No GPU work: prove the launch path (N ranks, barrier-bracketed timing, max over ranks) on the gloo backend."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
         pass
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank)
+    else:
+        ranks = [0]
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no GPU work)", "value": 0.0, "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 6),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "ranks_seen": sorted(ranks),
+                          "config": {"workload": "launch-check"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="images in the CPU-baseline sample")
-    ap.add_argument("--chunk-images", type=int, default=None, help="override the Infinity-Cache chunk size")
-    ap.add_argument("--nt", type=int, default=None, help="channel-attention final pass: bit0 NT loads, bit1 NT stores")
-    ap.add_argument("--reverse", type=int, default=None, help="channel-attention final pass walks the batch backwards")
-    ap.add_argument("--precision", type=int, default=None, help="MFMA operand precision 0 strict / 1 fp16 / 2 bf16")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="mi355_set_option override (tuning experiments)")
-    ap.add_argument("--only", default=None, help="keep only the blocks of the workload whose name contains this text (profiling aid)")
-    args = ap.parse_args()
-    _extra_workloads()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        return launch_check(args, rank, world)
+
+    import torch
+    _extra_workloads()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -125,21 +229,26 @@ def main():
         mi355attn.set_default_precision(args.precision)
 
     wl = WORKLOADS[args.workload](args.batch, dev)
-    wname, blocks, gather = wl["name"], wl["blocks"], wl.get("gather")
+    wname, blocks = wl["name"], wl["blocks"]
+    if wl.get("gather") is not None:                      # whole-workload gather (full-model workloads): applies to every block
+        for b in blocks:
+            b.setdefault("gather", True)
     if args.only:
         blocks = [b for b in blocks if args.only in b["name"]]
         wname += " [only: %s]" % args.only
         if not blocks:
             raise SystemExit("--only matched no block")
 
+    def run_block(b):
+        y = b["module"](b["x"], *b.get("fwd_args", ()))
+        if b.get("gather") and dist is not None:
+            from mi355attn.dist import gather_batch
+            y = gather_batch(y)                            # one RCCL all-gather over xGMI (1 MB per rank for ViT logits)
+        return y
+
     def step():
-        outs = []
         with torch.no_grad():
-            for b in blocks:
-                outs.append(b["module"](b["x"], *b.get("fwd_args", ())))
-        if gather and dist is not None:
-            outs = [gather(o, dist) for o in outs]
-        return outs
+            return [run_block(b) for b in blocks]
 
     for _ in range(args.warmup):
         step()
@@ -161,23 +270,34 @@ def main():
         elapsed = float(t.item())
 
     # per-block durations with HIP events on the launch stream (un-timed extra passes)
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            for wk, tab in json.load(open(pmc_path)).items():
+                if isinstance(tab, dict):
+                    for bk, v in tab.items():
+                        pmc.setdefault(bk, v)
+        except Exception:
+            pmc = {}
     per_block = []
     for b in blocks:
         with torch.no_grad():
-            b["module"](b["x"], *b.get("fwd_args", ()))
+            run_block(b)
         torch.cuda.synchronize()
         tm = StreamTimer(dev)
         tm.start()
         with torch.no_grad():
             for _ in range(args.steps):
-                b["module"](b["x"], *b.get("fwd_args", ()))
+                run_block(b)
         ms = tm.stop_ms() / args.steps
         if b["bound"] == "hbm":
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
         per_block.append(dict(block=b["name"], ms=round(ms, 4), images_per_s=round(args.batch / (ms * 1e-3), 1),
-                              bound=b["bound"], achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4)))
+                              bound=b["bound"], achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                              traffic=pmc.get(b["name"])))
 
     # achievable-bandwidth yardstick: float4 streaming copy of the same footprint
     copy_gbs = None
@@ -204,18 +324,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
     dom = max(per_block, key=lambda r: r["ms"])
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dom["block"])
-        except Exception:
-            traffic = None
     out = {
-        "metric": "forward images/sec (+ ms/block), B=%d per GPU, 224x224-derived shapes" % args.batch,
+        "metric": "forward images/sec through one step (+ ms/block), B=%d per GPU, 224x224-derived shapes; CPU leg = oracle port "
+                  "of the reference forward on this host" % args.batch,
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if wl.get("dtype", "f32") == "f32" else {0: "bf16x3", 1: "f16", 2: "bf16"}[mi355attn.default_precision()],
+        "dtype": wl.get("dtype", "f32") if wl.get("dtype", "f32") in ("f32", "f32/f16")
+        else {0: "bf16x3", 1: "f16", 2: "bf16"}[mi355attn.default_precision()],
         "data": "synthetic (torch.randn seed 4321; module-default init seed 1234)",
         "config": {"workload": wname, "batch_per_gpu": args.batch, "parallelism": "batch-shard x%d" % world,
                    "chunk_images": mi355attn.get_option("chunk_images"), "nt": mi355attn.get_option("nt"),
@@ -223,44 +338,54 @@ def main():
                    "precision": {0: "strict(bf16x3)", 1: "fp16-mfma", 2: "bf16-mfma"}[mi355attn.default_precision()],
                    "blocks": per_block, "stream_copy_GBps": copy_gbs},
         "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                     "frac": dom["frac"], "traffic": traffic, "kernel": dom["block"], "ms": dom["ms"]},
+                     "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["block"], "ms": dom["ms"]},
     }
 
     if world == 1 and not args.no_cpu:
-        ncores = os.cpu_count() or 1
-        ns = min(args.cpu_sample, args.batch)
-        # pick the torch thread count that is fastest on this host (all SMT threads is often NOT it on big dual-socket boxes)
-        probe = blocks[0]
-        xs0 = probe["x"][:ns].cpu()
-        best_t, best_n = None, None
-        for nthr in sorted({min(ncores, n) for n in (8, 16, 32, 64, 128, ncores)}):
-            torch.set_num_threads(nthr)
-            probe["cpu"](xs0)
-            t1 = time.perf_counter()
-            probe["cpu"](xs0)
-            dt = time.perf_counter() - t1
-            if best_t is None or dt < best_t:
-                best_t, best_n = dt, nthr
-        torch.set_num_threads(best_n)
-        t_cpu = 0.0
-        reps = 3
-        for b in blocks:
-            xs = b["x"][:ns].cpu() if b["x"].shape[0] >= ns else b["x"].cpu()
-            b["cpu"](xs)                                           # warm-up
-            ts = []
-            for _ in range(reps):
-                t1 = time.perf_counter()
-                b["cpu"](xs)
-                ts.append(time.perf_counter() - t1)
-            ts.sort()
-            t_cpu += ts[len(ts) // 2]
-        out["cpu_baseline"] = {"value": round(ns / t_cpu, 1), "unit": "images/s", "cores": torch.get_num_threads(),
-                               "kind": "port",
-                               "sample": "oracle (torch-CPU restatement of the reference forward) on the first %d images "
-                                         "of the same batch, median of %d after 1 warm-up, all blocks of the step" % (ns, reps)}
+        out["cpu_baseline"] = cpu_baseline(blocks, args)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_baseline(blocks, args):
+    """The oracle on this host's cores, per block on a bounded sample (`cpu_n` images of the same batch), median of 3 after one
+    warm-up.  value = images/s through the same step = 1 / sum_b (t_b / n_b)."""
+    import torch
+    cores, threads, model = host_cpu_info()
+    # pick the torch thread count that is fastest on this host (all SMT threads is often NOT it on big dual-socket boxes)
+    probe = blocks[0]
+    n0 = min(args.cpu_sample or probe.get("cpu_n", 16), probe["x"].shape[0])
+    xs0 = probe["x"][:n0].cpu()
+    best_t, best_n = None, None
+    for nthr in sorted({min(threads, n) for n in (16, 32, 64, cores, threads)}):
+        torch.set_num_threads(nthr)
+        probe["cpu"](xs0)
+        t1 = time.perf_counter()
+        probe["cpu"](xs0)
+        dt = time.perf_counter() - t1
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, nthr
+    torch.set_num_threads(best_n)
+    per_image, reps, detail = 0.0, 3, []
+    for b in blocks:
+        ns = min(args.cpu_sample or b.get("cpu_n", 16), b["x"].shape[0])
+        xs = b["x"][:ns].cpu()
+        b["cpu"](xs)                                           # warm-up
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            b["cpu"](xs)
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        per_image += ts[len(ts) // 2] / ns
+        detail.append({"block": b["name"], "images": ns, "images_per_s": round(ns / ts[len(ts) // 2], 1)})
+    return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cores": cores, "host_threads": threads, "host_cpu": model, "blocks": detail,
+            "sample": "oracle (torch-CPU restatement of the reference forward; the reference checkout does not exist on the GPU box) "
+                      "on the first n images of the same batch per block (n listed per block), median of %d after 1 warm-up, torch "
+                      "threads = cores field (fastest of a probe over thread counts), host has %d cores / %d hardware threads"
+                      % (reps, cores, threads)}
 
 
 if __name__ == "__main__":

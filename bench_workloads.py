@@ -24,9 +24,9 @@ def workload_c3(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 197, 768, device=dev)
     sd = _sd(m)
-    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B,
+    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=16,
                    cpu=lambda xs: O.vit_attention_forward(xs, sd, 12))]
-    return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, gather=None, dtype="f16")
+    return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, dtype="f16")
 
 
 def workload_c4(B, dev):
@@ -44,18 +44,18 @@ def workload_c4(B, dev):
         m = _seeded(lambda: CSWinBlock(*args, **kw))
         torch.manual_seed(4321)
         x = torch.randn(B, *shp, device=dev)
-        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m))))
+        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=16))
     xb = _seeded(lambda: XCABlock(384, 8, qkv_bias=True, eta=1.0))
     xa = _seeded(lambda: XCA(384, 8, qkv_bias=True))
     torch.manual_seed(4321)
     x = torch.randn(B, 196, 384, device=dev)
     sdb, sda = _sd(xb), _sd(xa)
-    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B,
+    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B, cpu_n=16,
                        cpu=lambda xs: O.xca_block_forward(xs, sdb, 8, 14, 14)))
-    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B,
+    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B, cpu_n=16,
                        cpu=lambda xs: O.xca_forward(xs, sda, 8)))
     return dict(name="CSWin-T blocks s1-s4 + XCiT-S XCABlock/XCA fwd, B=%d (BASELINE configs[3])" % B, blocks=blocks,
-                gather=None, dtype="f16")
+                dtype="f16")
 
 
 def workload_c5(B, dev):
@@ -65,14 +65,11 @@ def workload_c5(B, dev):
     x = torch.randn(B, 3, 224, 224, device=dev)
     sd = _sd(m)
 
-    def gather(logits, dist):
-        from mi355attn.dist import gather_batch
-        return gather_batch(logits)                                    # one RCCL all-gather over xGMI, 1 MB per rank
-
+    # gather=True: bench.py all-gathers this block's logits (mi355attn.dist.gather_batch: one RCCL all-gather over xGMI, 1 MB per rank)
     blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
-                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12))]
+                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12), cpu_n=8, gather=True)]
     return dict(name="ViT-Base full fwd, %d images per GPU, logits all-gathered (BASELINE configs[4])" % B, blocks=blocks,
-                gather=gather, dtype="f16")
+                gather=True, dtype="f16")
 
 
 def workload_mixer(B, dev):
@@ -83,7 +80,7 @@ def workload_mixer(B, dev):
     sd = _sd(m)
     blocks = [dict(name="MixerLayer(512,196)", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B,
                    cpu=lambda xs: O.mixer_layer_forward(xs, sd))]
-    return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, gather=None, dtype="f16")
+    return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, dtype="f16")
 
 
 def workload_da(B, dev):
@@ -101,7 +98,7 @@ def workload_da(B, dev):
                 "proj.bias")
         blocks.append(dict(name="DoubleAttention(%d,%d,%d)@%dx%d" % (C, cm, cn, hw, hw), module=m.to(dev), x=x, bound="mfma",
                            work=flop * B, cpu=(lambda sd_: (lambda xs: O.double_attention_forward(xs, *[sd_[k] for k in keys])))(sd)))
-    return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, gather=None, dtype="f16")
+    return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, dtype="f16")
 
 
 def _full_model(ctor, title, flop_per_image, cpu_fn, B, dev):
@@ -110,12 +107,9 @@ def _full_model(ctor, title, flop_per_image, cpu_fn, B, dev):
     x = torch.randn(B, 3, 224, 224, device=dev)
     sd = _sd(m)
 
-    def gather(logits, dist):
-        from mi355attn.dist import gather_batch
-        return gather_batch(logits)
-
-    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd))]
-    return dict(name="%s full fwd, %d images per GPU, logits all-gathered" % (title, B), blocks=blocks, gather=gather, dtype="f16")
+    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd), cpu_n=8,
+                   gather=True)]
+    return dict(name="%s full fwd, %d images per GPU, logits all-gathered" % (title, B), blocks=blocks, gather=True, dtype="f16")
 
 
 def workload_cswin(B, dev):
@@ -169,7 +163,7 @@ def workload_zoo(B, dev):
         else:
             cpu = (lambda s: (lambda xs: O.gct_forward(xs, s["alpha"], s["gamma"], s["beta"])))(sd)
         blocks.append(dict(name=name, module=m.to(dev), x=x, bound="hbm", work=nbytes * B, cpu=cpu))
-    return dict(name="SimAM+SRM+GaussianGCT+LCT+GCT fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, gather=None, dtype="f32")
+    return dict(name="SimAM+SRM+GaussianGCT+LCT+GCT fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, dtype="f32")
 
 
 def workload_zoo2(B, dev):
@@ -200,7 +194,7 @@ def workload_zoo2(B, dev):
         sd = _sd(m)
         cpu = (lambda f, s: (lambda xs: f(xs, s)))(orc, sd)
         blocks.append(dict(name=name, module=m.to(dev), x=x, bound=bound, work=work * B, cpu=cpu))
-    return dict(name="GC+CoordAtt+Triplet+BAM+SK+CAM fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, gather=None, dtype="f32")
+    return dict(name="GC+CoordAtt+Triplet+BAM+SK+CAM fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, dtype="f32")
 
 
 WORKLOADS = {"zoo2": workload_zoo2, "zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

@@ -39,7 +39,10 @@ class Attention(nn.Module):
 
 
 class SRAttention(nn.Module):
-    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0, proj_drop=0, sr_ratio=1, precision=None):
+    """pvt.py:53-54 / cmt.py:73-74: `sr_ratio` is the THIRD positional parameter (both files call `Attention(dim, num_heads,
+    sr_ratio, ...)` positionally, pvt.py:98, cmt.py:119); segformer.py:18 has it last (SRConvAttention below)."""
+
+    def __init__(self, dim, num_heads=8, sr_ratio=1, qkv_bias=False, attn_drop=0, proj_drop=0, precision=None):
         super().__init__()
         assert dim % num_heads == 0
         _no_dropout(attn_drop, proj_drop)
