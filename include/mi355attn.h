@@ -17,7 +17,7 @@
  *   - `ws` must hold at least mi355_<op>_workspace_bytes(...) bytes and be 16-byte aligned; it is scratch
  *     (contents undefined after return) and may be shared between calls on the same stream;
  *   - return 0 on success, <0 on failure: MI355_EINVAL (bad argument), MI355_EUNSUPPORTED (shape outside the
- *     kernel's envelope), MI355_EHIP (HIP runtime error).  mi355_last_error() returns a thread-local,
+ *     kernel's envelope), MI355_EHIP (HIP runtime error), MI355_ESYNC (see mi355_sync_status).  mi355_last_error() returns a thread-local,
  *     NUL-terminated description of the last failure on this thread.  Nothing throws or aborts across the ABI.
  *   - precision: 0 = strict (3-way split-bf16 MFMA, fp32-class accuracy), 1 = fp16 MFMA operands with fp32
  *     accumulate (default of the modules; within the 1e-3 parity tolerance), 2 = bf16 MFMA operands (fast,
@@ -37,6 +37,7 @@ extern "C" {
 #define MI355_EINVAL       -1
 #define MI355_EUNSUPPORTED -2
 #define MI355_EHIP         -3
+#define MI355_ESYNC        -4   /* an inter-workgroup exchange of an earlier launch timed out: see mi355_sync_status */
 
 #define MI355_PREC_STRICT 0
 #define MI355_PREC_FP16   1
@@ -74,6 +75,7 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   Under hipGraph stream capture the granule-exchange kernels are not used at all (a recorded launch replays with the
  *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
  *                   kernels instead, so captured graphs are replay-safe by construction.
+ *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
@@ -81,6 +83,13 @@ long        mi355_get_option(const char* key);
 /* Drop what the library remembers about workspaces inside [ws, ws + ws_bytes) ("ws_persistent"): call before freeing or
  * repurposing such a buffer.  The next call that uses the memory zeroes its exchange area again. */
 int         mi355_workspace_forget(const void* ws, size_t ws_bytes);
+/* Failure report of the single-read exchange kernels (SE, CBAM, GCT / LCT gates).  Their inter-workgroup polls are bounded
+ * (option "spin_limit", sweeps; default 1 << 22 ~ a second); a poll that runs out stores a code into a pinned host word that
+ * the library reads WITHOUT a device synchronisation.  MI355_OK = nothing pending.  MI355_ESYNC = some launch that has already
+ * executed produced invalid output (text in mi355_last_error); the condition is cleared by the report.  The same check runs at
+ * the start of every later mi355_se_fwd / mi355_se_ex_fwd / mi355_cbam_fwd / gate call, which then fails instead of launching.
+ * Launches also refuse shapes whose per-image workgroup set cannot be resident at once (they take the multi-pass kernels). */
+int         mi355_sync_status(void);
 
 /* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
 

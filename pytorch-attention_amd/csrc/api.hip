@@ -18,6 +18,7 @@ static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in r
 static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
 static std::atomic<long> g_stem_direct{1};  // narrow conv stems: direct fp32 kernel (stem_conv.hip) vs implicit GEMM
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
+static std::atomic<long> g_spin_limit{1L << 22};   // poll budget of the exchange kernels (sweeps) before they give up with an error code
 static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
 
 char* err_buf() { return g_err; }
@@ -101,6 +102,42 @@ void ws_forget_range(const void* base, size_t bytes) {
     }
 }
 
+// ---- exchange-kernel failure word (common.h) -----------------------------------------------------------------------------------
+namespace {
+std::once_flag g_sync_once;
+unsigned* g_sync_word = nullptr;
+}  // namespace
+unsigned* sync_err_word() {
+    std::call_once(g_sync_once, [] {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && p) {
+            std::memset(p, 0, 64);
+            g_sync_word = static_cast<unsigned*>(p);
+        } else {
+            (void)hipGetLastError();
+        }
+    });
+    return g_sync_word;
+}
+unsigned spin_limit() { return (unsigned)g_spin_limit.load(std::memory_order_relaxed); }
+int sync_pending(const char* who) {
+    unsigned* w = sync_err_word();
+    if (!w) return MI355_OK;
+    const unsigned code = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (!code) return MI355_OK;
+    __atomic_store_n(w, 0u, __ATOMIC_RELEASE);
+    static const char* const names[] = {"?", "SE (se_single_kernel)", "CBAM (cbam_single_kernel)", "channel-statistics gate (stat_single_kernel)"};
+    return fail(MI355_ESYNC, "%s: an inter-workgroup exchange of an EARLIER launch of %s ran out of its poll budget (%u sweeps): that launch's "
+                "output is invalid.  Typical cause: fewer workgroups resident than one image needs (partitioned / masked device)",
+                who, names[code < 4 ? code : 0], spin_limit());
+}
+int resident_slots(int per_cu) {
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); ncu = 256; }
+    return ncu * per_cu;
+}
+
 long opt_zoo_single() { return g_zoo_single.load(std::memory_order_relaxed); }
 long opt_stem_direct() { return g_stem_direct.load(std::memory_order_relaxed); }
 long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
@@ -163,6 +200,11 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_stem_direct.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "spin_limit") == 0) {
+        MI355_CHECK_ARG(value >= 1 && value <= (1L << 30));
+        mi355::g_spin_limit.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "se_occ") == 0) {
         MI355_CHECK_ARG(value == 2 || value == 3);
         mi355::g_se_occ.store(value, std::memory_order_relaxed);
@@ -190,6 +232,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
+    if (key && std::strcmp(key, "spin_limit") == 0) return (long)mi355::spin_limit();
     if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
     if (key && std::strcmp(key, "stem_direct") == 0) return mi355::opt_stem_direct();
     if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();
@@ -197,6 +240,8 @@ long mi355_get_option(const char* key) {
     mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
     return -1;
 }
+
+int mi355_sync_status(void) { return mi355::sync_pending("mi355_sync_status"); }
 
 int mi355_event_time_begin(mi355_stream_t stream, void** handle) {
     MI355_CHECK_ARG(handle != nullptr);

@@ -27,7 +27,6 @@ typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr u32 SPIN_LIMIT = 1u << 21;
 
 __device__ __forceinline__ void gran_put(rsrc_t g, u32 idx, float v0, float v1, u32 TAG) {
     const u32x4 v = {__float_as_uint(v0), TAG, __float_as_uint(v1), TAG};
@@ -67,7 +66,8 @@ __device__ __forceinline__ void seg_reduce(float& s, float& m, int lane) {
 
 struct CbamSingleArgs {
     const float* x; float* y; const float* w1; const float* w2; const float* wconv;
-    u32x4* g1; u32x4* g2; u32x4* g3; u32* ticket; u32* err;
+    u32x4* g1; u32x4* g2; u32x4* g3; u32* ticket; u32* err; u32* herr;   // herr: pinned host word every later call checks (api.hip)
+    u32 spin;
     int C, Cr, H, W, ks, R, Q, NB, cpb, total, nts, wlds;
     u32 tag, tbase;                                                   // granule tag and ticket base of this launch (ws_epoch)
 #ifdef CBAM_TIMING
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
             }
             if (__syncthreads_and(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT) { timeout = true; break; }
+            if (++spins > a.spin) { timeout = true; break; }
         }
         STAMP(2);                                                                    // hop 1 in
         if (t < nch) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
             }
             if (__syncthreads_and(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT) { timeout = true; break; }
+            if (++spins > a.spin) { timeout = true; break; }
         }
         STAMP(3);                                                                    // hop 2 in
         // ---- channel gates: gc = sigmoid(W2 (relu(W1 avg) + relu(W1 max)))  (cbam.py:31-35) ---------------------------------
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
                 }
                 if (__syncthreads_and(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPIN_LIMIT) { timeout = true; break; }
+                if (++spins > a.spin) { timeout = true; break; }
             }
         }
         STAMP(6);                                                                    // hop 3 in
@@ -283,7 +283,10 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
         u32 next_tk = 0;
         if (t == 0) {
             next_tk = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;     // consumed after the stores below
-            if (timeout) __hip_atomic_store(a.err, 1u, AGENT_RLX);
+            if (timeout) {
+                __hip_atomic_store(a.err, 1u, AGENT_RLX);
+                if (a.herr) __hip_atomic_store(a.herr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         // ---- spatial gate of the band: sigmoid(conv_ks x ks([mean, max]))  (2 -> 1, zero pad, cross-correlation) ----------------
         {
@@ -400,7 +403,8 @@ size_t cbam_single_extra_bytes(int B, int C, int H, int W) {
 
 bool cbam_single_applicable(int C, int Cr, int H, int W, int ks) {
     Geo g;
-    return opt_cbam_single() && pick_geometry(C, Cr, H, W, ks, g);
+    // all NB bands of an image must be resident together (two workgroups per CU): ADVICE r1, e.g. H = 1024 at R = 1
+    return opt_cbam_single() && pick_geometry(C, Cr, H, W, ks, g) && g.NB <= resident_slots(2);
 }
 
 int cbam_single(const float* x, const float* w1, const float* w2, const float* wconv, float* y, int B, int C, int Cr, int H, int W,
@@ -414,6 +418,8 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     a.g3 = a.g2 + (size_t)B * C;
     a.ticket = reinterpret_cast<u32*>(a.g3 + (size_t)B * H * W);
     a.err = a.ticket + 1;
+    a.herr = sync_err_word(); a.spin = spin_limit();
+    if (int rc = sync_pending("cbam_single")) return rc;
     a.C = C; a.Cr = Cr; a.H = H; a.W = W; a.ks = ks; a.R = g.R; a.Q = g.Q; a.NB = g.NB; a.cpb = g.cpb;
     const long total_l = (long)B * g.NB;
     if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "cbam_single: too many slices");
@@ -423,13 +429,11 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     const int per_cu = 2;
     a.wlds = (g.smem_base + g.smem_w <= (size_t)(120 * 1024) / per_cu) ? 1 : 0;
     const size_t smem = g.smem_base + (a.wlds ? g.smem_w : 0);
-    int dev = 0, ncu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    long grid = (long)ncu * per_cu;                                   // 16 waves per CU at <= 128 VGPRs, <= 120 KB LDS per CU
+    long grid = (long)resident_slots(per_cu);                                   // 16 waves per CU at <= 128 VGPRs, <= 120 KB LDS per CU
 #ifdef CBAM_TIMING
     a.dbg = g_cbam_dbg;
 #endif
+    if (g.NB > grid) return fail(MI355_EUNSUPPORTED, "cbam_single: an image needs %d resident workgroups, the device holds %ld", g.NB, grid);
     if (grid > a.total) grid = a.total;
     // every workgroup draws one ticket per slice plus one that tells it to stop: total + grid draws per launch
     const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ ((unsigned long long)g.NT << 40) ^ 0xCBA0000000000000ull;

@@ -17,7 +17,6 @@ using v4f = float __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
 
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr u32 SPIN_LIMIT = 1u << 22;   // ~1 s of polling before giving up with an error word
 
 // ---- ECA without any cross-workgroup exchange ------------------------------------------------------------------------------
 // The ECA gate of channel c only needs the means of channels c-pad..c+pad (eca.py:26-30, k taps, zero padding).  A workgroup
@@ -105,7 +104,8 @@ typedef unsigned long long u64;
 
 struct SeSingleArgs {
     const float* x; float* y; const float* w1; const float* w2; const float* b1; const float* b2;
-    u64* gran; u32* ticket; u32* err;
+    u64* gran; u32* ticket; u32* err; u32* herr;   // err: workspace word (debug), herr: pinned host word every later call checks
+    u32 spin;
     int gate;
     int C, Cr, HW, n4, gpi, total;
     u32 tag, tbase;                    // granule tag and ticket base of this launch (api.hip ws_epoch)
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
             }
             if (__syncthreads_and(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT) {
-                if (t == 0) __hip_atomic_store(a.err, 1u, AGENT_RLX);
+            if (++spins > a.spin) {
+                if (t == 0) {
+                    __hip_atomic_store(a.err, 1u, AGENT_RLX);
+                    if (a.herr) __hip_atomic_store(a.herr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 break;
             }
         }
@@ -253,7 +256,10 @@ size_t se_single_extra_bytes(int B, int C) { return (size_t)B * C * sizeof(u64);
 
 bool se_single_applicable(int C, int Cr, int H, int W) {
     const long HW = (long)H * W;
-    return opt_se_single() && (HW % 4 == 0) && (HW / 4 <= 16 * 64) && (C % ECW == 0) && ((size_t)(C + Cr) * 4 <= 48 * 1024);
+    // every slice of an image (C / 8 workgroups) has to be resident at the same time, or the image's workgroups wait for granules
+    // nobody can publish: at least two workgroups per CU are resident in every configuration of the kernel
+    return opt_se_single() && (HW % 4 == 0) && (HW / 4 <= 16 * 64) && (C % ECW == 0) && ((size_t)(C + Cr) * 4 <= 48 * 1024) &&
+           C / ECW <= resident_slots(2);
 }
 
 // `state` = arrive[B] | ticket | err (fused_state_bytes), `gran` = B*C granules (se_single_extra_bytes)
@@ -264,16 +270,16 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     a.gran = static_cast<u64*>(gran);
     a.ticket = static_cast<u32*>(state) + B;
     a.err = a.ticket + 1;
+    a.herr = sync_err_word(); a.spin = spin_limit();
+    if (int rc = sync_pending("se_single")) return rc;
     a.C = C; a.Cr = Cr; a.HW = H * W; a.n4 = a.HW / 4; a.gpi = C / ECW;
     const long total_l = (long)B * a.gpi;
     if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "se_single: too many slices");
     a.total = (int)total_l;
-    int dev = 0, ncu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
     const int occ = (opt_se_occ() == 3 && (!wlds || (size_t)(C + Cr + 2 * C * Cr) * 4 <= 50 * 1024)) ? 3 : 2;
-    long grid = (long)ncu * occ;                          // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
+    long grid = (long)resident_slots(occ);                // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
+    if (a.gpi > grid) return fail(MI355_EUNSUPPORTED, "se_single: an image needs %d resident workgroups, the device holds %ld", a.gpi, grid);
     if (grid > a.total) grid = a.total;
     const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ 0x5E00000000000000ull;
     const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid), st);     // one draw per slice + one stop draw per workgroup

@@ -26,16 +26,15 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 enum { M_SIMAM = 1, M_SRM = 2, M_GCTG = 3, M_LCT = 4, M_GCT2 = 5, M_GCT1 = 6 };
 constexpr int ECW = 8;
-constexpr u32 SPIN_LIMIT = 1u << 22;
 
 struct StatArgs {
     const float* x; float* y;
     const float* p0; const float* p1; const float* p2; const float* p3; const float* p4;   // per-channel parameter arrays (per mode)
     float f0, f1;                         // lambda | bn eps | eps, c | eps | epsilon
     int i0;                               // LCT: channels per group;  GCT1: after_relu
-    u64* gran; u32* ticket; u32* err; float* stats;   // exchange area (single read) / row statistics (two pass)
+    u64* gran; u32* ticket; u32* err; u32* herr; float* stats;   // exchange area (single read) / row statistics (two pass)
     int B, C, HW, n4, gpi, total;
-    u32 tag, tbase;
+    u32 tag, tbase, spin;
 };
 
 // gate of channel c from its own statistics and (exchange modes) the image's per-channel values s_p[0..C)
@@ -180,11 +179,14 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
                 }
                 if (__syncthreads_and(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPIN_LIMIT) { timeout = true; break; }
+                if (++spins > a.spin) { timeout = true; break; }
             }
             if (t == 0) {                                             // nobody is waited for any more: next ticket
                 s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
-                if (timeout) __hip_atomic_store(a.err, 1u, AGENT_RLX);
+                if (timeout) {
+                    __hip_atomic_store(a.err, 1u, AGENT_RLX);
+                    if (a.herr) __hip_atomic_store(a.herr, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             if (MODE == M_LCT) group_reduce(s_p, c, a.i0, red0, red1);
             else image_reduce<MODE, 512>(a, s_p, s_red, red0, red1);
@@ -279,22 +281,22 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
     a.HW = H * W;
     constexpr bool XCH = MODE >= M_GCTG;
     const bool single = !(XCH && mi355::stream_is_capturing(st)) && mi355::opt_zoo_single() && (a.HW % 4 == 0) && (a.HW / 4 <= 16 * 64) && (C % ECW == 0) && aligned16(a.x) &&
-                        aligned16(a.y) && (size_t)C * 4 <= 48 * 1024 && (MODE != M_LCT || a.i0 <= C);
+                        aligned16(a.y) && (size_t)C * 4 <= 48 * 1024 && (MODE != M_LCT || a.i0 <= C) &&
+                        (!XCH || C / ECW <= mi355::resident_slots(2));     // an image's slices must all be resident to exchange granules
     if (single) {
         a.n4 = a.HW / 4; a.gpi = C / ECW;
         const long total_l = (long)B * a.gpi;
         if (total_l > (1L << 30)) return mi355::fail(MI355_EUNSUPPORTED, "channel-statistics gate: too many slices");
         a.total = (int)total_l;
-        int dev = 0, ncu = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        long grid = (long)ncu * (MODE == M_SIMAM ? 2 : 3);        // three workgroups per CU (<= 80 VGPRs); SimAM's per-element gate needs 120
+        long grid = (long)mi355::resident_slots(MODE == M_SIMAM ? 2 : 3);        // three workgroups per CU (<= 80 VGPRs); SimAM's per-element gate needs 120
         if (grid > a.total) grid = a.total;
         if (XCH) {
             if (ws_bytes < mi355::zoo_workspace_bytes(B, C)) return mi355::fail(MI355_EINVAL, "channel-statistics gate: workspace too small");
             char* base = static_cast<char*>(ws);
             a.ticket = reinterpret_cast<u32*>(base);
             a.err = a.ticket + 1;
+            a.herr = mi355::sync_err_word(); a.spin = mi355::spin_limit();
+            if (int rc = mi355::sync_pending("channel-statistics gate")) return rc;
             a.gran = reinterpret_cast<u64*>(base + 16);
             const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ ((unsigned long long)MODE << 56);
             const mi355::WsEpoch ep = mi355::ws_epoch(ws, key, (unsigned)(a.total + grid), st);

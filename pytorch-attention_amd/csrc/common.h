@@ -27,6 +27,15 @@ void  ws_forget(const void* region);
 bool  stream_is_capturing(hipStream_t st);      // hipGraph capture in progress on this stream
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();
+// ---- exchange-kernel failure reporting (api.hip) ----------------------------------------------------------------------------
+// The single-read kernels bound their inter-workgroup polls.  A poll that runs out stores a non-zero code into ONE pinned,
+// device-visible host word (system-scope store, no synchronisation needed to read it); every later library entry that launches an
+// exchange kernel -- and mi355_sync_status() -- looks at that word first and fails with MI355_ESYNC instead of returning OK over
+// garbage.  spin_limit() is the poll budget (option "spin_limit", default 1 << 22 sweeps ~ a second).
+unsigned* sync_err_word();            // device-visible pinned host word (null if the allocation failed: reporting falls back to the workspace word)
+unsigned  spin_limit();
+int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
+int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
 long  opt_zoo_single();
 long  opt_stem_direct();
 bool  stem_conv_applicable(int Cin, int Cout, int KH, int KW, int in_layout, const float* bias, const float* pos, const float* y);

@@ -39,17 +39,20 @@ def _opt(t, name):
 
 
 # ---- channel / spatial attention -------------------------------------------------------------------------
-def _check_sync_state(ws, B, C, what):
-    """Debug aid (MI355_CHECK_SYNC=1): the single-pass SE/ECA kernel bounds its inter-workgroup spins and raises an error
-    word in the workspace instead of hanging; reading it costs a device sync, so it is off by default."""
+def sync_status(wait=False):
+    """Raise Mi355Error if an exchange kernel (single-read SE / CBAM / GCT / LCT) that has ALREADY executed ran out of its poll
+    budget (include/mi355attn.h mi355_sync_status: a pinned host word, read without a device synchronisation).  `wait=True`
+    synchronises the device first, so that the check covers every launch issued so far."""
+    if wait:
+        torch.cuda.synchronize()
+    check(lib().mi355_sync_status(), "mi355_sync_status")
+
+
+def _sync_check():
+    """After every exchange-kernel launch: report a failure of any EARLIER launch now (the library does the same check before it
+    launches).  MI355_CHECK_SYNC=1 waits for the device first -- a debugging aid that makes the check cover this very launch."""
     import os
-    if os.environ.get("MI355_CHECK_SYNC") != "1":
-        return
-    torch.cuda.synchronize()
-    off = ((B * C * 4 + 15) // 16) * 16 + (B + 1) * 4
-    err = int(ws[off:off + 4].view(torch.int32).item())
-    if err:
-        raise _ffi.Mi355Error(f"{what}: inter-workgroup wait timed out (error word {err})")
+    sync_status(wait=os.environ.get("MI355_CHECK_SYNC") == "1")
 
 
 def se_forward(x, w1, w2):
@@ -66,7 +69,7 @@ def se_forward(x, w1, w2):
     ws = _ffi.workspace_dedicated(("se", B, C, H, W), n, x.device)
     check(lib().mi355_se_fwd(dptr(x), dptr(w1), dptr(w2), dptr(y), B, C, Cr, H, W, dptr(ws), ws.numel(),
                              stream_ptr(x.device)), "mi355_se_fwd")
-    _check_sync_state(ws, B, C, "mi355_se_fwd")
+    _sync_check()
     return y
 
 
@@ -199,7 +202,7 @@ def se_ex_forward(x, w1, b1, w2, b2, gate="sigmoid"):
     ws = _ffi.workspace_dedicated(("se", B, C, H, W), n, x.device)
     check(lib().mi355_se_ex_fwd(dptr(x), dptr(w1), dptr(_opt(b1, "b1")), dptr(w2), dptr(_opt(b2, "b2")), dptr(y), B, C, Cr, H, W,
                                 1 if gate == "hard_sigmoid" else 0, dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_se_ex_fwd")
-    _check_sync_state(ws, B, C, "mi355_se_ex_fwd")
+    _sync_check()
     return y
 
 
@@ -214,7 +217,6 @@ def eca_forward(x, wconv):
     ws = workspace(n, x.device)
     check(lib().mi355_eca_fwd(dptr(x), dptr(wconv), dptr(y), B, C, k, H, W, dptr(ws), ws.numel(),
                               stream_ptr(x.device)), "mi355_eca_fwd")
-    _check_sync_state(ws, B, C, "mi355_eca_fwd")
     return y
 
 
@@ -237,18 +239,11 @@ def cbam_forward(x, w1=None, w2=None, wconv=None, stage=0):
     y = torch.empty_like(x)
     n = lib().mi355_cbam_workspace_bytes(B, C, H, W)
     ws = _ffi.workspace_dedicated(("cbam", B, C, H, W), n, x.device) if stage == 0 else workspace(n, x.device)
-    import os
-    debug = os.environ.get("MI355_CHECK_SYNC") == "1" and stage == 0       # error word of the single-read kernel: ws[n-12:n-8]
-    if debug:
-        ws[n - 12:n - 8].zero_()                                           # (never the ticket word next to it: it counts across calls)
     check(lib().mi355_cbam_fwd(dptr(x), dptr(w1 if stage != 2 else None), dptr(w2 if stage != 2 else None),
                                dptr(wconv if stage != 1 else None), dptr(y), B, C, Cr, ks, H, W, stage,
                                dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_cbam_fwd")
-    if debug:
-        torch.cuda.synchronize()
-        err = int(ws[n - 12:n - 8].view(torch.int32).item())
-        if err:
-            raise _ffi.Mi355Error(f"mi355_cbam_fwd: inter-workgroup wait timed out (error word {err})")
+    if stage == 0:
+        _sync_check()
     return y
 
 
@@ -281,6 +276,7 @@ def gct_gauss_forward(x, c=2, eps=1e-5):
     x, y, ws, (B, C, H, W) = _zoo("gct_gauss", x)
     check(lib().mi355_gct_gauss_fwd(dptr(x), dptr(y), B, C, H, W, float(c), float(eps), dptr(ws), ws.numel(), stream_ptr(x.device)),
           "mi355_gct_gauss_fwd")
+    _sync_check()
     return y
 
 
@@ -289,6 +285,7 @@ def lct_forward(x, w, b, groups, eps=1e-5):
     w, b = require_device_f32(w, "w"), require_device_f32(b, "b")
     check(lib().mi355_lct_fwd(dptr(x), dptr(w), dptr(b), dptr(y), B, C, int(groups), H, W, float(eps), dptr(ws), ws.numel(),
                               stream_ptr(x.device)), "mi355_lct_fwd")
+    _sync_check()
     return y
 
 
@@ -300,6 +297,7 @@ def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False
     check(lib().mi355_gct_fwd(dptr(x), dptr(alpha), dptr(gamma), dptr(beta), dptr(y), B, C, H, W, float(epsilon),
                               1 if mode == "l1" else 0, 1 if after_relu else 0, dptr(ws), ws.numel(), stream_ptr(x.device)),
           "mi355_gct_fwd")
+    _sync_check()
     return y
 
 
