@@ -201,7 +201,7 @@ int mi355_set_option(const char* key, long value) {
         return MI355_OK;
     }
     if (std::strcmp(key, "spin_limit") == 0) {
-        MI355_CHECK_ARG(value >= 1 && value <= (1L << 30));
+        MI355_CHECK_ARG(value >= 0 && value <= (1L << 30));
         mi355::g_spin_limit.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }

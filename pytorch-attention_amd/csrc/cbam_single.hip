@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
                 }
                 float h = h0 + h1;
                 h += dpp<0xB1>(h); h += dpp<0x4E>(h); h += dpp<0x124>(h); h += dpp<0x128>(h);
-                if (part == 0 && j < Cr) s_hh[j] = fmaxf(h, 0.f);
+                if (part == 0 && j < Cr) s_hh[j] = relu_nan(h);
             }
             __syncthreads();
             for (int c = t; c < C; c += NT) {

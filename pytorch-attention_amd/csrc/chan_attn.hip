@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict
         for (int j0 = 0; j0 < Cr; j0 += 16) {
             const int j = j0 + jl;
             float acc = (j < Cr) ? dot16(wa + (long)j * C, s_p, C, part) : 0.f;
-            if (part == 0 && j < Cr) s_h[j] = fmaxf(acc + (ex.b1 ? ex.b1[j] : 0.f), 0.f);
+            if (part == 0 && j < Cr) s_h[j] = relu_nan(acc + (ex.b1 ? ex.b1[j] : 0.f));
         }
         __syncthreads();
         if (t < RPB && c0 + t < C) {
@@ -209,7 +209,7 @@ __device__ __forceinline__ void cbam_channel_gates(const float* __restrict__ avg
             ha = dot16(w1 + (long)j * C, s_a, C, part);
             hm = dot16(w1 + (long)j * C, s_m, C, part);
         }
-        if (part == 0 && j < Cr) s_h[j] = fmaxf(ha, 0.f) + fmaxf(hm, 0.f);
+        if (part == 0 && j < Cr) s_h[j] = relu_nan(ha) + relu_nan(hm);
     }
     __syncthreads();
     for (int c = t; c < C; c += 256) {

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
             acc += __shfl_xor(acc, 4, WAVE);
             acc += __shfl_xor(acc, 2, WAVE);
             acc += __shfl_xor(acc, 1, WAVE);
-            if (part == 0 && j < a.Cr) s_h[j] = fmaxf(acc + (a.b1 ? a.b1[j] : 0.f), 0.f);
+            if (part == 0 && j < a.Cr) s_h[j] = relu_nan(acc + (a.b1 ? a.b1[j] : 0.f));
         }
         __syncthreads();
         const float* w2r = w2 + (long)(c0 + wave) * a.Cr;

@@ -110,8 +110,18 @@ __device__ __forceinline__ int xcd_contiguous_block() {
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
+// ReLU with torch's NaN behaviour (relu(NaN) = NaN, so one NaN in x poisons the whole gate exactly as in the reference): v_max_f32
+// returns the non-NaN operand, and a float compare could be folded away under -fno-honor-nans, hence the bit test.
+__device__ __forceinline__ float relu_nan(float v) {
+    const float r = fmaxf(v, 0.f);
+    return ((__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u) ? v : r;
+}
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
-__device__ __forceinline__ float se_gate(float z, int kind) { return kind ? fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f : sigmoidf_(z); }
+__device__ __forceinline__ float se_gate(float z, int kind) {
+    if (!kind) return sigmoidf_(z);
+    const float h = fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f;                    // relu6 clamps; torch's clamp keeps a NaN
+    return ((__float_as_uint(z) & 0x7fffffffu) > 0x7f800000u) ? z : h;
+}
 // exact-erf GELU (nn.GELU() default), library erff: used off the hot path (LPI)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf-form GELU for the GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level) on the

@@ -12,6 +12,7 @@ import collections
 import ctypes
 import os
 import threading
+import warnings
 
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
@@ -136,7 +137,13 @@ def check(code, what):
 
 
 def stream_ptr(device=None):
-    """hipStream_t of torch's current stream on `device`, as an int for ctypes."""
+    """hipStream_t of torch's current stream on `device`, as an int for ctypes.
+
+    The library launches on the calling thread's CURRENT HIP device (include/mi355attn.h conventions), so a tensor that lives on
+    another device than the current one is refused here instead of launching a kernel on the wrong GPU with foreign pointers."""
+    if device is not None and device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+        raise Mi355Error(f"tensor on {device} but the current device is cuda:{torch.cuda.current_device()}: "
+                         "wrap the call in `with torch.cuda.device(x.device):` (kernels launch on the current device)")
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -154,15 +161,39 @@ def require_device_f32(t, name):
             "(move the module and its input to 'cuda'); there is no CPU path in this package.")
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.requires_grad and torch.is_grad_enabled():
+        _warn_no_autograd()
     return t if t.is_contiguous() else t.contiguous()
+
+
+_warned_autograd = False
+
+
+def _warn_no_autograd():
+    """Once per process: the engine is forward-only, its outputs carry no grad_fn."""
+    global _warned_autograd
+    if not _warned_autograd:
+        _warned_autograd = True
+        warnings.warn("mi355attn is a forward-only engine: a tensor that requires grad entered a kernel with autograd enabled; "
+                      "the output has no grad_fn and no gradient will flow through this module (use torch.no_grad() / "
+                      "requires_grad_(False) to silence this)", RuntimeWarning, stacklevel=4)
 
 
 _ws_cache = {}
 
 
+def _capturing():
+    return torch.cuda.is_current_stream_capturing()
+
+
 def workspace(nbytes, device):
     """Per-(device, stream) scratch tensor, grown on demand.  Reuse is safe because every op that uses it
-    is enqueued on the same stream, in order."""
+    is enqueued on the same stream, in order.
+
+    Under hipGraph capture the cache is bypassed: the buffer comes fresh from the graph's private memory pool, so a later eager
+    call that grows or evicts a cached buffer can never free memory a captured graph still points at."""
+    if _capturing():
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     t = _ws_cache.get(key)
@@ -173,13 +204,16 @@ def workspace(nbytes, device):
 
 
 _ws_dedicated = collections.OrderedDict()
-_WS_DEDICATED_MAX = 12
+_WS_DEDICATED_MAX = int(os.environ.get("MI355_WS_CACHE", "64"))      # distinct (op, shape, stream) exchange workspaces kept alive
 
 
 def workspace_dedicated(op_key, nbytes, device):
     """Workspace owned by ONE op + shape (single-read SE / CBAM): nothing else ever writes it, which is what lets the library
     skip re-zeroing the granule exchange area on every call ("ws_persistent", include/mi355attn.h).  A small LRU; an evicted
-    buffer is reported to the library before it is released."""
+    buffer is reported to the library before it is released.  Under hipGraph capture: a fresh buffer from the graph's pool, never
+    cached (see workspace())."""
+    if _capturing():
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (op_key, device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     t = _ws_dedicated.get(key)

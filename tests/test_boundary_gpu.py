@@ -1,0 +1,203 @@
+"""Boundary behaviour of the drop-in (VERDICT r1 'what's weak' 3-4): failure reporting of the exchange kernels, NaN
+semantics of the gates, workspaces under hipGraph capture, device / autograd guards."""
+import warnings
+
+import pytest
+import torch
+
+import oracle as O
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods(C, r=16):
+    from mi355attn.modules import CBAM, ECALayer, SELayer
+    torch.manual_seed(1234)
+    return SELayer(C, r).eval().cuda(), CBAM(C, r).eval().cuda(), ECALayer(C).eval().cuda()
+
+
+# ---- exchange-kernel timeouts are reported, not swallowed -----------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["se", "cbam", "gct"])
+def test_poll_timeout_is_reported_by_the_next_call(which):
+    """With a poll budget of zero sweeps the first unsuccessful sweep gives up: the launch finishes (no hang), its output is
+    garbage, and (1) mi355_sync_status reports it once the device has run the kernel, (2) the condition is cleared by the report,
+    (3) if nobody asks, the NEXT launch of an exchange kernel fails with MI355_ESYNC instead of returning OK, (4) afterwards the op
+    works again and matches the oracle."""
+    import mi355attn
+    from mi355attn.modules import GCT
+    se, cbam, _ = _mods(256)
+    gct = GCT(256).cuda()
+    m = {"se": se, "cbam": cbam, "gct": gct}[which]
+    torch.manual_seed(5)
+    x = torch.randn(64, 256, 56, 56, device="cuda")
+    mi355attn.sync_status(wait=True)                       # clean slate
+    old = mi355attn.get_option("spin_limit")
+    def launch():
+        """One launch with the zero budget.  True when its own post-launch check already saw (and thereby cleared) the failure
+        word -- the kernel can finish before the binding returns -- False when the failure is still pending."""
+        try:
+            with torch.no_grad():
+                m(x)
+        except mi355attn.Mi355Error as e:
+            assert "poll budget" in str(e)
+            return True
+        return False
+
+    try:
+        mi355attn.set_option("spin_limit", 0)
+        if not launch():
+            torch.cuda.synchronize()
+            with pytest.raises(mi355attn.Mi355Error, match="poll budget"):
+                mi355attn.sync_status()
+        mi355attn.sync_status(wait=True)                   # reported once, then clear
+        seen = launch()                                    # times out again ...
+        torch.cuda.synchronize()
+        mi355attn.set_option("spin_limit", old)
+        if not seen:
+            with pytest.raises(mi355attn.Mi355Error, match="poll budget"):
+                with torch.no_grad():
+                    m(x)                                   # ... and the next launch refuses to run over it
+    finally:
+        mi355attn.set_option("spin_limit", old)
+    mi355attn.sync_status(wait=True)
+    with torch.no_grad():
+        y = m(x[:3].contiguous())
+    mi355attn.sync_status(wait=True)
+    xs = x[:3].cpu()
+    if which == "se":
+        ref = O.se_forward(xs, se.fc[0].weight.cpu(), se.fc[2].weight.cpu())
+    elif which == "cbam":
+        ref = O.cbam_forward(xs, cbam.ca.fc[0].weight.cpu(), cbam.ca.fc[2].weight.cpu(), cbam.sa.conv.weight.cpu())
+    else:
+        sd = {k: v.cpu() for k, v in gct.state_dict().items()}
+        ref = O.gct_forward(xs, sd["alpha"], sd["gamma"], sd["beta"], gct.epsilon, gct.mode, gct.after_relu)
+    assert_parity(y.cpu(), ref, 1e-5, which + " after a reported timeout")
+
+
+def test_unresident_image_takes_the_multipass_path():
+    """C / 8 slices per image must all be resident for the SE exchange: C = 8192 on a 256-CU part needs 1024 > 2 x 256
+    workgroups, so the single-read kernel must step aside -- result still equals the oracle, nothing times out."""
+    import mi355attn
+    from mi355attn.modules import SELayer
+    torch.manual_seed(1234)
+    m = SELayer(8192, 64).eval().cuda()
+    torch.manual_seed(3)
+    x = torch.randn(2, 8192, 8, 8)
+    with torch.no_grad():
+        y = m(x.cuda())
+    mi355attn.sync_status(wait=True)
+    assert_parity(y.cpu(), O.se_forward(x, m.fc[0].weight.cpu(), m.fc[2].weight.cpu()), 1e-5, "SE C=8192")
+
+
+# ---- NaN semantics ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("single", [1, 0])
+@pytest.mark.parametrize("which", ["se", "eca", "cbam"])
+def test_nan_in_x_propagates_like_the_reference(which, single):
+    """One NaN in image 1 of 3: the reference's gates are built from means (and ReLU / max keep NaN in torch), so SE and CBAM turn the
+    whole image into NaN and ECA the k neighbouring channels; the other images are untouched.  Checked on the single-read kernels
+    and on the multi-pass fallbacks (cbam_single.hip is compiled with -fno-honor-nans: the NaN must still arrive)."""
+    import mi355attn
+    se, cbam, eca = _mods(64)
+    m = {"se": se, "eca": eca, "cbam": cbam}[which]
+    torch.manual_seed(11)
+    x = torch.randn(3, 64, 32, 32)
+    x[1, 17, 5, 9] = float("nan")
+    if which == "se":
+        ref = O.se_forward(x, se.fc[0].weight.cpu(), se.fc[2].weight.cpu())
+    elif which == "eca":
+        ref = O.eca_forward(x, eca.conv.weight.cpu())
+    else:
+        ref = O.cbam_forward(x, cbam.ca.fc[0].weight.cpu(), cbam.ca.fc[2].weight.cpu(), cbam.sa.conv.weight.cpu())
+    key = which + "_single"
+    old = mi355attn.get_option(key)
+    try:
+        mi355attn.set_option(key, single)
+        with torch.no_grad():
+            y = m(x.cuda()).cpu()
+    finally:
+        mi355attn.set_option(key, old)
+    mi355attn.sync_status(wait=True)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref)), \
+        f"{which}: NaN pattern differs ({int(torch.isnan(y).sum())} vs {int(torch.isnan(ref).sum())} NaNs)"
+    ok = ~torch.isnan(ref)
+    assert_parity(torch.where(ok, y, torch.zeros_like(y)), torch.where(ok, ref, torch.zeros_like(ref)), 1e-5, which + " non-NaN part")
+
+
+# ---- workspaces under hipGraph capture ------------------------------------------------------------------------------------------
+def test_captured_graph_survives_workspace_growth_and_eviction():
+    """a graph captured while a cached workspace existed baked its pointer in; growing / evicting the cache then freed
+    memory the graph still used.  Under capture the binding now allocates from the graph's pool: replays stay correct after the
+    eager cache has been grown, evicted and its memory overwritten."""
+    from mi355attn import _ffi
+    from mi355attn.modules import DoubleAttention
+    _, cbam, eca = _mods(64)
+    torch.manual_seed(1234)
+    da = DoubleAttention(64, 32, 32).eval().cuda()
+    torch.manual_seed(2)
+    x = torch.randn(4, 64, 32, 32, device="cuda")
+    with torch.no_grad():
+        want = [cbam(x).clone(), da(x).clone(), eca(x).clone()]          # eager first: the caches hold small buffers now
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        cbam(x), da(x), eca(x)                                           # warm-up on the side stream
+        with torch.cuda.graph(g, stream=s):
+            got = [cbam(x), da(x), eca(x)]
+    torch.cuda.current_stream().wait_stream(s)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert_parity(a.cpu(), b.cpu(), 1e-6, "first replay")
+    # grow every shared workspace, churn the dedicated cache, and scribble over whatever the allocator hands out next
+    big = torch.randn(16, 256, 56, 56, device="cuda")
+    with torch.no_grad():
+        for C in (256,):
+            se2, cbam2, eca2 = _mods(C)
+            cbam2(big), se2(big), eca2(big)
+        for hw in range(8, 8 + 2 * 70, 2):
+            _mods(16, 4)[1](torch.randn(1, 16, hw, hw, device="cuda"))
+    _ffi._ws_cache.clear()
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(16)]
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert_parity(a.cpu(), b.cpu(), 1e-6, "replay after the eager caches moved")
+    del junk
+
+
+# ---- guards -----------------------------------------------------------------------------------------------------------------------
+def test_autograd_warning_once_and_no_grad_fn():
+    from mi355attn import _ffi
+    se, _, _ = _mods(64)
+    x = torch.randn(2, 64, 8, 8, device="cuda")
+    _ffi._warned_autograd = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = se(x)                                          # parameters require grad, autograd is on
+        se(x)
+    assert y.grad_fn is None and not y.requires_grad
+    assert sum("forward-only" in str(i.message) for i in w) == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _ffi._warned_autograd = False
+        with torch.no_grad():
+            se(x)
+    assert not any("forward-only" in str(i.message) for i in w)
+
+
+def test_wrong_current_device_is_refused():
+    import mi355attn
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    se, _, _ = _mods(64)
+    se = se.to("cuda:1")
+    x = torch.randn(2, 64, 8, 8, device="cuda:1")
+    with pytest.raises(mi355attn.Mi355Error, match="current device"):
+        with torch.no_grad():
+            se(x)
+    with torch.cuda.device(1), torch.no_grad():
+        y = se(x)
+    assert_parity(y.cpu(), O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, "SE on cuda:1")
