@@ -416,6 +416,11 @@ int mi355_axpby_fwd(const float* x, const float* u, const float* gamma, float* y
                     long ldy, float alpha, mi355_stream_t stream);
 
 /* ---- measurement helpers --------------------------------------------------------------------------- */
+/* Bicubic resize of a token-major table (n0h*n0w, dim) -> (oh*ow, dim), the arithmetic of F.interpolate(mode="bicubic",
+ * align_corners=False, scale_factor=(scale_h, scale_w)) on the (1, dim, n0h, n0w) view: the position-embedding interpolation of
+ * vision_transformers/ViT.py:160-178 (run once per resolution by the host mirror, cached). */
+int mi355_bicubic_rows_fwd(const float* table, float* out, int n0h, int n0w, int oh, int ow, int dim, float scale_h, float scale_w,
+                           mi355_stream_t stream);
 /* float4 streaming copy of `bytes` (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py. */
 int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t stream);
 /* read-only float4 sweep of `bytes` (sum-reduced, result discarded; `sink` is a 4-byte device scratch). */

@@ -23,7 +23,7 @@ from .chan_attn import simam_forward, srm_forward, gct_gauss_forward, lct_forwar
 from .chan_attn import se_forward, eca_forward, eca_kernel_size, cbam_forward, cbam_channel_forward, \
     cbam_spatial_forward, double_attention_forward, eca_gate_explicit, spatial_conv_explicit
 from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_mlp_forward,
-                          vit_encoder_forward, vit_patch_embed_forward, vit_forward,
+                          vit_encoder_forward, vit_patch_embed_forward, vit_forward, bicubic_rows, vit_position_rows,
                           mixer_layer_forward, sdpa_core, mixer_forward, mhsa_forward, global_attention_forward,
                           broad_attention_forward, qk_v_attention_forward, knn_attention_forward, conv_attention_forward,
                           pooling_attention_forward)

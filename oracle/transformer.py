@@ -97,16 +97,65 @@ def vit_patch_embed_forward(img, w, b, dtype=torch.float32):
     return patches @ w.reshape(E, Cin * P * P).t() + b
 
 
-def vit_forward(img, p, num_heads, depth, dtype=torch.float32):
-    """VisionTransformer.forward -- vision_transformers/ViT.py:180-192 at the native resolution.
+def _cubic_coeffs(t):
+    """Cubic-convolution weights (A = -0.75) of the four taps around a sample at fractional offset t in [0, 1)."""
+    A = -0.75
+    x0, x1, x2, x3 = t + 1.0, t, 1.0 - t, 2.0 - t
+    return (((A * x0 - 5.0 * A) * x0 + 8.0 * A) * x0 - 4.0 * A, ((A + 2.0) * x1 - (A + 3.0)) * x1 * x1 + 1.0,
+            ((A + 2.0) * x2 - (A + 3.0)) * x2 * x2 + 1.0, ((A * x3 - 5.0 * A) * x3 + 8.0 * A) * x3 - 4.0 * A)
 
-    Tokens = [patch_0..patch_{n-1}, cls] (cls appended LAST, :183), + position_embedding, `depth`
-    encoder blocks, logits = head(token 0) (global_pool="token", :187-188); no final LayerNorm.
+
+def bicubic_rows(table, n0h, n0w, oh, ow, scale_h, scale_w, dtype=torch.float32):
+    """Restatement of F.interpolate(mode="bicubic", align_corners=False, scale_factor=(scale_h, scale_w)) on a token-major table
+    (n0h*n0w, dim) -> (oh*ow, dim): output (oy, ox) samples the source at (o + 0.5) / scale - 0.5 (coordinate NOT clamped for the
+    cubic filter), four taps per axis, tap indices clamped to the grid.  The call site is ViT.py:171-175."""
+    t = _t(table, dtype).reshape(n0h, n0w, -1)
+
+    def axis(n_out, n_in, scale):
+        r = (torch.arange(n_out, dtype=dtype) + 0.5) / scale - 0.5
+        f = torch.floor(r)
+        c = _cubic_coeffs(r - f)
+        idx = [torch.clamp(f.long() - 1 + i, 0, n_in - 1) for i in range(4)]
+        return idx, c
+
+    iy, cy = axis(oh, n0h, scale_h)
+    ix, cx = axis(ow, n0w, scale_w)
+    out = torch.zeros(oh, ow, t.shape[-1], dtype=dtype)
+    for i in range(4):
+        rows = t[iy[i]]                                            # (oh, n0w, dim)
+        acc = torch.zeros(oh, ow, t.shape[-1], dtype=dtype)
+        for j in range(4):
+            acc = acc + cx[j][None, :, None] * rows[:, ix[j]]
+        out = out + cy[i][:, None, None] * acc
+    return out.reshape(oh * ow, -1)
+
+
+def vit_position_rows(pe, patch, H, W, dtype=torch.float32):
+    """interpolate_pos_encoding -- ViT.py:160-178: the parameter at the native resolution; otherwise row 0 (`class_pos_embed`, :165)
+    followed by the other rows resized from their (n0, n0) grid to (W // patch, H // patch) with scale factors
+    ((W // patch + 0.1) / n0, (H // patch + 0.1) / n0) (:169-175: note that the WIDTH count scales the first grid axis)."""
+    import math
+    pe = _t(pe, dtype)
+    N = pe.shape[1] - 1
+    if (H // patch) * (W // patch) == N and W == H:
+        return pe
+    n0 = int(math.sqrt(N))
+    w0, h0 = W // patch, H // patch
+    body = bicubic_rows(pe[0, 1:], n0, n0, w0, h0, (w0 + 0.1) / math.sqrt(N), (h0 + 0.1) / math.sqrt(N), dtype)
+    return torch.cat([pe[:, 0:1], body[None]], dim=1)
+
+
+def vit_forward(img, p, num_heads, depth, dtype=torch.float32):
+    """VisionTransformer.forward -- vision_transformers/ViT.py:180-192.
+
+    Tokens = [patch_0..patch_{n-1}, cls] (cls appended LAST, :183), + position rows (interpolated off the native resolution,
+    :160-178), `depth` encoder blocks, logits = head(token 0) (global_pool="token", :187-188); no final LayerNorm.
     """
-    x = vit_patch_embed_forward(img, p["patch_embedding.proj.weight"], p["patch_embedding.proj.bias"], dtype)
+    w = p["patch_embedding.proj.weight"]
+    x = vit_patch_embed_forward(img, w, p["patch_embedding.proj.bias"], dtype)
     B = x.shape[0]
     cls = _t(p["cls_token"], dtype).expand(B, -1, -1)
-    x = torch.cat([x, cls], dim=1) + _t(p["position_embedding"], dtype)
+    x = torch.cat([x, cls], dim=1) + vit_position_rows(p["position_embedding"], w.shape[-1], img.shape[-2], img.shape[-1], dtype)
     for i in range(depth):
         x = vit_encoder_forward(x, _sub(p, f"blocks.{i}."), num_heads, dtype)
     return linear(x[:, 0], _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))

@@ -117,8 +117,9 @@ def conv_patch_embed_forward(img, p, dtype=torch.float32, eps=1e-5):
     return x.flatten(2).transpose(1, 2), (Hp, Wp)
 
 
-def class_attention_block_forward(x, p, num_heads, dtype=torch.float32):
-    """ClassAttentionBlock.forward -- xcit.py:218-231 with ClassAttention.forward :174-188 (tokens_norm=False).
+def class_attention_block_forward(x, p, num_heads, dtype=torch.float32, tokens_norm=False):
+    """ClassAttentionBlock.forward -- xcit.py:218-231 with ClassAttention.forward :174-188.  tokens_norm=True (xcit.py:221-222, the
+    XCiT-S/M/L configurations): norm2 is applied to EVERY token after the first residual, not to the cls token only.
 
     The attention returns cat(proj(cls attention), NORMED patch tokens) (:187), so the first residual gives patch tokens
     x + gamma1*LN1(x); norm2 is applied to the cls token only (:223); the second residual adds x_res to cat(gamma2*mlp(cls), x[1:])
@@ -141,15 +142,18 @@ def class_attention_block_forward(x, p, num_heads, dtype=torch.float32):
     cls = linear(cls, _t(p["attn.proj.weight"], dtype), _t(p["attn.proj.bias"], dtype))
     att = torch.cat([cls[:, None, :], u[:, 1:]], dim=1)
     x = x + _t(p["gamma1"], dtype) * att
-    c = layernorm(x[:, 0:1], _t(p["norm2.weight"], dtype), _t(p["norm2.bias"], dtype))
-    x = torch.cat([c, x[:, 1:]], dim=1)
+    if tokens_norm:
+        x = layernorm(x, _t(p["norm2.weight"], dtype), _t(p["norm2.bias"], dtype))
+    else:
+        c = layernorm(x[:, 0:1], _t(p["norm2.weight"], dtype), _t(p["norm2.bias"], dtype))
+        x = torch.cat([c, x[:, 1:]], dim=1)
     m = _sub(p, "mlp.")
     h = gelu(linear(x[:, 0:1], _t(m["fc1.weight"], dtype), _t(m["fc1.bias"], dtype)))
     c = _t(p["gamma2"], dtype) * linear(h, _t(m["fc2.weight"], dtype), _t(m["fc2.bias"], dtype))
     return x + torch.cat([c, x[:, 1:]], dim=1)
 
 
-def xcit_forward(img, p, num_heads=4, depth=12, cls_layers=2, dtype=torch.float32):
+def xcit_forward(img, p, num_heads=4, depth=12, cls_layers=2, dtype=torch.float32, tokens_norm=False):
     """XCiT.forward -- xcit.py:392-414 (xcit_nano_12_p16 :416-420): ConvPatchEmbed, + Fourier position rows, `depth` XCABlocks,
     cls token prepended, `cls_layers` ClassAttentionBlocks, LayerNorm, cls row, head."""
     x, (Hp, Wp) = conv_patch_embed_forward(img, _sub(p, "patch_embed."), dtype)
@@ -159,6 +163,6 @@ def xcit_forward(img, p, num_heads=4, depth=12, cls_layers=2, dtype=torch.float3
     B = x.shape[0]
     x = torch.cat([_t(p["cls_token"], dtype).expand(B, -1, -1), x], dim=1)
     for i in range(cls_layers):
-        x = class_attention_block_forward(x, _sub(p, f"cls_attn_blocks.{i}."), num_heads, dtype)
+        x = class_attention_block_forward(x, _sub(p, f"cls_attn_blocks.{i}."), num_heads, dtype, tokens_norm)
     x = layernorm(x, _t(p["norm.weight"], dtype), _t(p["norm.bias"], dtype))[:, 0]
     return linear(x, _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))

@@ -13,6 +13,10 @@
 //                     P re-packed in-lane as the A operand, O = O * alpha + P . V
 //   end:              O / sum -> per-wave LDS slab -> row-contiguous stores
 // q, k, v are addressed through row strides, so they can be slices of one fused projection or separate tensors.
+// Head widths above 64 (128 / 192 / 256: ViT.py:68-77 defaults to dim 768 / 4 heads = 192) run with the logits contracted over the
+// full width DQK and the value / output columns cut into DV = 64 wide slices, one workgroup per (query block, slice): a slice
+// recomputes the logits of its queries (the S^T product is 1/(1 + DQK/DV) ... of the work) but keeps O at 16 registers per lane, and
+// the slices of one query block sit next to each other in the grid, i.e. on one XCD, and share K through its L2.
 #include "common.h"
 #include "mma.h"
 #include <type_traits>
@@ -24,6 +28,7 @@ struct SdpaArgs {
     const float* bias;               // (heads, Nq, Nkv) fp32 or null; image b uses bias + b * bias_bstride
     long bias_bstride;
     int Nq, Nkv, heads;
+    int hd, nsl;                     // full head width (column stride between heads); value / output slices per head (hd / DV)
     long ldq, ldk, ldv, ldo;         // row strides in elements
     float scale;
 };
@@ -31,7 +36,7 @@ struct SdpaArgs {
 constexpr int KTILE = 64;            // keys per streamed tile
 constexpr int NWV = 4;               // waves per workgroup
 
-template <int PREC, int D, bool IO16>
+template <int PREC, int D, int DV, bool IO16>
 __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a) {
     constexpr int NTHR = NWV * 64;
     static_assert(!IO16 || PREC != 0, "16-bit I/O exists for the fp16 / bf16 operand modes only");
@@ -42,8 +47,8 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
     constexpr int NS = M_::NSPLIT;
     constexpr int KP = D + 8;                 // K row pitch (elements)
     constexpr int VP = KTILE + 4;             // V^T row pitch
-    constexpr int OP = IO16 ? D + 8 : D + 4;  // output slab pitch
-    constexpr int K_EL = KTILE * KP, V_EL = D * VP;
+    constexpr int OP = IO16 ? DV + 8 : DV + 4;  // output slab pitch
+    constexpr int K_EL = KTILE * KP, V_EL = DV * VP;
     using slab_t = typename std::conditional<IO16, unsigned short, float>::type;
     using gel = typename std::conditional<IO16, el, float>::type;
     __shared__ __attribute__((aligned(16))) unsigned short s_k[NS * K_EL];
@@ -53,12 +58,14 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     const int nqb = (a.Nq + 63) >> 6;
     int bid = xcd_contiguous_block();                       // query blocks of one head (same K / V) and neighbouring heads share an L2
+    int sl = 0;
+    if constexpr (DV != D) { sl = bid % a.nsl; bid /= a.nsl; }
     const int qb = bid % nqb; bid /= nqb;
     const int head = bid % a.heads;
     const int b = bid / a.heads;
-    const gel* qbase = static_cast<const gel*>(a.q) + (long)b * a.Nq * a.ldq + head * D;
-    const gel* kbase = static_cast<const gel*>(a.k) + (long)b * a.Nkv * a.ldk + head * D;
-    const gel* vbase = static_cast<const gel*>(a.v) + (long)b * a.Nkv * a.ldv + head * D;
+    const gel* qbase = static_cast<const gel*>(a.q) + (long)b * a.Nq * a.ldq + head * a.hd;
+    const gel* kbase = static_cast<const gel*>(a.k) + (long)b * a.Nkv * a.ldk + head * a.hd;
+    const gel* vbase = static_cast<const gel*>(a.v) + (long)b * a.Nkv * a.ldv + head * a.hd + sl * DV;
     const float* bias = a.bias ? a.bias + (long)b * a.bias_bstride + (long)head * a.Nq * a.Nkv : nullptr;
     const float L2E = 1.44269504088896340736f;
 
@@ -90,17 +97,18 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
 
     // ---- staging registers of one K / V tile ----------------------------------------------------------------------------------
     constexpr int EPV = IO16 ? 8 : 4;                          // elements per 16-byte global load
-    constexpr int DV_ = D / EPV;                               // vector columns per row
-    constexpr int NKI = (KTILE * DV_ + NTHR - 1) / NTHR;       // K vectors per thread
+    constexpr int DK_ = D / EPV;                               // vector columns per K row
+    constexpr int DV_ = DV / EPV;                              // vector columns per V row (of this slice)
+    constexpr int NKI = (KTILE * DK_ + NTHR - 1) / NTHR;       // K vectors per thread
     constexpr int NVI = ((KTILE / 4) * DV_ + NTHR - 1) / NTHR; // V (4 keys x one vector column) groups per thread
     using gv = typename std::conditional<IO16, v8, f4>::type;
     gv kreg[NKI], vreg[NVI][4];
     auto fetch = [&](int key0) {
 #pragma unroll
         for (int it = 0; it < NKI; ++it) {
-            const int idx = t + it * NTHR, key = idx / DV_, dc = idx % DV_;
+            const int idx = t + it * NTHR, key = idx / DK_, dc = idx % DK_;
             kreg[it] = gv{};
-            if (idx < KTILE * DV_ && key0 + key < a.Nkv)
+            if (idx < KTILE * DK_ && key0 + key < a.Nkv)
                 kreg[it] = *reinterpret_cast<const gv*>(kbase + (long)(key0 + key) * a.ldk + dc * EPV);
         }
 #pragma unroll
@@ -117,8 +125,8 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
     auto commit = [&]() {                                      // staging registers -> LDS in the MFMA operand format
 #pragma unroll
         for (int it = 0; it < NKI; ++it) {
-            const int idx = t + it * NTHR, key = idx / DV_, dc = idx % DV_;
-            if (idx < KTILE * DV_) {
+            const int idx = t + it * NTHR, key = idx / DK_, dc = idx % DK_;
+            if (idx < KTILE * DK_) {
                 if constexpr (IO16) {
                     *reinterpret_cast<v8*>(s_k + key * KP + dc * 8) = kreg[it];
                 } else {
@@ -154,9 +162,9 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
 
     // ---- running state: query column l15 of this lane (max, sum); O rows g*4 + r ------------------------------------------------
     float m_run = -INFINITY, l_run = 0.f;
-    f4 o[D / 16];
+    f4 o[DV / 16];
 #pragma unroll
-    for (int nt = 0; nt < D / 16; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < DV / 16; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
     const float sc = a.scale * L2E;                            // logits in log2 units: exp(x) = 2^(x*log2 e)
     const bool bias_vec = bias && (a.Nkv % 4 == 0) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0);
 
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, g * 4 + r, WAVE);
 #pragma unroll
-        for (int nt = 0; nt < D / 16; ++nt)
+        for (int nt = 0; nt < DV / 16; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
         // O += P . V : A = P (row q = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = V^T same enumeration
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
                     pf[1] = v8{e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
                 }
 #pragma unroll
-                for (int nt = 0; nt < D / 16; ++nt) {
+                for (int nt = 0; nt < DV / 16; ++nt) {
                     v8 vf[NS];
 #pragma unroll
                     for (int sp = 0; sp < NS; ++sp) {
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
     for (int r = 0; r < 4; ++r) inv[r] = 1.0f / __shfl(l_run, g * 4 + r, WAVE);
     slab_t* slab = s_o + wave * 16 * OP;
 #pragma unroll
-    for (int nt = 0; nt < D / 16; ++nt)
+    for (int nt = 0; nt < DV / 16; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float val = o[nt][r] * inv[r];
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
         }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    gel* obase = static_cast<gel*>(a.out) + (long)b * a.Nq * a.ldo + head * D;
-    constexpr int LPR = D / EPV, RPI = 64 / LPR;
+    gel* obase = static_cast<gel*>(a.out) + (long)b * a.Nq * a.ldo + head * a.hd + sl * DV;
+    constexpr int LPR = DV / EPV, RPI = 64 / LPR;
 #pragma unroll
     for (int it = 0; it < 16 / RPI; ++it) {
         const int r = it * RPI + lane / LPR, cv = (lane % LPR) * EPV;
@@ -283,16 +291,17 @@ __global__ __launch_bounds__(NWV * 64) void sdpa_stream_kernel(const SdpaArgs a)
     }
 }
 
-template <int D, bool IO16>
-int launch(const SdpaArgs& a, int B, int precision, hipStream_t st) {
-    const long blocks = (long)B * a.heads * ((a.Nq + 63) / 64);
+template <int D, int DV, bool IO16>
+int launch(SdpaArgs a, int B, int precision, hipStream_t st) {
+    a.hd = D; a.nsl = D / DV;
+    const long blocks = (long)B * a.heads * ((a.Nq + 63) / 64) * a.nsl;
     if (blocks > 0x7FFFFFFFL) return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_general_fwd: grid too large");
     const int grid = (int)blocks;
-    if (precision == 1) sdpa_stream_kernel<1, D, IO16><<<grid, NWV * 64, 0, st>>>(a);
-    else if (precision == 2) sdpa_stream_kernel<2, D, IO16><<<grid, NWV * 64, 0, st>>>(a);
+    if (precision == 1) sdpa_stream_kernel<1, D, DV, IO16><<<grid, NWV * 64, 0, st>>>(a);
+    else if (precision == 2) sdpa_stream_kernel<2, D, DV, IO16><<<grid, NWV * 64, 0, st>>>(a);
     else {
         if constexpr (IO16) return mi355::fail(MI355_EINVAL, "mi355_sdpa_general_fwd: 16-bit I/O needs precision 1 or 2");
-        else sdpa_stream_kernel<0, D, false><<<grid, NWV * 64, 0, st>>>(a);
+        else sdpa_stream_kernel<0, D, DV, false><<<grid, NWV * 64, 0, st>>>(a);
     }
     return MI355_OK;
 }
@@ -314,9 +323,12 @@ extern "C" int mi355_sdpa_general_fwd(const void* q, const void* k, const void* 
     a.Nq = Nq; a.Nkv = Nkv; a.heads = num_heads; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
-    if (head_dim == 32) rc = io16 ? launch<32, true>(a, B, precision, st) : launch<32, false>(a, B, precision, st);
-    else if (head_dim == 64) rc = io16 ? launch<64, true>(a, B, precision, st) : launch<64, false>(a, B, precision, st);
-    else return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_general_fwd: head_dim %d not in {32, 64}", head_dim);
+    if (head_dim == 32) rc = io16 ? launch<32, 32, true>(a, B, precision, st) : launch<32, 32, false>(a, B, precision, st);
+    else if (head_dim == 64) rc = io16 ? launch<64, 64, true>(a, B, precision, st) : launch<64, 64, false>(a, B, precision, st);
+    else if (head_dim == 128) rc = io16 ? launch<128, 64, true>(a, B, precision, st) : launch<128, 64, false>(a, B, precision, st);
+    else if (head_dim == 192) rc = io16 ? launch<192, 64, true>(a, B, precision, st) : launch<192, 64, false>(a, B, precision, st);
+    else if (head_dim == 256) rc = io16 ? launch<256, 64, true>(a, B, precision, st) : launch<256, 64, false>(a, B, precision, st);
+    else return mi355::fail(MI355_EUNSUPPORTED, "mi355_sdpa_general_fwd: head_dim %d not in {32, 64, 128, 192, 256}", head_dim);
     if (rc) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mi355_cswin_lepe_attn16_pair_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [ctypes.c_float, c_int, c_vp]),
     "mi355_class_attn_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
     "mi355_axpby_fwd": (c_int, [c_vp] * 4 + [ctypes.c_long, c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
+    "mi355_bicubic_rows_fwd": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_float, c_float, c_vp]),
     "mi355_stream_copy": (c_int, [c_vp, c_vp, c_size, c_vp]),
     "mi355_stream_read": (c_int, [c_vp, c_size, c_vp, c_vp]),
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),

@@ -886,13 +886,43 @@ def head_padded(weight, bias, groups, d, dp, axis):
     return _derived_get(anchors, ("headpad", groups, d, dp, axis), tag, build)
 
 
+SDPA_WIDTHS = (32, 64, 128, 192, 256)      # head widths mi355_sdpa_general_fwd is built for
+
+
 def attn_head_width(d):
     """Head width the streaming attention kernel runs a logical width d on (zero padded)."""
-    if d <= 32:
-        return 32
-    if d <= 64:
-        return 64
-    raise ValueError(f"attention head width {d} > 64 is outside the kernel's envelope")
+    for w in SDPA_WIDTHS:
+        if d <= w:
+            return w
+    raise ValueError(f"attention head width {d} > {SDPA_WIDTHS[-1]} is outside the kernel's envelope")
+
+
+def vit_pos_table(position_embedding, patch_size, H, W):
+    """Rows to add to the tokens of a ViT forward at image size (H, W): the parameter itself at the native resolution, otherwise
+    ViT.py:160-178 -- row 0 kept, rows 1.. resized bicubically from their (n0, n0) grid to (W // patch, H // patch) with the
+    reference's scale factors ((W // patch + 0.1) / n0, (H // patch + 0.1) / n0).  Cached per (H, W) and parameter version."""
+    import math
+    pe = position_embedding
+    N = pe.shape[1] - 1
+    E = pe.shape[2]
+    n_tok = (H // patch_size) * (W // patch_size)
+    if n_tok == N and W == H:
+        return pe.reshape(N + 1, E)
+    n0 = int(math.sqrt(N))
+    w0, h0 = W // patch_size, H // patch_size
+    if n0 * n0 != N:
+        raise ValueError("position embedding does not hold a square patch grid")
+
+    def build():
+        src = require_device_f32(pe.detach().reshape(N + 1, E), "position_embedding")
+        out = torch.empty(1 + w0 * h0, E, dtype=torch.float32, device=src.device)
+        axpby(src, out, 1, E, E, E)                                                       # row 0 as is
+        check(lib().mi355_bicubic_rows_fwd(ctypes.c_void_p(src.data_ptr() + E * 4), ctypes.c_void_p(out.data_ptr() + E * 4), n0, n0,
+                                           w0, h0, E, (w0 + 0.1) / math.sqrt(N), (h0 + 0.1) / math.sqrt(N), stream_ptr(src.device)),
+              "mi355_bicubic_rows_fwd")
+        return out
+
+    return _derived_get((pe,), ("vitpos", patch_size, H, W), (pe._version, pe.data_ptr()), build)
 
 
 def dwconv_patch_tokens(x, conv_w, conv_b, bn, H, W, sr):

@@ -8,5 +8,5 @@ from .xcit import (LPI, XCA, ClassAttention, ClassAttentionBlock, ConvPatchEmbed
 from .zoo import GCT, LCT, SRM, GaussianGCT, simam_module  # noqa: F401
 from .mhsa import (Broad_Attention, ConvAttention, GlobalAttention, KNNAttention, PoolingAttention, QKVSplitAttention, SRAttention,  # noqa: F401
                    SRAttentionRelPos, SRConvAttention)
-from .se_variants import SELayerBias, SELayerHidden, SqueezeExcite  # noqa: F401
+from .se_variants import SELayerBias, SELayerBias4, SELayerHidden, SqueezeExcite  # noqa: F401
 from .axis import BAM, CAM, PAM, CoordinateAttention, GCModule, SKLayer, TripletAttention  # noqa: F401

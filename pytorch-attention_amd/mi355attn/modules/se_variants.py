@@ -2,6 +2,7 @@
 bias / gate options (mi355_se_ex_fwd).  Module level only: the surrounding networks are convolution stacks and are not mirrored.
 
   SELayerBias      cnns/efficientnet.py:13-28, cnns/mnasnet.py:11-26   Linear layers WITH bias, ReLU, sigmoid
+  SELayerBias4     cnns/efficientnetv2.py:14-29                         the same, default ratio 4
   SELayerHidden    cnns/mobilenetv3.py:15-30                            explicit hidden width, no bias
   SqueezeExcite    cnns/ghostnet.py:48-65                               1x1 convs with bias, ReLU, hard-sigmoid gate
 (vision_transformers/moat.py:18-33 is the plain bias-free SELayer: attention_mechanisms.se_module.SELayer serves it.)
@@ -20,6 +21,13 @@ class SELayerBias(nn.Module):
 
     def forward(self, x):
         return F.se_ex_forward(x, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias)
+
+
+class SELayerBias4(SELayerBias):
+    """cnns/efficientnetv2.py:14-29: the same module with a default reduction ratio of 4."""
+
+    def __init__(self, channels, ratio=4):
+        super().__init__(channels, ratio)
 
 
 class SELayerHidden(nn.Module):

@@ -59,20 +59,40 @@ class Attention(nn.Module):
         self.precision = precision
         self.attn_drop, self.proj_drop = attn_drop, proj_drop   # identity at inference
 
-    def fast_ok(self, n_tokens):
-        """16-bit dataflow applies: 16-bit operand mode, GEMM shapes in the fast envelope, core kernel built for (d, N)."""
+    def fast_ok(self, n_tokens=None):
+        """16-bit dataflow applies: 16-bit operand mode, GEMM shapes in the fast envelope, a core kernel built for the head width
+        (the K/V-resident kernel for d in {32, 64} and N <= 224, the streaming kernel for any N and d in F.SDPA_WIDTHS)."""
         d = self.qkv.in_features // self.num_heads
-        return _fast(self.precision, self.qkv, self.proj) and d in (32, 64) and n_tokens <= 224
+        return _fast(self.precision, self.qkv, self.proj) and d in F.SDPA_WIDTHS
+
+    def _core(self, qkv, fast):
+        """softmax(q k^T scale) v on the (B,N,3C) projection.  Short sequences of 32 / 64 wide heads stay in LDS (attn.hip); longer
+        sequences (384 px input: N = 577) and wider heads (ViT.py:68 defaults to 4 heads: d = 192 at dim 768) stream K / V
+        (sdpa_general.hip); any other width runs zero padded to the next built one."""
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        d = C // self.num_heads
+        if d in (32, 64) and N <= 224:
+            return F.sdpa16(qkv, self.num_heads, self.scale, precision=self.precision) if fast else \
+                F.sdpa(qkv, self.num_heads, self.scale, precision=self.precision)
+        return F.sdpa_general(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.num_heads, self.scale, precision=self.precision)
 
     def forward(self, x, resid=None):
-        if self.fast_ok(x.shape[1]):
+        d = self.qkv.in_features // self.num_heads
+        if d not in F.SDPA_WIDTHS:                                                           # odd head width: padded projections
+            from .mhsa import _fused_qkv_attention
+            out, _, _ = _fused_qkv_attention(x if x.dtype == torch.float32 else x.float(), self.qkv, self.proj, self.num_heads, d,
+                                             self.scale, self.precision)
+            return out if resid is None else F.axpby(out, torch.empty_like(out), out.numel() // out.shape[-1], out.shape[-1],
+                                                     out.shape[-1], out.shape[-1], u=resid, ldu=out.shape[-1])
+        if self.fast_ok():
             p = F._prec(self.precision)                                                     # q/k/v/ctx stay 16-bit in HBM
             x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
             qkv16 = F.linear16(x16, F.weight16(self.qkv.weight, p), _bias(self.qkv), out16=True, precision=p)
-            ctx16 = F.sdpa16(qkv16, self.num_heads, self.scale, precision=p)
+            ctx16 = self._core(qkv16, True)
             return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, resid=resid, precision=p)
         qkv = F.linear(x, self.qkv.weight, _bias(self.qkv), precision=self.precision)      # (B,N,3C)
-        ctx = F.sdpa(qkv, self.num_heads, self.scale, precision=self.precision)             # (B,N,C)
+        ctx = self._core(qkv, False)                                                        # (B,N,C)
         return F.linear(ctx, self.proj.weight, self.proj.bias, resid=resid, precision=self.precision)
 
 
@@ -142,13 +162,9 @@ class VisionTransformer(nn.Module):
     def forward(self, x):
         B, _, H, W = x.shape
         ps = self.patch_embedding.patch_size
-        n = self.position_embedding.shape[1] - 1
-        if (H // ps) * (W // ps) != n or H != W:
-            raise NotImplementedError("position-embedding interpolation (ViT.py:160-178) is outside the MI355X "
-                                      "hot path: run at the native resolution")
+        pos = F.vit_pos_table(self.position_embedding, ps, H, W)     # ViT.py:160-178: bicubic resize off the native grid (cached)
         tok = F.patch_embed(x, self.patch_embedding.proj.weight, self.patch_embedding.proj.bias,
-                            self.cls_token.reshape(-1), self.position_embedding.reshape(n + 1, -1), ps,
-                            self.precision)
+                            self.cls_token.reshape(-1), pos, ps, self.precision)
         for blk in self.blocks:
             tok = blk(tok)
         if self.global_pool == "token":
@@ -156,5 +172,5 @@ class VisionTransformer(nn.Module):
         elif self.global_pool == "avg":
             pooled = F.token_mean(tok, skip_first=1)
         else:
-            raise ValueError(self.global_pool)
+            pooled = tok                                         # ViT.py:187-190: any other value pools nothing, head on every token
         return F.linear(pooled, self.head.weight, self.head.bias, precision=self.precision)

@@ -246,18 +246,23 @@ class ClassAttentionBlock(nn.Module):
             self.gamma2 = nn.Parameter(eta * torch.ones(dim), requires_grad=True)
         else:
             self.gamma1, self.gamma2 = 1.0, 1.0
-        if tokens_norm:
-            raise NotImplementedError("tokens_norm=True (LayerNorm over all tokens in the class-attention stage) is not built")
-        self.tokens_norm = tokens_norm
+        self.tokens_norm = tokens_norm           # xcit.py:221-222: norm2 over every token instead of the cls token only
 
     def forward(self, x, H, W, mask=None):
         B, N, C = x.shape
         g1 = self.gamma1 if isinstance(self.gamma1, torch.Tensor) else None
         g2 = self.gamma2 if isinstance(self.gamma2, torch.Tensor) else None
         u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        out = torch.empty_like(x)
-        # patch tokens: 2 * (x + g1 * LN1(x)); the cls rows written here are replaced below
-        F.axpby(x, out, B * N, C, C, C, alpha=2.0, u=u, ldu=C, gamma=None if g1 is None else _twice(self, g1))
+        if self.tokens_norm:
+            # patch tokens: 2 * LN2(x + g1 * LN1(x)) -- the doubling of the second residual rides in the LayerNorm's affine part
+            t1 = torch.empty_like(x)
+            F.axpby(x, t1, B * N, C, C, C, alpha=1.0, u=u, ldu=C, gamma=g1)
+            w2, b2 = _twice(self, self.norm2.weight, "_n2w"), _twice(self, self.norm2.bias, "_n2b")
+            out = F.layernorm(t1, w2, b2, self.norm2.eps)
+        else:
+            out = torch.empty_like(x)
+            # patch tokens: 2 * (x + g1 * LN1(x)); the cls rows written here are replaced below
+            F.axpby(x, out, B * N, C, C, C, alpha=2.0, u=u, ldu=C, gamma=None if g1 is None else _twice(self, g1))
         # cls token: c1 = x0 + g1 * proj(attn); c2 = LN2(c1); out0 = c2 + g2 * mlp(c2)
         c1 = torch.empty(B, C, dtype=torch.float32, device=x.device)
         F.axpby(x, c1, B, C, N * C, C, u=self.attn.cls_out(u), ldu=C, gamma=g1)
@@ -267,15 +272,15 @@ class ClassAttentionBlock(nn.Module):
         return out
 
 
-def _twice(owner, g):
-    """2*gamma1 for the doubled patch-token path, cached per parameter version on the block."""
+def _twice(owner, g, slot="_g1x2"):
+    """2 * parameter for the doubled patch-token path, cached per parameter version on the block."""
     tag = (g._version, g.data_ptr())
-    hit = getattr(owner, "_g1x2", None)
+    hit = getattr(owner, slot, None)
     if hit is None or hit[0] != tag:
         buf = torch.empty_like(g.detach())
         F.axpby(g.detach(), buf, 1, g.numel(), g.numel(), g.numel(), alpha=2.0)
         hit = (tag, buf)
-        owner._g1x2 = hit
+        setattr(owner, slot, hit)
     return hit[1]
 
 

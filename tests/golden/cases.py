@@ -6,6 +6,8 @@ constructor arguments, the input shape of the seed protocol (oracle/params.py) a
 restates the forward.  ``small`` cases also get their full output tensor committed under
 ``tests/golden/small/``; all cases get fp64 checksums + strided samples in ``golden.json``.
 """
+import torch.nn as nn
+
 import oracle as O
 
 
@@ -202,6 +204,34 @@ CASES = [
     dict(id="se_ghost", mod="cnns.ghostnet", cls="SqueezeExcite", args=(160,), shape=(2, 160, 14, 14), small=True, prep="perturb_all",
          oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["conv_reduce.weight"], sd["conv_reduce.bias"], sd["conv_expand.weight"],
                                                   sd["conv_expand.bias"], "hard_sigmoid", dt)),
+    # ---- round 2: the envelope the reference's own defaults need (VERDICT r1 missing 1-3, 6) -------------------------------------
+    # ViT.py:68 / :126 default to 4 heads (d = 192 at dim 768): streaming core with 64-wide value slices; d = 128 and a padded odd
+    # width (96 -> 128); 384 px and a rectangular input through interpolate_pos_encoding (ViT.py:160-178), N = 577 / 225 tokens
+    dict(id="vit_attn_h4", mod="vision_transformers.ViT", cls="Attention", args=(768,), shape=(2, 197, 768),
+         oracle=lambda x, sd, dt: O.vit_attention_forward(x, sd, 4, dt)),
+    dict(id="vit_attn_d128", mod="vision_transformers.ViT", cls="Attention", args=(640, 5), kwargs=dict(qkv_bias=True), shape=(2, 50, 640),
+         oracle=lambda x, sd, dt: O.vit_attention_forward(x, sd, 5, dt)),
+    dict(id="vit_attn_d96", mod="vision_transformers.ViT", cls="Attention", args=(768, 8), shape=(2, 65, 768),
+         oracle=lambda x, sd, dt: O.vit_attention_forward(x, sd, 8, dt)),
+    dict(id="vit_default_heads4", mod="vision_transformers.ViT", cls="VisionTransformer", kwargs=dict(depths=2), shape=(2, 3, 224, 224),
+         slow=True, oracle=lambda x, sd, dt: O.vit_forward(x, sd, 4, 2, dt)),
+    dict(id="vit_384", mod="vision_transformers.ViT", cls="VisionTransformer", kwargs=dict(num_heads=12, depths=2), shape=(2, 3, 384, 384),
+         slow=True, oracle=lambda x, sd, dt: O.vit_forward(x, sd, 12, 2, dt)),
+    dict(id="vit_rect", mod="vision_transformers.ViT", cls="VisionTransformer", kwargs=dict(num_heads=12, depths=1), shape=(2, 3, 224, 256),
+         slow=True, oracle=lambda x, sd, dt: O.vit_forward(x, sd, 12, 1, dt)),
+    # XCiT-S12/16 as SURVEY section 2 spells it (no factory in the reference): tokens_norm=True (xcit.py:221-222)
+    dict(id="xcit_cls_block_tn", mod="vision_transformers.xcit", cls="ClassAttentionBlock", args=(128, 4),
+         kwargs=dict(qkv_bias=True, eta=1.0, tokens_norm=True), shape=(2, 197, 128), fwd_args=(14, 14),
+         oracle=lambda x, sd, dt: O.class_attention_block_forward(x, sd, 4, dt, True)),
+    dict(id="xcit_s12_full", mod="vision_transformers.xcit", cls="XCiT",
+         kwargs=dict(patch_size=16, embed_dim=384, depth=12, num_heads=8, mlp_ratio=4, qkv_bias=True, norm_layer=nn.LayerNorm, eta=1.0,
+                     tokens_norm=True), shape=(2, 3, 224, 224), slow=True, prep="perturb_batchnorm",
+         oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 8, 12, 2, dt, True)),
+    # the two squeeze-excite copies that had no import shim
+    dict(id="se_effnetv2", mod="cnns.efficientnetv2", cls="SELayer", args=(96,), shape=(2, 96, 28, 28),
+         oracle=lambda x, sd, dt: O.se_ex_forward(x, sd["fc.0.weight"], sd["fc.0.bias"], sd["fc.2.weight"], sd["fc.2.bias"], "sigmoid", dt)),
+    dict(id="se_moat", mod="vision_transformers.moat", cls="SELayer", args=(64,), shape=(2, 64, 32, 32),
+         oracle=lambda x, sd, dt: O.se_forward(x, sd["fc.0.weight"], sd["fc.2.weight"], dt)),
     dict(id="xcit_nano_full", mod="vision_transformers.xcit", cls="xcit_nano_12_p16", shape=(2, 3, 224, 224), slow=True,
          prep="perturb_batchnorm", oracle=lambda x, sd, dt: O.xcit_forward(x, sd, 4, 12, 2, dt)),
 ]
