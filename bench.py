@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--precision", type=int, default=None, help="MFMA operand precision 0 strict / 1 fp16 / 2 bf16")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="mi355_set_option override (tuning experiments)")
     ap.add_argument("--only", default=None, help="keep only the blocks of the workload whose name contains this text (profiling aid)")
+    ap.add_argument("--gather", default="auto", choices=("auto", "capi", "torch"),
+                    help="end-of-forward all-gather of the ViT logits: 'capi' = mi355_allgather_f32 (RCCL behind the C ABI), 'torch' = "
+                         "torch.distributed all_gather_into_tensor, 'auto' (default) = capi when its start-up self-test passes on every "
+                         "rank, else torch -- the choice is reported in config.gather")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + barrier + max-reduce of an empty step on the gloo backend, no GPU work: what the CPU tests "
                          "use to check that --gpus N really runs N ranks")
@@ -228,6 +232,18 @@ def main(argv=None):
     if args.precision is not None:
         mi355attn.set_default_precision(args.precision)
 
+    comm, gather_kind = None, "none (single rank)"
+    if dist is not None:
+        gather_kind = "torch.distributed all_gather_into_tensor (RCCL)"
+        if args.gather in ("auto", "capi"):
+            comm, why = make_comm(dist, dev, rank, world)
+            if comm is not None:
+                gather_kind = "mi355_allgather_f32 (RCCL behind the C ABI)"
+            elif args.gather == "capi":
+                raise SystemExit("--gather capi: " + why)
+            else:
+                gather_kind += " [C-ABI communicator self-test failed: %s]" % why
+
     wl = WORKLOADS[args.workload](args.batch, dev)
     wname, blocks = wl["name"], wl["blocks"]
     if wl.get("gather") is not None:                      # whole-workload gather (full-model workloads): applies to every block
@@ -243,7 +259,7 @@ def main(argv=None):
         y = b["module"](b["x"], *b.get("fwd_args", ()))
         if b.get("gather") and dist is not None:
             from mi355attn.dist import gather_batch
-            y = gather_batch(y)                            # one RCCL all-gather over xGMI (1 MB per rank for ViT logits)
+            y = gather_batch(y, comm=comm)                 # one RCCL all-gather over xGMI (1 MB per rank for ViT logits)
         return y
 
     def step():
@@ -336,7 +352,7 @@ def main(argv=None):
                    "chunk_images": mi355attn.get_option("chunk_images"), "nt": mi355attn.get_option("nt"),
                    "reverse": mi355attn.get_option("reverse"),
                    "precision": {0: "strict(bf16x3)", 1: "fp16-mfma", 2: "bf16-mfma"}[mi355attn.default_precision()],
-                   "blocks": per_block, "stream_copy_GBps": copy_gbs},
+                   "gather": gather_kind, "blocks": per_block, "stream_copy_GBps": copy_gbs},
         "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                      "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["block"], "ms": dom["ms"]},
     }
@@ -346,6 +362,30 @@ def main(argv=None):
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def make_comm(dist, dev, rank, world):
+    """C-ABI communicator + a self-test all-gather checked on every rank (outside the timed region).  Returns (comm, None) when every
+    rank passed, else (None, reason) -- bench.py then gathers through torch.distributed and says so in its JSON line."""
+    import torch
+    comm, why = None, ""
+    try:
+        from mi355attn.dist import RcclComm
+        comm = RcclComm(device=dev)
+        got = comm.all_gather(torch.full((3, 5), float(rank + 1), device=dev))
+        torch.cuda.synchronize()
+        want = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(3)[:, None].expand(-1, 5)
+        if not torch.equal(got, want):
+            why = "self-test all-gather returned wrong data on rank %d" % rank
+    except Exception as e:                                   # noqa: BLE001  (reported, not swallowed: see config.gather)
+        why = "%s: %s" % (type(e).__name__, str(e)[:200])
+    flag = torch.tensor([1.0 if why else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if float(flag.item()) > 0:
+        if comm is not None and not why:
+            why = "another rank failed"
+        return None, why or "failed"
+    return comm, None
 
 
 def cpu_baseline(blocks, args):

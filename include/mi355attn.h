@@ -416,6 +416,20 @@ int mi355_axpby_fwd(const float* x, const float* u, const float* gamma, float* y
                     long ldy, float alpha, mi355_stream_t stream);
 
 /* ---- measurement helpers --------------------------------------------------------------------------- */
+/* ---- multi-GPU: the end-of-forward all-gather (the reference has no distributed code, this is the collective the
+ * batch-sharded ViT forward of BASELINE configs[4] ends with) --------------------------------------------------------------------
+ * One process per GPU.  Rank 0 calls mi355_comm_unique_id and hands the MI355_COMM_ID_BYTES bytes to every rank through the host's
+ * own bootstrap (the Python mirror uses the torch.distributed store); every rank then calls mi355_comm_init with the SAME id on its
+ * current HIP device (collective: returns once all `world` ranks have joined) and owns the opaque handle until mi355_comm_destroy.
+ * mi355_allgather_f32: every rank contributes `count` floats from `send`; `recv` (world * count floats) receives the contributions
+ * in rank order on every rank -- one ncclAllGather over xGMI, asynchronous on `stream`.  RCCL is bound at run time (the copy already
+ * loaded in the process wins); without a loadable librccl these return MI355_EUNSUPPORTED. */
+#define MI355_COMM_ID_BYTES 128
+int mi355_comm_unique_id(void* id_out, size_t id_bytes);
+int mi355_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);
+int mi355_allgather_f32(void* comm, const float* send, float* recv, size_t count, mi355_stream_t stream);
+int mi355_comm_destroy(void* comm);
+
 /* Bicubic resize of a token-major table (n0h*n0w, dim) -> (oh*ow, dim), the arithmetic of F.interpolate(mode="bicubic",
  * align_corners=False, scale_factor=(scale_h, scale_w)) on the (1, dim, n0h, n0w) view: the position-embedding interpolation of
  * vision_transformers/ViT.py:160-178 (run once per resolution by the host mirror, cached). */

@@ -93,6 +93,10 @@ SIGNATURES = {
     "mi355_cswin_lepe_attn16_pair_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [ctypes.c_float, c_int, c_vp]),
     "mi355_class_attn_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
     "mi355_axpby_fwd": (c_int, [c_vp] * 4 + [ctypes.c_long, c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
+    "mi355_comm_unique_id": (c_int, [c_vp, c_size]),
+    "mi355_comm_init": (c_int, [c_vp, c_size, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "mi355_allgather_f32": (c_int, [c_vp, c_vp, c_vp, c_size, c_vp]),
+    "mi355_comm_destroy": (c_int, [c_vp]),
     "mi355_bicubic_rows_fwd": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_float, c_float, c_vp]),
     "mi355_stream_copy": (c_int, [c_vp, c_vp, c_size, c_vp]),
     "mi355_stream_read": (c_int, [c_vp, c_size, c_vp, c_vp]),

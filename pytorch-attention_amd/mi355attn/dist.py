@@ -26,12 +26,55 @@ def shard_batch(x, rank=None, world=None):
     return x[lo:hi]
 
 
-def gather_batch(y_local, global_batch=None, group=None):
+class RcclComm:
+    """Communicator of the C ABI (include/mi355attn.h: mi355_comm_init / mi355_allgather_f32 / mi355_comm_destroy): the all-gather
+    is issued by libmi355attn on torch's current stream, RCCL over xGMI underneath.  The 128-byte unique id is created by rank 0 and
+    handed to the other ranks through the already initialised torch.distributed group (its store is the bootstrap; any backend)."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes
+        from . import _ffi
+        self._ffi = _ffi
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _ffi.check(_ffi.lib().mi355_comm_unique_id(buf, 128), "mi355_comm_unique_id")
+        if self.world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _ffi.check(_ffi.lib().mi355_comm_init(buf, 128, self.rank, self.world, ctypes.byref(self._h)), "mi355_comm_init")
+
+    def all_gather(self, y_local):
+        """(n, ...) fp32 on every rank -> (world * n, ...) in rank order on every rank (equal shards)."""
+        f = self._ffi
+        y_local = f.require_device_f32(y_local, "y_local")
+        out = torch.empty((self.world * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=torch.float32, device=y_local.device)
+        f.check(f.lib().mi355_allgather_f32(self._h, f.dptr(y_local), f.dptr(out), y_local.numel(), f.stream_ptr(y_local.device)),
+                "mi355_allgather_f32")
+        return out
+
+    def close(self):
+        if self._h:
+            self._ffi.check(self._ffi.lib().mi355_comm_destroy(self._h), "mi355_comm_destroy")
+            self._h = None
+
+
+def gather_batch(y_local, global_batch=None, group=None, comm=None):
     """All-gather per-rank outputs (axis 0) into the full batch, in rank order, on every rank.
 
-    Equal shards use one all_gather_into_tensor (a single RCCL all-gather: 1 MB per rank for ViT logits);
+    Equal shards use ONE all-gather (1 MB per rank for ViT logits): through the C ABI when an RcclComm is passed
+    (mi355_allgather_f32), else torch.distributed's all_gather_into_tensor (RCCL under the "nccl" backend, gloo in the CPU tests);
     ragged shards fall back to all_gather on padded buffers.
     """
+    if comm is not None and (global_batch is None or global_batch % comm.world == 0):
+        return y_local if comm.world == 1 else comm.all_gather(y_local)
     world = dist.get_world_size(group)
     if world == 1:
         return y_local

@@ -201,3 +201,21 @@ def test_wrong_current_device_is_refused():
     with torch.cuda.device(1), torch.no_grad():
         y = se(x)
     assert_parity(y.cpu(), O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu()), 1e-5, "SE on cuda:1")
+
+
+# ---- the all-gather behind the C ABI --------------------------------------------------------------------------------------------------
+def test_capi_allgather_single_rank():
+    """mi355_comm_unique_id / mi355_comm_init / mi355_allgather_f32 / mi355_comm_destroy on a world of one (all this box has): the
+    gathered tensor equals the contribution, twice in a row on the same communicator, and gather_batch routes through it."""
+    from mi355attn.dist import RcclComm, gather_batch
+    comm = RcclComm()
+    try:
+        assert (comm.rank, comm.world) == (0, 1)
+        x = torch.randn(256, 1000, device="cuda")
+        for _ in range(2):
+            y = comm.all_gather(x)
+            torch.cuda.synchronize()
+            assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)
+        assert gather_batch(x, comm=comm) is x
+    finally:
+        comm.close()
