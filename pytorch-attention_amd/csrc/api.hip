@@ -166,7 +166,7 @@ int mi355_set_option(const char* key, long value) {
         return MI355_OK;
     }
     if (std::strcmp(key, "gemm_variant") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= 14);
+        MI355_CHECK_ARG(value >= 0 && value <= 31);
         mi355::g_gemm_variant.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }

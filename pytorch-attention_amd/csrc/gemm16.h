@@ -1,0 +1,35 @@
+// gemm16.h -- argument block and MFMA operand traits shared by the 16-bit GEMM kernels (gemm16.hip, gemm16_p8.hip).
+#pragma once
+#include "common.h"
+#include "mma.h"
+
+namespace g16 {
+
+constexpr int BK = 64;
+
+struct G16Args {
+    const void* A; const void* B; void* C;
+    const float* bias; const float* gamma; const float* resid;
+    int M, N, K, lda, ldb, ldc;
+    int act;
+    int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
+    const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
+    float ln_eps;
+};
+
+template <typename T> struct Vec8;
+template <> struct Vec8<_Float16> { using t = h8; using t4 = h4; };
+template <> struct Vec8<__bf16> { using t = b8; using t4 = b4; };
+
+template <typename T>
+__device__ __forceinline__ f4 mma16(typename Vec8<T>::t a, typename Vec8<T>::t b, f4 c);
+template <>
+__device__ __forceinline__ f4 mma16<_Float16>(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <>
+__device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+}  // namespace g16
+
+namespace mi355 {
+int gemm16_p8(const g16::G16Args& g, int out16, int precision, hipStream_t st);     // gemm16_p8.hip
+}

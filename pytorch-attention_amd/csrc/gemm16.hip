@@ -12,33 +12,10 @@
 // the DMA writes lane-linear; bank conflicts of the fragment reads are removed by an XOR swizzle applied on the SOURCE address
 // (chunk ^= row & 7) and again on the ds_read (cdna_hip_programming.md rule 21).  One LDS buffer + two barriers per K-step and
 // three resident workgroups per CU (24 waves) measured faster than double buffering at two workgroups per CU.
-#include "common.h"
-#include "mma.h"
+#include "gemm16.h"
 
 namespace {
-
-constexpr int BK = 64;
-
-struct G16Args {
-    const void* A; const void* B; void* C;
-    const float* bias; const float* gamma; const float* resid;
-    int M, N, K, lda, ldb, ldc;
-    int act;
-    int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
-    const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
-    float ln_eps;
-};
-
-template <typename T> struct Vec8;
-template <> struct Vec8<_Float16> { using t = h8; using t4 = h4; };
-template <> struct Vec8<__bf16> { using t = b8; using t4 = b4; };
-
-template <typename T>
-__device__ __forceinline__ f4 mma16(typename Vec8<T>::t a, typename Vec8<T>::t b, f4 c);
-template <>
-__device__ __forceinline__ f4 mma16<_Float16>(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-template <>
-__device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+using namespace g16;
 
 // Tile BM x BN x 64 per workgroup of WM x WN waves; each wave owns a (BM/WM) x (BN/WN) sub-tile = MF x NF MFMA 16x16 tiles.
 // TR = true: the product is written TRANSPOSED per image -- row m = img * tr_rows + c, column n -> Y[(img * N + n) * tr_rows + c]
@@ -638,6 +615,12 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
     hipStream_t st = static_cast<hipStream_t>(stream);
     long variant = mi355::opt_gemm_variant();
+    if (variant == 15) {                   // persistent 256 x 256 kernel (gemm16_p8.hip)
+        const int rc = mi355::gemm16_p8(g, out16, precision, st);
+        if (rc != MI355_OK) return mi355::fail(rc, "mi355_linear16_fwd: persistent kernel does not take this shape");
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     if (variant == 0 && (K == 64 || K == 128) && M >= 2048 && (!out16 || (N & 7) == 0)) {       // short-K, HBM-bound: weight-stationary streaming kernel
         int ncu = 256, dev = 0;
         (void)hipGetDevice(&dev);
@@ -661,6 +644,21 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
 #undef WS
         MI355_LAUNCH_CHECK();
         return MI355_OK;
+    }
+    if (variant == 0 && (N & 7) == 0 && !(out16 && resid)) {
+        // Persistent 256 x 256 kernel (gemm16_p8.hip) where its one-workgroup-per-CU rounds fill the chip: 16-bit outputs (light
+        // epilogue) when the last round is >= 85 % full, fp32 + residual outputs only for long K (the epilogue of a lone workgroup
+        // is exposed, the 3-workgroups-per-CU kernel below hides it behind its neighbours).  profiles/r02_gemm_p8.md
+        const int ncu = mi355::resident_slots(1);
+        const long ntiles = (long)cdiv(M, 256) * cdiv(N, 256);
+        const long rounds = (ntiles + ncu - 1) / ncu;
+        const bool full = ntiles >= ncu && ntiles * 100 >= rounds * ncu * 85;
+        if ((out16 && full && K >= 256) || (!out16 && ntiles >= 2L * ncu && K >= 2048 && N >= 768)) {
+            if (mi355::gemm16_p8(g, out16, precision, st) == MI355_OK) {
+                MI355_LAUNCH_CHECK();
+                return MI355_OK;
+            }
+        }
     }
     if (variant == 0) {        // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups
         variant = (N <= 64) ? 9 : (N < 256 ? 1 : 7);   // per CU; narrow outputs use 256x64 / 128x128 tiles instead
