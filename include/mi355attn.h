@@ -76,6 +76,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
  *                   kernels instead, so captured graphs are replay-safe by construction.
  *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status.
+ *   "gemm_splitk"   1 (default) = mi355_linear16_ws_fwd may cut the tiles of the persistent kernel's last partial round along K
+ *                   (K >= 1536 only); the fp32 summation order of those tiles then differs from the unsplit order, so a row's
+ *                   result can depend (at rounding level) on where its tile falls in the launch; 0 = never split: every output row
+ *                   is bit-identical whatever the batch around it.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);
@@ -287,6 +291,15 @@ int mi355_layernorm16_fwd(const float* x, const float* weight, const float* bias
  * Needs K % 64 == 0, N % 4 == 0, ldx % 8 == 0 (other shapes: cast back and use mi355_linear_fwd). */
 int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
                        int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, mi355_stream_t stream);
+/* The same with a scratch buffer of mi355_linear16_workspace_bytes(M, N, K) bytes (0 = this shape needs none): the persistent
+ * 256 x 256 kernel then cuts the tiles of its last, partially filled round along K across the otherwise idle CUs (partial
+ * accumulators travel through `ws`; N = 768 outputs of ViT-Base take 2.33 rounds instead of 3).  Results are bit-identical to
+ * mi355_linear16_fwd only where the split does not apply; with it the fp32 summation order over K changes (covered by the same
+ * tolerance).  ws may be NULL / too small: identical to mi355_linear16_fwd. */
+size_t mi355_linear16_workspace_bytes(int M, int N, int K);
+int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
+                          int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, void* ws, size_t ws_bytes,
+                          mi355_stream_t stream);
 /* Channel-major token mixing (mlp_mixer.py:45-47: norm1 -> transpose(1,2) -> token_mlp -> transpose(1,2) -> + x) without transposes
  * in HBM.  mi355_layernorm16_t_fwd writes LayerNorm(x (B,N,C)) TRANSPOSED per image in 16 bit: ut (B, C, NP), zero-filled for
  * N <= n < NP (NP % 32 == 0; pick NP % 64 == 0 so that it is a valid K for mi355_linear16_fwd against a weight zero-padded to

@@ -17,6 +17,7 @@ long  opt_chunk_images();
 long  opt_nt();
 long  opt_reverse();
 long  opt_gemm_variant();
+long  opt_gemm_splitk();
 long  opt_eca_single();
 long  opt_se_single();
 long  opt_se_occ();

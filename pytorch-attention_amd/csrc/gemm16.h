@@ -31,5 +31,6 @@ __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin
 }  // namespace g16
 
 namespace mi355 {
-int gemm16_p8(const g16::G16Args& g, int out16, int precision, hipStream_t st);     // gemm16_p8.hip
+int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);     // gemm16_p8.hip
+size_t gemm16_p8_workspace_bytes(int M, int N, int K);
 }

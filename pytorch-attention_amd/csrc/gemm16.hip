@@ -601,8 +601,16 @@ int mi355_cast16_fwd(const float* src, void* dst16, size_t n, int precision, mi3
     return MI355_OK;
 }
 
+size_t mi355_linear16_workspace_bytes(int M, int N, int K) { return mi355::gemm16_p8_workspace_bytes(M, N, K); }
+
 int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y, int M,
                        int N, int K, int ldx, int ldy, int act, int out16, int precision, mi355_stream_t stream) {
+    return mi355_linear16_ws_fwd(X16, W16, bias, gamma, resid, Y, M, N, K, ldx, ldy, act, out16, precision, nullptr, 0, stream);
+}
+
+int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y, int M,
+                          int N, int K, int ldx, int ldy, int act, int out16, int precision, void* ws, size_t ws_bytes,
+                          mi355_stream_t stream) {
     MI355_CHECK_ARG(X16 && W16 && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
     MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
     MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
@@ -616,7 +624,7 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     long variant = mi355::opt_gemm_variant();
     if (variant == 15) {                   // persistent 256 x 256 kernel (gemm16_p8.hip)
-        const int rc = mi355::gemm16_p8(g, out16, precision, st);
+        const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
         if (rc != MI355_OK) return mi355::fail(rc, "mi355_linear16_fwd: persistent kernel does not take this shape");
         MI355_LAUNCH_CHECK();
         return MI355_OK;
@@ -652,9 +660,9 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
         const int ncu = mi355::resident_slots(1);
         const long ntiles = (long)cdiv(M, 256) * cdiv(N, 256);
         const long rounds = (ntiles + ncu - 1) / ncu;
-        const bool full = ntiles >= ncu && ntiles * 100 >= rounds * ncu * 85;
-        if ((out16 && full && K >= 256) || (!out16 && ntiles >= 2L * ncu && K >= 2048 && N >= 768)) {
-            if (mi355::gemm16_p8(g, out16, precision, st) == MI355_OK) {
+        (void)rounds;
+        if (ntiles >= ncu && K >= 256) {
+            if (mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st) == MI355_OK) {
                 MI355_LAUNCH_CHECK();
                 return MI355_OK;
             }

@@ -21,13 +21,31 @@
 //   (direct stores from the transposed MFMA tiles, bias / GELU / LayerScale / residual fused) while the next tile's first seven
 //   half-tiles are already in flight.  Tiles are dealt XCD-contiguously: the 32 workgroups of an XCD work on neighbouring tiles
 //   (shared A rows, the whole of W) out of one L2.
+//   Last partial round: ntiles = F * ncu + R.  Every workgroup walks F whole tiles; each of the R left-over tiles is cut along K
+//   into S = ncu / R chunks, one per workgroup (the stream of a workgroup simply ends with a shorter entry).  Chunks s > 0 dump
+//   their accumulators in register layout (1 KB per wave-instruction) into a caller-provided fp32 slab, release at agent scope and
+//   count themselves in on a per-tile word; chunk 0 polls that word (relaxed), acquires, adds the slabs and runs the normal
+//   epilogue -- N = 768 outputs (591 tiles on 256 CUs = 2.31 rounds) take 2.33 rounds instead of 3.  Without a workspace S = 1.
 #include "gemm16.h"
+#include "bufops.h"
 
 namespace {
 using namespace g16;
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+
+}  // namespace
+struct P8Plan {
+    int tiles_m, tiles_n;
+    int full;              // F: whole tiles per workgroup
+    int left, split;       // R left-over tiles, each cut into S K-chunks (S >= 1; the chunk units go to workgroups 0 .. R*S-1)
+    float* part;           // (R, S-1, 8 waves, 8192) fp32 partial accumulators
+    unsigned* arrive;      // R words, zeroed by the launcher: waves of chunks s > 0 that have published
+};
+namespace {
 
 template <typename T, bool OUT16>
-__global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P8Plan pl) {
+    const int tiles_n = pl.tiles_n;
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
     constexpr int SLOT = 128 * BK;                              // elements per half-tile slot (16 KB)
@@ -45,24 +63,29 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
 
     // ---- this workgroup's tile list: XCD x owns the contiguous range [x0, x0 + xn) of the n-fastest tile order; its workgroups
     //      (blockIdx = x, x + 8, ...) take every per_xcd-th tile of that range ----------------------------------------------------
-    const int ntiles = tiles_m * tiles_n;
+    //      Entries 0 .. F-1 of a workgroup's list are whole tiles out of the first F * gridDim tiles; entry F (if any) is its K-chunk
+    //      of a left-over tile ----------------------------------------------------------------------------------------------------
     const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
-    const int per_xcd = (gridDim.x - xcd + 7) >> 3;             // workgroups of this launch that sit on XCD `xcd`
-    const int tq = ntiles >> 3, trm = ntiles & 7;
-    const int x0 = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
-    const int xn = tq + (xcd < trm ? 1 : 0);
-    const int my_first = x0 + slot_in_xcd;
-    const int my_count = slot_in_xcd < xn ? (xn - slot_in_xcd + per_xcd - 1) / per_xcd : 0;
+    const int gq = gridDim.x >> 3, gr = gridDim.x & 7;
+    const int per_xcd = gq + (xcd < gr ? 1 : 0);                // workgroups of this launch that sit on XCD `xcd`
+    const int my_first = pl.full * (xcd * gq + (xcd < gr ? xcd : gr)) + slot_in_xcd;      // XCD x owns F * per_xcd consecutive tiles
+    const int nfull = pl.full;
+    const bool has_chunk = (int)blockIdx.x < pl.left * pl.split;
+    const int ch_tile_r = has_chunk ? (int)blockIdx.x / pl.split : 0, ch_s = has_chunk ? (int)blockIdx.x % pl.split : 0;
+    const int ch_tile = pl.full * (int)gridDim.x + ch_tile_r;
+    const int ch_k0 = has_chunk ? (int)((long)ch_s * nk / pl.split) : 0, ch_k1 = has_chunk ? (int)((long)(ch_s + 1) * nk / pl.split) : 0;
+    const int my_count = nfull + (has_chunk ? 1 : 0);
     if (my_count == 0) return;
-    const int total_kt = my_count * nk;                         // length of this workgroup's K-tile stream
+    const int total_kt = nfull * nk + (ch_k1 - ch_k0);          // length of this workgroup's K-tile stream
+    auto entry_tile = [&](int e) { return e < nfull ? my_first + e * per_xcd : ch_tile; };
 
     // ---- DMA sources.  One instruction = 8 rows x 128 B; lane -> (row = lane >> 3, physical chunk = lane & 7) holding logical
     //      chunk (lane & 7) ^ row.  A half-tiles: this wave stages rows wc*16 + i*8 + lrow of ITS OWN row group's 64-row half;
     //      B half-tiles: rows w*16 + i*8 + lrow of the 128-row slot, slot row r <-> column (r / 32) * 64 + half * 32 + r % 32 ------
     const int lrow = lane >> 3, csw = ((lane & 7) ^ lrow) * 8;
-    struct Cursor { const T* a[2]; const T* b[2]; int kt; int tile; };    // pointers of half 0 at k = 0; half 1 = + 64 rows / + 32 columns
+    struct Cursor { const T* a[2]; const T* b[2]; int kt; int kend; int tile; };   // pointers of half 0 at k = 0; half 1 = + 64 rows / + 32 columns
     auto seek = [&](Cursor& c, int tile_no) {                  // tile_no: index into this workgroup's list
-        const int tile = my_first + tile_no * per_xcd;
+        const int tile = entry_tile(tile_no);
         const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -73,16 +96,18 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
             c.a[i] = A + (long)(ma < g.M ? ma : g.M - 1) * g.lda + csw;
             c.b[i] = B + (long)(nb < g.N ? nb : g.N - 1) * g.ldb + csw;
         }
-        c.kt = 0; c.tile = tile_no;
+        c.kt = tile_no < nfull ? 0 : ch_k0;
+        c.kend = tile_no < nfull ? nk : ch_k1;
+        c.tile = tile_no;
     };
     // offsets of the second halves, clamped per lane against the matrix edge (element offsets relative to the half-0 pointers)
     auto half1_a = [&](const Cursor& c, int i) -> const T* {
-        const int tile = my_first + c.tile * per_xcd;
+        const int tile = entry_tile(c.tile);
         const int ma = (tile / tiles_n) * 256 + wr * 128 + 64 + wc * 16 + i * 8 + lrow;
         return A + (long)(ma < g.M ? ma : g.M - 1) * g.lda + csw;
     };
     auto half1_b = [&](const Cursor& c, int i) -> const T* {
-        const int tile = my_first + c.tile * per_xcd;
+        const int tile = entry_tile(c.tile);
         const int rb = wave * 16 + i * 8 + lrow;
         const int nb = (tile % tiles_n) * 256 + (rb >> 5) * 64 + 32 + (rb & 31);
         return B + (long)(nb < g.N ? nb : g.N - 1) * g.ldb + csw;
@@ -113,9 +138,9 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
         }
     };
     auto advance = [&](Cursor& c) {                             // next K-tile of the stream
-        if (++c.kt == nk) {
+        if (++c.kt == c.kend) {
             if (c.tile + 1 < my_count) seek(c, c.tile + 1);
-            else { c.kt = 0; c.tile = my_count; }               // past the end: never staged (callers test the stream index)
+            else { c.kt = 0; c.kend = 1 << 30; c.tile = my_count; }   // past the end: never staged (callers test the stream index)
         }
     };
 
@@ -173,7 +198,9 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
     P8_BAR();
     if (wr == 1) P8_BAR();                                       // one-interval shift of the second row group
 
+    const bool producer = has_chunk && ch_s > 0;                // the stream ends with a K-chunk whose partial sums go to the slab
     int kt_in_tile = 0, out_tile = 0;
+    int entry_len = nfull > 0 ? nk : ch_k1 - ch_k0;
     for (int T_ = 0; T_ < total_kt; ++T_) {
         const bool has1 = T_ + 1 < total_kt, has2 = T_ + 2 < total_kt;
         // ---- phase 0: A0 + B0 fragments; DMA (T+1, A1) ---------------------------------------------------------------------------
@@ -217,9 +244,43 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
         P8_MMA(1, 0);
         P8_BAR();
 
-        if (++kt_in_tile == nk) {
+        if (++kt_in_tile == entry_len && !(producer && T_ + 1 == total_kt)) {
+            // Both row groups run their epilogues AT THE SAME TIME: group 0 waits one barrier for the partner's last MFMA interval,
+            // and group 1 re-creates the one-interval shift with an extra barrier before the next entry (left shifted, the partner's
+            // epilogue could only start after this group's had finished: the next barrier it needs is this group's first of the next tile).
+            if (wr == 0) P8_BAR();
+            const bool is_chunk = out_tile >= nfull;
+            if (is_chunk && pl.split > 1) {
+                // ---- K-chunk 0: wait for the 8 * (S-1) partner waves, add their partial accumulators ------------------------------------
+                const unsigned want = 8u * (unsigned)(pl.split - 1);
+                for (;;) {
+                    const unsigned got = __hip_atomic_load(pl.arrive + ch_tile_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane(got) >= want) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                for (int s = 0; s < pl.split - 1; ++s) {                    // sc1 loads: served below this CU's L1, coherent with the sc1 stores
+                    const float* slab = pl.part + (((long)ch_tile_r * (pl.split - 1) + s) * 8 + wave) * 8192;
+                    const rsrc_t rs = make_rsrc(slab, 32768u);
+#pragma unroll
+                    for (int i0 = 0; i0 < 8; i0 += 4) {              // sixteen 1 KB loads in flight per step (the fragment registers are free here)
+                        f4 pv[4][4];
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                pv[ii][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rs, (bufops_u32)lane * 16u, (bufops_u32)((i0 + ii) * 4 + j) * 1024u, AUX_SC1));
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i0 + ii][j] = acc[i0 + ii][j] + pv[ii][j];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             // ---- epilogue of this output tile (transposed MFMA tiles: lane = one row, 4 consecutive columns) -------------------------
-            const int tile = my_first + out_tile * per_xcd;
+            const int tile = entry_tile(out_tile);
             const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
             // The tile leaves through a wave-private 2 KB LDS slab -- the part of slot A1 of the buffer just consumed that THIS wave
             // refills (rows wr*64 + wc*16 + [0,16)): nobody else touches it, its next DMA is issued by this wave after the epilogue in
@@ -305,9 +366,29 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
                 for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
             kt_in_tile = 0;
             ++out_tile;
+            entry_len = out_tile < nfull ? nk : ch_k1 - ch_k0;
+            if (wr == 1 && out_tile < my_count) P8_BAR();
         }
     }
-    if (wr == 0) P8_BAR();                                       // balance the shift: every wave executed the same number of barriers
+    if (producer) {
+        if (wr == 0) P8_BAR();
+        // ---- K-chunk s > 0 of a left-over tile: publish the partial accumulators, count this wave in, done ---------------------
+        // (buffer addressing: one descriptor + one VGPR of lane offset + immediate offsets -- 32 flat addresses would spill)
+        float* slab = pl.part + (((long)ch_tile_r * (pl.split - 1) + (ch_s - 1)) * 8 + wave) * 8192;
+        const rsrc_t rs = make_rsrc(slab, 32768u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc[i][j]), rs, (bufops_u32)lane * 16u,
+                                                       (bufops_u32)(i * 4 + j) * 1024u, AUX_SC1);
+        // write-through (sc1) stores + a drained queue ARE the publish (MI355X_MICROARCH.md "publish-large"): an agent-scope release
+        // fence here would write back every dirty line of the XCD's L2 -- megabytes of output tiles -- once per wave (measured: the
+        // split round then cost more than a whole tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(pl.arrive + ch_tile_r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // barrier balance: 1 + 8 * total_kt + my_count per wave (group 1: prologue shift + (my_count - 1) re-shifts; group 0: my_count re-alignments)
 #undef P8_MMA
 #undef P8_BAR
 }
@@ -316,21 +397,60 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const i
 
 namespace mi355 {
 
+// Workspace of the split last round: partial accumulators of the K-chunks s > 0 of the left-over tiles + one arrival word per tile.
+static void p8_plan(int M, int N, int K, int ncu, P8Plan& pl, int& grid, size_t& part_bytes, size_t& arrive_bytes) {
+    pl.tiles_m = cdiv(M, 256); pl.tiles_n = cdiv(N, 256);
+    const long ntiles = (long)pl.tiles_m * pl.tiles_n;
+    grid = ntiles < ncu ? (int)ntiles : ncu;
+    pl.full = (int)(ntiles / ncu);
+    pl.left = (int)(ntiles - (long)pl.full * ncu);
+    const int nk = K / g16::BK;
+    int S = pl.left > 0 ? ncu / pl.left : 1;
+    // a chunk saves nk * (1 - 1/S) K-tiles of ~1.75 us and costs a slab round trip (~15-20 us): only long reductions split
+    if (nk < 24 || !opt_gemm_splitk()) S = 1;
+    if (S > nk / 8) S = nk / 8;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    pl.split = S;
+    if (pl.full == 0) grid = pl.left * S;                      // fewer tiles than CUs: only the chunk units exist
+    part_bytes = (size_t)pl.left * (S - 1) * 8 * 8192 * sizeof(float);
+    arrive_bytes = ((size_t)pl.left * sizeof(unsigned) + 255) & ~(size_t)255;
+}
+
+size_t gemm16_p8_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < g16::BK || (K % g16::BK)) return 0;
+    P8Plan pl{};
+    int grid;
+    size_t pb, ab;
+    p8_plan(M, N, K, resident_slots(1), pl, grid, pb, ab);
+    return pl.split > 1 ? pb + ab : 0;
+}
+
 // Launch the persistent kernel when the shape suits it: called by mi355_linear16_fwd (gemm16.hip).  Returns MI355_EUNSUPPORTED
-// without touching anything when it does not apply.
-int gemm16_p8(const g16::G16Args& g, int out16, int precision, hipStream_t st) {
+// without touching anything when it does not apply.  `ws` (may be null) enables the split last round.
+int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st) {
     if ((g.K % g16::BK) || (g.N & 7) || (out16 && g.resid)) return MI355_EUNSUPPORTED;   // 16-bit out + residual: rounding point differs
-    const int tiles_m = cdiv(g.M, 256), tiles_n = cdiv(g.N, 256);
-    const long ntiles = (long)tiles_m * tiles_n;
-    if (ntiles > (1L << 30)) return MI355_EUNSUPPORTED;
-    int grid = resident_slots(1);
-    if (grid > ntiles) grid = (int)ntiles;
+    if ((long)cdiv(g.M, 256) * cdiv(g.N, 256) > (1L << 30)) return MI355_EUNSUPPORTED;
+    P8Plan pl{};
+    int grid;
+    size_t pb, ab;
+    p8_plan(g.M, g.N, g.K, resident_slots(1), pl, grid, pb, ab);
+    if (pl.split > 1 && (ws == nullptr || ws_bytes < pb + ab || !aligned16(ws))) {      // no workspace: whole left-over tiles
+        pl.split = 1;
+        if (pl.full == 0) grid = pl.left;
+    }
+    if (pl.split > 1) {
+        pl.arrive = static_cast<unsigned*>(ws);
+        pl.part = reinterpret_cast<float*>(static_cast<char*>(ws) + ab);
+        hipError_t e = hipMemsetAsync(pl.arrive, 0, (size_t)pl.left * sizeof(unsigned), st);
+        if (e != hipSuccess) return fail(MI355_EHIP, "gemm16_p8: memset -> %s", hipGetErrorString(e));
+    }
     if (precision == MI355_PREC_FP16) {
-        if (out16) gemm16_p8_kernel<_Float16, true><<<grid, 512, 0, st>>>(g, tiles_m, tiles_n);
-        else       gemm16_p8_kernel<_Float16, false><<<grid, 512, 0, st>>>(g, tiles_m, tiles_n);
+        if (out16) gemm16_p8_kernel<_Float16, true><<<grid, 512, 0, st>>>(g, pl);
+        else       gemm16_p8_kernel<_Float16, false><<<grid, 512, 0, st>>>(g, pl);
     } else {
-        if (out16) gemm16_p8_kernel<__bf16, true><<<grid, 512, 0, st>>>(g, tiles_m, tiles_n);
-        else       gemm16_p8_kernel<__bf16, false><<<grid, 512, 0, st>>>(g, tiles_m, tiles_n);
+        if (out16) gemm16_p8_kernel<__bf16, true><<<grid, 512, 0, st>>>(g, pl);
+        else       gemm16_p8_kernel<__bf16, false><<<grid, 512, 0, st>>>(g, pl);
     }
     return MI355_OK;
 }

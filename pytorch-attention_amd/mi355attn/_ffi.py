@@ -61,6 +61,8 @@ SIGNATURES = {
     "mi355_layernorm16_t_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [c_float, c_int, c_vp]),
     "mi355_linear16_tr_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),
     "mi355_linear16_fwd": (c_int, [c_vp] * 6 + [c_int] * 8 + [c_vp]),
+    "mi355_linear16_workspace_bytes": (c_size, [c_int] * 3),
+    "mi355_linear16_ws_fwd": (c_int, [c_vp] * 6 + [c_int] * 8 + [c_vp, c_size, c_vp]),
     "mi355_sdpa16_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_int, c_vp]),
     "mi355_cswin_lepe_attn16_fwd": (c_int, [c_vp] * 4 + [c_int] * 8 + [c_float, c_int, c_vp]),
     "mi355_conv2d_tokens_fwd": (c_int, [c_vp] * 5 + [c_int] * 13 + [c_vp]),
@@ -205,6 +207,23 @@ def workspace(nbytes, device):
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
+    return t
+
+
+_ws_named = {}
+
+
+def workspace_named(name, nbytes, device):
+    """Per-(name, device, stream) scratch tensor, grown on demand, kept apart from the generic workspace() buffer so that one
+    large user (the GEMM's split-K slabs: tens of MB) does not inflate the scratch every small op borrows.  Capture-safe like
+    workspace()."""
+    if _capturing():
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    key = (name, device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _ws_named.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_named[key] = t
     return t
 
 

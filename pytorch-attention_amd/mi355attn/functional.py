@@ -538,8 +538,11 @@ def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=Fa
     if resid is not None and resid.numel() != M * N:
         raise ValueError("linear16: residual shape mismatch")
     y = torch.empty(*x16.shape[:-1], N, dtype=dtype16(precision) if out16 else torch.float32, device=x16.device)
-    check(lib().mi355_linear16_fwd(dptr(x16), dptr(w16), dptr(bias), dptr(gamma), dptr(resid), dptr(y), M, N, K, K, N, act,
-                                   1 if out16 else 0, _prec(precision), stream_ptr(x16.device)), "mi355_linear16_fwd")
+    nws = lib().mi355_linear16_workspace_bytes(M, N, K)                  # split last round of the persistent kernel (0: not needed)
+    ws = _ffi.workspace_named("linear16", nws, x16.device) if nws else None
+    check(lib().mi355_linear16_ws_fwd(dptr(x16), dptr(w16), dptr(bias), dptr(gamma), dptr(resid), dptr(y), M, N, K, K, N, act,
+                                      1 if out16 else 0, _prec(precision), dptr(ws), nws if ws is not None else 0,
+                                      stream_ptr(x16.device)), "mi355_linear16_ws_fwd")
     return y
 
 

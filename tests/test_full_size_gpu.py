@@ -10,9 +10,9 @@ test asserts:
     the 3 072 ... 114 688-workgroup attention grids and the XCD-remapped block order are the ones bench.py reports;
   * the same three images in strict mode (split-bf16 operands) within 5e-5;
   * run-to-run bit identity of the full-size launch;
-  * batch independence: a 3-image batch of the sampled images gives the same rows as the 256-image run (bit-for-bit when the same
-    kernels are selected, otherwise to 2e-6 -- a different tile shape only changes nothing in a row's K order, so any difference
-    beyond rounding noise is a bug).
+  * batch independence: a 3-image batch of the sampled images gives the same rows as the 256-image run bit-for-bit (every GEMM
+    variant keeps a row's K order); the one exception is the split last round of the persistent GEMM ("gemm_splitk"), with which
+    the rows agree to the operand format's rounding level and bit-for-bit again once it is switched off.
 """
 import pytest
 import torch
@@ -62,7 +62,22 @@ def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5):
     ref = ref_fn(xs)
     assert_parity(y[PICK].cpu(), ref, tol, name + " [B=256, images 0/127/255]")
     if not torch.equal(y[PICK], sub):
-        assert_parity(sub.cpu(), y[PICK].cpu(), 2e-6, name + " [batch independence]")
+        # The only launch-dependent arithmetic is the persistent GEMM's split last round (option "gemm_splitk", K >= 1536): the fp32
+        # summation order of those tiles changes, and a 1e-7 difference in front of a 16-bit re-rounding of the next operand shows up
+        # at the operand format's rounding level downstream -- inside the parity tolerance by a factor of two at least.  With the
+        # split off every row must be bit-identical whatever the batch around it.
+        assert_parity(sub.cpu(), y[PICK].cpu(), 5e-4, name + " [batch independence, split-K on]")
+        mi355attn.set_option("gemm_splitk", 0)
+        try:
+            with torch.no_grad():
+                y0 = m(x, *fwd_args)
+                sub0 = m(x[PICK].contiguous(), *fwd_args)
+            torch.cuda.synchronize()
+        finally:
+            mi355attn.set_option("gemm_splitk", 1)
+        assert torch.equal(y0[PICK], sub0), name + ": output of an image depends on its batch neighbours (split-K off)"
+        assert_parity(y0[PICK].cpu(), ref, tol, name + " [B=256, split-K off]")
+        del y0, sub0
     assert_parity(sub.cpu(), ref, tol, name + " [3-image batch]")
     del y2, sub
     # strict (fp32-class) mode on the same full-size input

@@ -46,6 +46,7 @@ for shp in shapes:
         y = F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
         torch.cuda.synchronize()
         same = True if ref is None else bool(torch.equal(y, ref))
+        relerr = 0.0 if ref is None else float((y.float() - ref.float()).norm() / ref.float().norm())
         if ref is None:
             ref = y.clone()
         for _ in range(3):
@@ -56,7 +57,7 @@ for shp in shapes:
             F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
         ms = tm.stop_ms() / 10
         tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-        res.append(dict(shape=name, N=N, K=K, variant=v, ms=round(ms, 4), tflops=round(tf, 1), same_as_v0=same))
+        res.append(dict(shape=name, N=N, K=K, variant=v, ms=round(ms, 4), tflops=round(tf, 1), same_as_v0=same, rel_vs_v0=relerr))
         print(res[-1], flush=True)
 mi355attn.set_option("gemm_variant", 0)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
