@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
                 const int img = m / g.tr_rows, c = m - img * g.tr_rows;
                 const long o = ((long)img * g.N + n) * g.tr_rows + c;
                 f4 v = acc[i][j] + f4{bn, bn, bn, bn};
-                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + o);
                 *reinterpret_cast<f4*>(Cf + o) = v;
             }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
                 const int n = n0 + wc * TN + j * 16 + g4;
                 if (n >= g.N) continue;                         // N % 4 == 0 is a launch precondition
                 f4 v = acc[i][j] + bias4[j];
-                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                 if (g.gamma) v = v * gam4[j];
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
                 if constexpr (OUT16) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
                 const int n = n0 + wc * 64 + j * 16 + g4;
                 if (n >= g.N) continue;
                 f4 v = acc[i][j] + bias4[j];
-                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                 if (g.gamma) v = v * gam4[j];
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
                 if constexpr (OUT16) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
                     f4 v = acc[i][j];
                     if (n < g.N) {
                         if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
-                        if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                        if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                         if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
                         const int m = m0 + wr * TM + i * 16 + l15;
                         if (g.resid && m < g.M) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
                 if (n >= g.N) continue;
                 f4 v = acc[i][j];
                 if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);       // L1-resident, reloaded per tile to keep VGPRs <= 128
-                if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                 if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
                 *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;

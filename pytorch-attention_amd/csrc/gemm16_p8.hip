@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f4 v = acc[i][j] + bias4[j];
-                        if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                        if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                         if (g.gamma) v = v * gam4[j];
                         *reinterpret_cast<v4*>(slab + l15 * 128 + (((j * 2 + (fq4 >> 1)) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8) =
                             v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = jh * 2 + jj;
                             f4 v = acc[i][j] + bias4[j];
-                            if (g.act == MI355_ACT_GELU) v = f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
+                            if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                             if (g.gamma) v = v * gam4[j];
                             *reinterpret_cast<f4*>(slab + l15 * 128 + (((jj * 4 + fq4) ^ (l15 & 7)) * 16)) = v;
                         }

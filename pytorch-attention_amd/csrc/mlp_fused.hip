@@ -127,8 +127,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 f4 p0 = s[tt][0], p1 = s[tt][1];
-                p0 = f4{gelu_fast(p0.x), gelu_fast(p0.y), gelu_fast(p0.z), gelu_fast(p0.w)};
-                p1 = f4{gelu_fast(p1.x), gelu_fast(p1.y), gelu_fast(p1.z), gelu_fast(p1.w)};
+                p0 = gelu_fast4(p0);
+                p1 = gelu_fast4(p1);
                 const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
                 pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             }
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
                 for (int ks = 0; ks < KS; ++ks)
                     s[h2] = M_::mma(*reinterpret_cast<const v8*>(sw1 + (h2 * 16 + l15) * P1 + ks * 32 + g * 8), xb[ks], s[h2]);
             }
-            const f4 p0 = f4{gelu_fast(s[0].x), gelu_fast(s[0].y), gelu_fast(s[0].z), gelu_fast(s[0].w)};
-            const f4 p1 = f4{gelu_fast(s[1].x), gelu_fast(s[1].y), gelu_fast(s[1].z), gelu_fast(s[1].w)};
+            const f4 p0 = gelu_fast4(s[0]);
+            const f4 p1 = gelu_fast4(s[1]);
             const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
             const v8 pf = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs a) {
             if (has1) r1 += *reinterpret_cast<const f4*>(a.pos + (p0 + 1) * a.Cout + c * 4);
         }
         if (a.act == MI355_ACT_GELU) {
-            r0 = f4{gelu_fast(r0.x), gelu_fast(r0.y), gelu_fast(r0.z), gelu_fast(r0.w)};
-            r1 = f4{gelu_fast(r1.x), gelu_fast(r1.y), gelu_fast(r1.z), gelu_fast(r1.w)};
+            r0 = gelu_fast4(r0);
+            r1 = gelu_fast4(r1);
         }
         *reinterpret_cast<f4*>(y0 + c * 4) = r0;
         if (has1) *reinterpret_cast<f4*>(y0 + a.Cout + c * 4) = r1;
