@@ -329,6 +329,17 @@ int mi355_cswin_lepe_attn16_pair_fwd(const void* qkv16, const float* getv_w0, co
                                      const float* getv_b1, void* out16, int B, int reso, int Ctot, int heads, int split, float scale,
                                      int precision, mi355_stream_t stream);
 
+/* First half of a CSWinBlock for the narrow stages in one kernel (cswin.py:180-190, LePEAttention.forward :101-127):
+ * ctx16 = concat over branches / heads of  softmax((q * scale) k^T) v + LePE(v)  with  [q | k | v] = LayerNorm(x) Wqkv^T + bqkv
+ * on the two stripe branches (branch 0: stripes reso x split on channels [0, C/2), branch 1: split x reso on [C/2, C)).  x (B, L, C)
+ * fp32; wqkv16 (3C, C) 16-bit and bqkv (3C) fp32 with the LayerNorm affine part folded in by the caller (W' = W diag(ln_w),
+ * b' = b + W ln_b); getv_w* (C/2, 1, 3, 3) / getv_b* (C/2) of the two branches; ctx16 (B, L, C) 16-bit.  Built for C = 64 / 128,
+ * head width 32 (heads_per_branch = C / 64), reso * split <= 64 tokens per stripe; other shapes: MI355_EUNSUPPORTED (callers use
+ * mi355_ln_linear16_fwd + mi355_cswin_lepe_attn16_pair_fwd).  qkv never exists in HBM. */
+int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, const float* bqkv, const float* getv_w0, const float* getv_b0,
+                                const float* getv_w1, const float* getv_b1, void* ctx16, int B, int reso, int C, int heads_per_branch,
+                                int split, float scale, float eps, int precision, mi355_stream_t stream);
+
 /* Fused LayerNorm + MLP + residual for narrow token streams (C = 64 / hidden 256: CSWin stage 1; C = 128 / hidden 512: CSWin stage 2,
  * XCiT-nano; cswin.py:194-196 with Mlp :29-44, xcit.py:293 with Mlp :21-38):
  *   y = x + gamma * (W2 gelu(W1' xn + b1') + b2),   xn = (x - mean) / sqrt(var + eps) over the C channels (layernorm != 0) or x.

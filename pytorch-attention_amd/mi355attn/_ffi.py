@@ -93,6 +93,7 @@ SIGNATURES = {
     "mi355_sdpa_general_fwd": (c_int, [c_vp] * 5 + [c_int] * 5 + [ctypes.c_long] * 5 + [ctypes.c_float, c_int, c_int, c_vp]),
     "mi355_dwconv_patch_tokens_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),
     "mi355_cswin_lepe_attn16_pair_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [ctypes.c_float, c_int, c_vp]),
+    "mi355_cswin_stripe_attn_fwd": (c_int, [c_vp] * 8 + [c_int] * 5 + [c_float, c_float, c_int, c_vp]),
     "mi355_class_attn_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
     "mi355_axpby_fwd": (c_int, [c_vp] * 4 + [ctypes.c_long, c_int, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_float, c_vp]),
     "mi355_comm_unique_id": (c_int, [c_vp, c_size]),

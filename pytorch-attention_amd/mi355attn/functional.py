@@ -399,6 +399,42 @@ def cswin_lepe_attention16_pair(qkv16, w0, b0, w1, b1, out16, reso, heads, split
     return out16
 
 
+def cswin_stripe_ok(C, reso, split, heads, precision=None):
+    """Shape / precision envelope of mi355_cswin_stripe_attn_fwd (CSWin-T stages 1-2)."""
+    return _prec(precision) in (PREC_FP16, PREC_BF16) and C in (64, 128) and heads * 32 == C and reso * split <= 64 and reso % split == 0
+
+
+def _ln_folded16(ln, lin, p):
+    """(W diag(ln.weight) in 16 bit, b + W ln.bias in fp32) of a Linear behind a LayerNorm, cached per parameter version."""
+    N = lin.weight.shape[0]
+
+    def build():
+        w = lin.weight.detach()
+        b = lin.bias.detach() if lin.bias is not None else torch.zeros(N, dtype=torch.float32, device=w.device)
+        b = b + w @ ln.bias.detach()
+        return cast16((w * ln.weight.detach()[None, :]).contiguous(), p), b.contiguous()
+
+    parts = [lin.weight] + ([] if lin.bias is None else [lin.bias]) + [ln.weight, ln.bias]
+    tag = tuple((t._version, t.data_ptr()) for t in parts)
+    return _derived_get((lin, ln), ("ln_linear16", p), tag, build)
+
+
+def cswin_stripe_attention(x, ln, qkv, getv0, getv1, reso, heads, split, scale, precision=None):
+    """LayerNorm -> qkv -> both stripe branches of LePE attention in one kernel; x (B, L, C) fp32 -> ctx (B, L, C) 16-bit.
+    `heads` = heads of the whole block (heads / 2 per branch)."""
+    p = _prec(precision)
+    x = require_device_f32(x, "x")
+    B, L, C = x.shape
+    w16, b = _ln_folded16(ln, qkv, p)
+    ws = [require_device_f32(t, n) for t, n in ((getv0.weight, "attns.0.get_v.weight"), (getv0.bias, "attns.0.get_v.bias"),
+                                                (getv1.weight, "attns.1.get_v.weight"), (getv1.bias, "attns.1.get_v.bias"))]
+    ctx = torch.empty(B, L, C, dtype=dtype16(p), device=x.device)
+    check(lib().mi355_cswin_stripe_attn_fwd(dptr(x), dptr(w16), dptr(b), dptr(ws[0]), dptr(ws[1]), dptr(ws[2]), dptr(ws[3]), dptr(ctx), B, reso,
+                                            C, heads // 2, split, float(scale), float(ln.eps), p, stream_ptr(x.device)),
+          "mi355_cswin_stripe_attn_fwd")
+    return ctx
+
+
 def fast_gemm_ok(K, N):
     """Shape envelope of mi355_linear16_fwd (K-step 64, float4 epilogue)."""
     return K % 64 == 0 and N % 4 == 0
@@ -499,15 +535,7 @@ def ln_linear16(x, ln, lin, act=ACT_NONE, out16=True, precision=None):
     K = x.shape[-1]
     N = lin.weight.shape[0]
 
-    def build():
-        w = lin.weight.detach()
-        b = lin.bias.detach() if lin.bias is not None else torch.zeros(N, dtype=torch.float32, device=w.device)
-        b = b + w @ ln.bias.detach()
-        return cast16((w * ln.weight.detach()[None, :]).contiguous(), p), b.contiguous()
-
-    parts = [lin.weight] + ([] if lin.bias is None else [lin.bias]) + [ln.weight, ln.bias]
-    tag = tuple((t._version, t.data_ptr()) for t in parts)
-    w16, b = _derived_get((lin, ln), ("ln_linear16", p), tag, build)
+    w16, b = _ln_folded16(ln, lin, p)
     M = x.numel() // K
     y = torch.empty(*x.shape[:-1], N, dtype=dtype16(p) if out16 else torch.float32, device=x.device)
     check(lib().mi355_ln_linear16_fwd(dptr(x), dptr(w16), dptr(b), dptr(y), M, N, K, K, N, float(ln.eps), act, 1 if out16 else 0, p,

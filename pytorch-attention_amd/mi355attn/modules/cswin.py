@@ -95,7 +95,12 @@ class CSWinBlock(nn.Module):
         assert L == self.patches_resolution ** 2, "flatten img_tokens has wrong size"
         p = F._prec(self.precision)
         fast = _fast(p, self.qkv, self.proj, self.mlp.fc1, self.mlp.fc2) and self.attns[0].dim // self.attns[0].num_heads == 32
-        if fast:                     # LN -> qkv -> attention -> proj with every GEMM operand kept 16-bit in HBM
+        stripe = fast and self.branch_num == 2 and F.cswin_stripe_ok(C, self.patches_resolution, self.split_size, self.num_heads, p)
+        if stripe:                   # narrow stages: LN -> qkv -> both stripe attentions in one kernel, qkv never reaches HBM
+            a0, a1 = self.attns[0], self.attns[1]
+            att = F.cswin_stripe_attention(x, self.norm1, self.qkv, a0.get_v, a1.get_v, self.patches_resolution, self.num_heads,
+                                           self.split_size, a0.scale, p)
+        elif fast:                   # LN -> qkv -> attention -> proj with every GEMM operand kept 16-bit in HBM
             if F.ln_linear16_ok(C, 3 * C, p):        # narrow stages: LayerNorm applied on the way into the qkv GEMM
                 qkv = F.ln_linear16(x, self.norm1, self.qkv, out16=True, precision=p)
             else:
@@ -106,7 +111,9 @@ class CSWinBlock(nn.Module):
             u = F.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             qkv = F.linear(u, self.qkv.weight, self.qkv.bias, precision=self.precision)    # (B,L,3C) == (B,L,3,C)
             att = torch.empty(B, L, C, dtype=torch.float32, device=x.device)
-        if self.branch_num == 2 and fast:
+        if stripe:
+            pass
+        elif self.branch_num == 2 and fast:
             a0, a1 = self.attns[0], self.attns[1]                  # both stripe branches in one launch
             F.cswin_lepe_attention16_pair(qkv, a0.get_v.weight, a0.get_v.bias, a1.get_v.weight, a1.get_v.bias, att,
                                           self.patches_resolution, a0.num_heads, self.split_size, a0.scale, p)
