@@ -329,6 +329,15 @@ int mi355_cswin_lepe_attn16_pair_fwd(const void* qkv16, const float* getv_w0, co
                                      const float* getv_b1, void* out16, int B, int reso, int Ctot, int heads, int split, float scale,
                                      int precision, mi355_stream_t stream);
 
+/* Second half of a CSWinBlock for the narrow stages in one kernel (cswin.py:191-196): x1 = x + ctx16 Wp^T + bp (the proj Linear and
+ * its residual), y = x1 + gamma * (W2 gelu(W1' LN(x1) + b1') + b2).  ctx16 (M, C) and wp16 (C, C) 16-bit, bp (C) fp32, the rest as
+ * mi355_mlp_fused_fwd (at C = 128 w2_16 slice-major).  Built for C = 64 / hidden 256 (x1 never reaches HBM) and C = 128 / hidden 512
+ * (x1 is parked in the y rows and read back by the same lanes); other shapes: MI355_EUNSUPPORTED (callers use mi355_linear16_fwd +
+ * mi355_mlp_fused_fwd). */
+int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const void* wp16, const float* bp, const void* w1_16, const float* b1,
+                             const void* w2_16, const float* b2, const float* gamma, float* y, long M, int C, int hidden, int layernorm,
+                             float eps, int precision, mi355_stream_t stream);
+
 /* First half of a CSWinBlock for the narrow stages in one kernel (cswin.py:180-190, LePEAttention.forward :101-127):
  * ctx16 = concat over branches / heads of  softmax((q * scale) k^T) v + LePE(v)  with  [q | k | v] = LayerNorm(x) Wqkv^T + bqkv
  * on the two stripe branches (branch 0: stripes reso x split on channels [0, C/2), branch 1: split x reso on [C/2, C)).  x (B, L, C)

@@ -25,9 +25,12 @@ struct MlpArgs {
     long M;
     float eps;
     int do_ln;
+    // PROJ kernels: x1 = x + ctx Wp^T + bp is formed first (the proj Linear + residual of the block half in front of the MLP,
+    // cswin.py:191-193), the MLP then runs on x1:  y = x1 + gamma * (W2 gelu(W1 LN(x1) + b1) + b2)
+    const void* ctx; const void* wp; const float* bp;      // ctx (M, C) 16-bit, wp (C, C) 16-bit, bp (C) fp32
 };
 
-template <int PREC, int C, int HD>
+template <int PREC, int C, int HD, bool PROJ = false>
 __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
     el* s_w2 = s_w1 + HD * P1;
     float* s_b1 = reinterpret_cast<float*>(s_w2 + C * P2);
     float* s_slab = s_b1 + HD;
+    el* s_wp = reinterpret_cast<el*>(s_slab + NWV * 16 * SP);          // PROJ: (C, C) rows = output channels, pitch P1
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     // ---- weights -> LDS once per workgroup (16-byte chunks) -----------------------------------------------------------------------
@@ -58,6 +62,13 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
             *reinterpret_cast<v4*>(s_w2 + r * P2 + c4) = *reinterpret_cast<const v4*>(w2 + (long)r * HD + c4);
         }
         for (int i = t; i < HD; i += 1024) s_b1[i] = a.b1[i];
+        if constexpr (PROJ) {
+            const el* wp = static_cast<const el*>(a.wp);
+            for (int i = t; i < C * (C / 8); i += 1024) {
+                const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
+                *reinterpret_cast<v8*>(s_wp + r * P1 + c8) = *reinterpret_cast<const v8*>(wp + (long)r * C + c8);
+            }
+        }
     }
     __syncthreads();
     float* slab = s_slab + wave * 16 * SP;
@@ -68,6 +79,7 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
         const long tok0 = ch * (16 * TT);
         // ---- tokens in B-operand layout: lane (l15, g) holds channels ks*32 + g*8 + [0,8) of token tok0 + tt*16 + l15 -------------
         v8 xb[TT][KS];
+        f4 x1lo[PROJ ? TT : 1][KS], x1hi[PROJ ? TT : 1][KS];       // PROJ: the residual stream after the projection, kept for the epilogue
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             const long tok = tok0 + tt * 16 + l15;
@@ -77,6 +89,28 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
             for (int ks = 0; ks < KS; ++ks) {
                 lo[ks] = *reinterpret_cast<const f4*>(xr + ks * 32);
                 hi[ks] = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+            }
+            if constexpr (PROJ) {
+                // x1 = x + ctx Wp^T + bp.  P^T = Wp . ctx^T with the rows of each 16-row MFMA tile PERMUTED so that the accumulator
+                // layout (lane (l15, g): rows g*4 + r of token l15) is the layout x is held in (channels ks*32 + g*8 + [0,8)):
+                // tile (ks', h) row i  <->  output channel ks'*32 + (i / 4)*8 + h*4 + i % 4
+                const el* cr = static_cast<const el*>(a.ctx) + (tok < a.M ? tok : 0) * C + g * 8;
+                v8 cb[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) cb[ks] = *reinterpret_cast<const v8*>(cr + ks * 32);
+#pragma unroll
+                for (int kp = 0; kp < KS; ++kp)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int nrow = kp * 32 + (l15 >> 2) * 8 + h * 4 + (l15 & 3);
+                        f4 acc = *reinterpret_cast<const f4*>(a.bp + kp * 32 + g * 8 + h * 4);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            acc = M_::mma(*reinterpret_cast<const v8*>(s_wp + nrow * P1 + ks * 32 + g * 8), cb[ks], acc);
+                        if (h == 0) lo[kp] = lo[kp] + acc; else hi[kp] = hi[kp] + acc;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { x1lo[tt][ks] = lo[ks]; x1hi[tt][ks] = hi[ks]; }
             }
             float mean = 0.f, rstd = 1.f;
             if (a.do_ln) {
@@ -161,7 +195,9 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
                 for (int ks = 0; ks < KS; ++ks) {
                     const f4 r0 = *reinterpret_cast<const f4*>(slab + l15 * SP + ks * 32 + g * 8);
                     const f4 r1 = *reinterpret_cast<const f4*>(slab + l15 * SP + ks * 32 + g * 8 + 4);
-                    const f4 x0 = *reinterpret_cast<const f4*>(xr + ks * 32), x1 = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+                    f4 x0, x1;
+                    if constexpr (PROJ) { x0 = x1lo[tt][ks]; x1 = x1hi[tt][ks]; }
+                    else { x0 = *reinterpret_cast<const f4*>(xr + ks * 32); x1 = *reinterpret_cast<const f4*>(xr + ks * 32 + 4); }
                     *reinterpret_cast<f4*>(yr + ks * 32) = x0 + r0;
                     *reinterpret_cast<f4*>(yr + ks * 32 + 4) = x1 + r1;
                 }
@@ -176,7 +212,10 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
 // blocks in lockstep and the 32-unit slices of W1 (rows) and W2 (columns, pre-arranged slice-major by the caller) stream through a
 // double-buffered 16 KB LDS stage: loads of slice kb+1 are in flight during the MFMAs of slice kb, two barriers per slice.  One
 // 16-token tile per wave (the 128-wide accumulator leaves no room for two).
-template <int PREC, int C, int HD>
+// PROJ: x1 = x + ctx Wp^T + bp first (Wp resident in LDS).  The 128-wide accumulator leaves no registers to carry x1 to the epilogue,
+// so a lane parks its x1 values in the y rows it will overwrite at the end and reads them back there (same lane, same addresses:
+// program order; the lines are L2-resident).
+template <int PREC, int C, int HD, bool PROJ = false>
 __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
@@ -190,6 +229,15 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     el* s_stage = reinterpret_cast<el*>(lds);                   // two stages
     float* s_slab = reinterpret_cast<float*>(s_stage + 2 * STAGE);
+    el* s_wp = reinterpret_cast<el*>(s_slab + NWV * 16 * SPH);  // PROJ: (C, C), rows = output channels, pitch P1
+    if constexpr (PROJ) {
+        const el* wp = static_cast<const el*>(a.wp);
+        for (int i = threadIdx.x; i < C * (C / 8); i += 1024) {
+            const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
+            *reinterpret_cast<v8*>(s_wp + r * P1 + c8) = *reinterpret_cast<const v8*>(wp + (long)r * C + c8);
+        }
+        __syncthreads();
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     float* slab = s_slab + wave * 16 * SPH;
     const float invC = 1.0f / (float)C;
@@ -223,6 +271,31 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
             for (int ks = 0; ks < KS; ++ks) {
                 lo[ks] = *reinterpret_cast<const f4*>(xr + ks * 32);
                 hi[ks] = *reinterpret_cast<const f4*>(xr + ks * 32 + 4);
+            }
+            if constexpr (PROJ) {                                   // see mlp_fused_kernel: permuted tile rows = the layout of lo / hi
+                const el* cr = static_cast<const el*>(a.ctx) + (tok < a.M ? tok : 0) * C + g * 8;
+                v8 cb[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) cb[ks] = *reinterpret_cast<const v8*>(cr + ks * 32);
+#pragma unroll
+                for (int kp = 0; kp < KS; ++kp)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int nrow = kp * 32 + (l15 >> 2) * 8 + h * 4 + (l15 & 3);
+                        f4 acc = *reinterpret_cast<const f4*>(a.bp + kp * 32 + g * 8 + h * 4);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            acc = M_::mma(*reinterpret_cast<const v8*>(s_wp + nrow * P1 + ks * 32 + g * 8), cb[ks], acc);
+                        if (h == 0) lo[kp] = lo[kp] + acc; else hi[kp] = hi[kp] + acc;
+                    }
+                if (tok < a.M) {
+                    float* yr = a.y + tok * C + g * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        *reinterpret_cast<f4*>(yr + ks * 32) = lo[ks];
+                        *reinterpret_cast<f4*>(yr + ks * 32 + 4) = hi[ks];
+                    }
+                }
             }
             float mean = 0.f, rstd = 1.f;
             if (a.do_ln) {
@@ -297,7 +370,7 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (tok < a.M) {
-                const float* xr = a.x + tok * C + hh * 64 + g * 8;
+                const float* xr = (PROJ ? a.y : a.x) + tok * C + hh * 64 + g * 8;
                 float* yr = a.y + tok * C + hh * 64 + g * 8;
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
@@ -315,8 +388,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
 }
 
 template <int C, int HD>
-constexpr size_t mlp_smem() {
-    return (size_t)(HD * (C + 8) + C * (HD + 4)) * 2 + (size_t)HD * 4 + (size_t)16 * 16 * (C + 4) * 4;
+constexpr size_t mlp_smem(bool proj = false) {
+    return (size_t)(HD * (C + 8) + C * (HD + 4)) * 2 + (size_t)HD * 4 + (size_t)16 * 16 * (C + 4) * 4 + (proj ? (size_t)C * (C + 8) * 2 : 0);
 }
 
 }  // namespace
@@ -371,6 +444,61 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
             attr2 = true;
         }
         mlp_fused_kernel<2, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
+    }
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const void* wp16, const float* bp, const void* w1_16, const float* b1,
+                                        const void* w2_16, const float* b2, const float* gamma, float* y, long M, int C, int hidden,
+                                        int layernorm, float eps, int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && ctx16 && wp16 && bp && w1_16 && b1 && w2_16 && y && M > 0);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!((C == 64 && hidden == 256) || (C == 128 && hidden == 512)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_proj_mlp_fused_fwd: built for C = 64, hidden = 256 and C = 128, hidden = 512 (got C = %d, hidden = %d)", C, hidden);
+    if (!aligned16(x) || !aligned16(y) || !aligned16(w1_16) || !aligned16(w2_16) || !aligned16(ctx16) || !aligned16(wp16) || !aligned16(bp))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_proj_mlp_fused_fwd: 16-byte aligned buffers required");
+    MlpArgs a{};
+    a.x = x; a.y = y; a.w1 = w1_16; a.w2 = w2_16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.M = M; a.eps = eps; a.do_ln = layernorm ? 1 : 0;
+    a.ctx = ctx16; a.wp = wp16; a.bp = bp;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ncu = mi355::resident_slots(1);
+    if (C == 128) {
+        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)16 * 16 * 68 * 4 + (size_t)128 * (128 + 8) * 2;
+        static_assert(sm <= 160 * 1024, "LDS budget");
+        const long niter = ((M + 15) / 16 + 15) / 16;
+        const int grid2 = (int)(niter < ncu ? niter : ncu);
+        if (precision == MI355_PREC_FP16) {
+            static bool at1 = false;
+            if (!at1) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at1 = true; }
+            mlp_fused_stream_kernel<1, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
+        } else {
+            static bool at2 = false;
+            if (!at2) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at2 = true; }
+            mlp_fused_stream_kernel<2, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
+        }
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
+    const long nchunk = (M + 31) / 32;
+    long grid = (nchunk + 15) / 16;
+    if (grid > ncu) grid = ncu;
+    constexpr size_t smem = mlp_smem<64, 256>(true);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    if (precision == MI355_PREC_FP16) {
+        static bool attr1 = false;
+        if (!attr1) {
+            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr1 = true;
+        }
+        mlp_fused_kernel<1, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) {
+            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr2 = true;
+        }
+        mlp_fused_kernel<2, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
     }
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mi355_adaptive_pool_tokens_fwd": (c_int, [c_vp] * 2 + [c_int] * 6 + [c_vp]),
     "mi355_dwconv3x3_tokens_residual_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [ctypes.c_long, c_vp]),
     "mi355_mlp_fused_fwd": (c_int, [c_vp] * 7 + [ctypes.c_long, c_int, c_int, c_int, ctypes.c_float, c_int, c_vp]),
+    "mi355_proj_mlp_fused_fwd": (c_int, [c_vp] * 10 + [ctypes.c_long, c_int, c_int, c_int, ctypes.c_float, c_int, c_vp]),
     "mi355_sdpa_general_fwd": (c_int, [c_vp] * 5 + [c_int] * 5 + [ctypes.c_long] * 5 + [ctypes.c_float, c_int, c_int, c_vp]),
     "mi355_dwconv_patch_tokens_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),
     "mi355_cswin_lepe_attn16_pair_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [ctypes.c_float, c_int, c_vp]),

@@ -489,9 +489,15 @@ def mlp_fused_ok(C, hidden, precision=None):
     return _prec(precision) in (PREC_FP16, PREC_BF16) and (C, hidden) in ((64, 256), (128, 512))
 
 
-def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None):
+def proj_mlp_fused_ok(C, hidden, precision=None):
+    """Shape / precision envelope of mi355_proj_mlp_fused_fwd."""
+    return _prec(precision) in (PREC_FP16, PREC_BF16) and (C, hidden) in ((64, 256), (128, 512))
+
+
+def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None, ctx16=None, proj=None):
     """y = x + gamma * fc2(gelu(fc1(ln(x)))) in one kernel (hidden activations never reach HBM).  `ln` is the LayerNorm in front of
-    the MLP (its affine part is folded into fc1 here, cached per parameter version) or None."""
+    the MLP (its affine part is folded into fc1 here, cached per parameter version) or None.  With `ctx16` (M, C) 16-bit and `proj`
+    (a Linear) the kernel first forms x1 = x + proj(ctx16) and runs the MLP on x1 (second half of a CSWinBlock in one launch)."""
     p = _prec(precision)
     x = require_device_f32(x, "x")
     C = x.shape[-1]
@@ -516,6 +522,16 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None):
                              lambda: cast16(fc2.weight.detach().reshape(C, Hd // 32, 32).permute(1, 0, 2).contiguous(), p))
     y = torch.empty_like(x)
     M = x.numel() // C
+    if ctx16 is not None:
+        ctx16 = _require16(ctx16, "ctx16", p)
+        wp16 = weight16(proj.weight, p)
+        bp = proj.bias if proj.bias is not None else _derived_get((proj,), ("zero_bias",), (proj.weight.data_ptr(),),
+                                                                  lambda: torch.zeros(C, dtype=torch.float32, device=x.device))
+        check(lib().mi355_proj_mlp_fused_fwd(dptr(x), dptr(ctx16), dptr(wp16), dptr(require_device_f32(bp, "proj.bias")), dptr(w1_16), dptr(b1),
+                                             dptr(w2_16), dptr(_opt(fc2.bias, "fc2.bias")), dptr(_opt(gamma, "gamma")), dptr(y), M, C, Hd,
+                                             0 if ln is None else 1, float(ln.eps) if ln is not None else 0.0, p, stream_ptr(x.device)),
+              "mi355_proj_mlp_fused_fwd")
+        return y
     check(lib().mi355_mlp_fused_fwd(dptr(x), dptr(w1_16), dptr(b1), dptr(w2_16), dptr(_opt(fc2.bias, "fc2.bias")), dptr(_opt(gamma, "gamma")),
                                     dptr(y), M, C, Hd, 0 if ln is None else 1, float(ln.eps) if ln is not None else 0.0, p,
                                     stream_ptr(x.device)), "mi355_mlp_fused_fwd")

@@ -123,6 +123,9 @@ class CSWinBlock(nn.Module):
         else:
             self.attns[0].run(qkv, att, 0)
         if fast:
+            if F.proj_mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
+                # proj + residual + LN2 + fc1 + GELU + fc2 + residual in one launch: x1 never reaches HBM
+                return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=p, ctx16=att, proj=self.proj)
             x = F.linear16(att, F.weight16(self.proj.weight, p), self.proj.bias, resid=x, precision=p)
             if F.mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
                 return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=p)      # LN2 + fc1 + GELU + fc2 + residual
