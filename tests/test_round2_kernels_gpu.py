@@ -1,0 +1,156 @@
+"""Op-level checks of the kernels added in round 2, below the module-level golden / full-size tests:
+
+  * persistent 256x256 GEMM (gemm16_p8.hip): ragged M / N edges, one tile, fewer tiles than CUs, many rounds, every epilogue
+    combination, bf16, bit identity with the round-1 kernel where no K split applies, split-K last round against fp64;
+  * fused first half of a CSWinBlock (cswin_fused.hip) on geometries beyond the two model stages (short windows, one row of
+    windows, bf16) against the oracle's LayerNorm -> qkv -> LePE attention;
+  * fused second half (proj + residual + LN + MLP + residual) against the unfused composition of the same library ops and fp64.
+"""
+import pytest
+import torch
+
+import oracle as O
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_linear(x16, w16, b, act, gamma, resid):
+    y = x16.double() @ w16.double().t()
+    if b is not None:
+        y = y + b.double()
+    if act:
+        y = torch.nn.functional.gelu(y)
+    if gamma is not None:
+        y = y * gamma.double()
+    if resid is not None:
+        y = y + resid.double()
+    return y
+
+
+P8_SHAPES = [  # (M, N, K): all have >= one full round of 256x256 tiles on a 256-CU part unless forced through gemm_variant 15
+    (50432, 2304, 768), (50432, 768, 768), (12544, 1536, 512), (50176, 1152, 384),
+    (65536 + 40, 256 + 8, 256),          # ragged in both directions, 2 tile columns, the second almost empty
+    (300, 264, 128), (256, 256, 64), (1, 8, 64), (4097, 520, 192),
+]
+
+
+@pytest.mark.parametrize("prec,dt", [(1, torch.float16), (2, torch.bfloat16)])
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_persistent_gemm_matches_round1_kernel_and_fp64(M, N, K, prec, dt):
+    """gemm_variant 15 forces the persistent kernel on any shape; with the K split off it must be bit-identical to variant 7
+    (same products, same K order) for every epilogue, and both must sit on the fp64 product of the rounded operands."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(M + N + K)
+    x16 = torch.randn(M, K, device="cuda").to(dt)
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).to(dt)
+    b = torch.randn(N, device="cuda")
+    gamma = torch.rand(N, device="cuda") + 0.5
+    resid = torch.randn(M, N, device="cuda")
+    combos = [dict(bias=b, out16=True), dict(bias=b, act=F.ACT_GELU, out16=True), dict(bias=b, resid=resid), dict(bias=None, gamma=gamma, resid=resid, act=F.ACT_GELU)]
+    try:
+        mi355attn.set_option("gemm_splitk", 0)
+        for kw in combos:
+            mi355attn.set_option("gemm_variant", 7)
+            y7 = F.linear16(x16, w16, precision=prec, **kw)
+            mi355attn.set_option("gemm_variant", 15)
+            y15 = F.linear16(x16, w16, precision=prec, **kw)
+            y15b = F.linear16(x16, w16, precision=prec, **kw)
+            assert torch.equal(y15, y15b), "run-to-run"
+            assert torch.equal(y7, y15), f"persistent kernel differs from variant 7 with {sorted(kw)}"
+        if M * N <= 3_000_000:
+            ref = _ref_linear(x16.cpu(), w16.cpu(), b.cpu(), True, None, None)
+            assert_parity(F.linear16(x16, w16, b, act=F.ACT_GELU, precision=prec).cpu(), ref.float(), 2e-5 if prec == 1 else 2e-5, "fp64 product")
+    finally:
+        mi355attn.set_option("gemm_variant", 0)
+        mi355attn.set_option("gemm_splitk", 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 3072), (12544, 512, 2048), (20000, 1024, 1536), (770, 520, 4096)])
+def test_persistent_gemm_split_last_round(M, N, K):
+    """K >= 1536 with a partially filled last round: the left-over tiles are cut along K (partial sums through the workspace).  The
+    result equals the unsplit one to fp32 summation-order noise, is deterministic, and sits on the fp64 product (sampled rows)."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(7)
+    x16 = torch.randn(M, K, device="cuda").half()
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda")
+    try:
+        mi355attn.set_option("gemm_variant", 15)
+        mi355attn.set_option("gemm_splitk", 1)
+        ys = F.linear16(x16, w16, b, resid=resid, precision=1)
+        ys2 = F.linear16(x16, w16, b, resid=resid, precision=1)
+        mi355attn.set_option("gemm_splitk", 0)
+        yu = F.linear16(x16, w16, b, resid=resid, precision=1)
+    finally:
+        mi355attn.set_option("gemm_variant", 0)
+        mi355attn.set_option("gemm_splitk", 1)
+    assert torch.equal(ys, ys2), "split-K result is not deterministic"
+    assert_parity(ys.cpu(), yu.cpu(), 2e-6, "split vs unsplit")
+    rows = torch.tensor([0, 1, M // 3, M // 2 + 5, M - 2, M - 1])
+    ref = _ref_linear(x16[rows].cpu(), w16.cpu(), b.cpu(), False, None, resid[rows].cpu())
+    assert_parity(ys[rows].cpu(), ref.float(), 2e-6, "fp64 product, sampled rows")
+
+
+STRIPES = [  # (C, reso, heads, split, B): tokens per stripe = reso * split <= 64
+    (64, 56, 2, 1, 3), (128, 28, 4, 2, 3), (64, 28, 2, 2, 2), (64, 8, 2, 2, 5), (128, 16, 4, 4, 2), (64, 16, 2, 1, 1), (128, 8, 4, 8, 2), (64, 7, 2, 7, 3),
+]
+
+
+@pytest.mark.parametrize("prec,tol", [(1, 1e-3), (2, 8e-3)])
+@pytest.mark.parametrize("C,reso,heads,split,B", STRIPES)
+def test_fused_stripe_attention_vs_oracle(C, reso, heads, split, B, prec, tol):
+    """LayerNorm -> qkv -> two stripe branches of LePE attention in one kernel, against the oracle's composition (fp32)."""
+    from mi355attn import functional as F
+    from mi355attn.modules import CSWinBlock
+    if reso == split:
+        pytest.skip("reso == split is the single-branch last stage (cswin.py:146-147), not a stripe pair")
+    torch.manual_seed(1234)
+    m = CSWinBlock(C, reso, heads, split_size=split, qkv_bias=True).eval()
+    with torch.no_grad():                                   # non-trivial LayerNorm affine part: it is folded into the projection
+        m.norm1.weight.add_(0.2 * torch.randn(C))
+        m.norm1.bias.add_(0.2 * torch.randn(C))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(B, reso * reso, C)
+    u = O.layernorm(x, sd["norm1.weight"], sd["norm1.bias"])
+    qkv = O.linear(u, sd["qkv.weight"], sd["qkv.bias"]).reshape(B, reso * reso, 3, C).permute(2, 0, 1, 3)
+    half = C // 2
+    ref = torch.cat([O.lepe_attention_forward(qkv[..., :half], sd["attns.0.get_v.weight"], sd["attns.0.get_v.bias"], reso, 0, split, heads // 2),
+                     O.lepe_attention_forward(qkv[..., half:], sd["attns.1.get_v.weight"], sd["attns.1.get_v.bias"], reso, 1, split, heads // 2)], dim=2)
+    m = m.cuda()
+    assert F.cswin_stripe_ok(C, reso, split, heads, prec)
+    with torch.no_grad():
+        ctx = F.cswin_stripe_attention(x.cuda(), m.norm1, m.qkv, m.attns[0].get_v, m.attns[1].get_v, reso, heads, split, m.attns[0].scale, prec)
+        ctx2 = F.cswin_stripe_attention(x.cuda(), m.norm1, m.qkv, m.attns[0].get_v, m.attns[1].get_v, reso, heads, split, m.attns[0].scale, prec)
+    assert torch.equal(ctx, ctx2)
+    assert_parity(ctx.float().cpu(), ref, tol, f"stripe attention C={C} reso={reso} split={split}")
+
+
+@pytest.mark.parametrize("prec,tol", [(1, 3e-4), (2, 3e-3)])
+@pytest.mark.parametrize("C", [64, 128])
+@pytest.mark.parametrize("M", [1, 33, 802, 70000])
+def test_fused_proj_mlp_vs_fp64(M, C, prec, tol):
+    """x1 = x + proj(ctx16); y = x1 + fc2(gelu(fc1(LN(x1)))) in one kernel against fp64 on the same 16-bit ctx."""
+    from mi355attn import functional as F
+    from torch import nn
+    torch.manual_seed(M + C)
+    ln, proj, fc1, fc2 = nn.LayerNorm(C), nn.Linear(C, C), nn.Linear(C, 4 * C), nn.Linear(4 * C, C)
+    with torch.no_grad():
+        ln.weight.add_(0.2 * torch.randn(C)); ln.bias.add_(0.2 * torch.randn(C))
+    mods = [mm.eval().cuda() for mm in (ln, proj, fc1, fc2)]
+    ln, proj, fc1, fc2 = mods
+    x = torch.randn(M, C, device="cuda")
+    ctx16 = torch.randn(M, C, device="cuda").to(F.dtype16(prec))
+    with torch.no_grad():
+        y = F.mlp_fused(x, ln, fc1, fc2, precision=prec, ctx16=ctx16, proj=proj)
+        y2 = F.mlp_fused(x, ln, fc1, fc2, precision=prec, ctx16=ctx16, proj=proj)
+        d = lambda t: t.detach().double().cpu()
+        x1 = d(x) + d(ctx16) @ d(proj.weight).t() + d(proj.bias)
+        u = torch.nn.functional.layer_norm(x1, (C,), d(ln.weight), d(ln.bias), ln.eps)
+        ref = x1 + torch.nn.functional.gelu(u @ d(fc1.weight).t() + d(fc1.bias)) @ d(fc2.weight).t() + d(fc2.bias)
+    assert torch.equal(y, y2)
+    assert_parity(y.cpu(), ref.float(), tol, f"proj + MLP fused M={M} C={C}")
