@@ -127,10 +127,11 @@ int sync_pending(const char* who) {
     const unsigned code = __atomic_load_n(w, __ATOMIC_ACQUIRE);
     if (!code) return MI355_OK;
     __atomic_store_n(w, 0u, __ATOMIC_RELEASE);
-    static const char* const names[] = {"?", "SE (se_single_kernel)", "CBAM (cbam_single_kernel)", "channel-statistics gate (stat_single_kernel)"};
+    static const char* const names[] = {"?", "SE (se_single_kernel)", "CBAM (cbam_single_kernel)", "channel-statistics gate (stat_single_kernel)",
+                                        "the persistent GEMM's split last round (gemm16_p8_kernel)"};
     return fail(MI355_ESYNC, "%s: an inter-workgroup exchange of an EARLIER launch of %s ran out of its poll budget (%u sweeps): that launch's "
                 "output is invalid.  Typical cause: fewer workgroups resident than one image needs (partitioned / masked device)",
-                who, names[code < 4 ? code : 0], spin_limit());
+                who, names[code < 5 ? code : 0], spin_limit());
 }
 int resident_slots(int per_cu) {
     int dev = 0, ncu = 256;

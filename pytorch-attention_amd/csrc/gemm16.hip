@@ -625,7 +625,8 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
     long variant = mi355::opt_gemm_variant();
     if (variant == 15) {                   // persistent 256 x 256 kernel (gemm16_p8.hip)
         const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
-        if (rc != MI355_OK) return mi355::fail(rc, "mi355_linear16_fwd: persistent kernel does not take this shape");
+        if (rc == MI355_EUNSUPPORTED) return mi355::fail(rc, "mi355_linear16_fwd: persistent kernel does not take this shape");
+        if (rc != MI355_OK) return rc;
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
@@ -662,10 +663,12 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
         const long rounds = (ntiles + ncu - 1) / ncu;
         (void)rounds;
         if (ntiles >= ncu && K >= 256) {
-            if (mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st) == MI355_OK) {
+            const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
+            if (rc == MI355_OK) {
                 MI355_LAUNCH_CHECK();
                 return MI355_OK;
             }
+            if (rc != MI355_EUNSUPPORTED) return rc;                 // e.g. MI355_ESYNC: an earlier launch failed, reported once
         }
     }
     if (variant == 0) {        // default (profiles/r01_gemm_variants.md): 8 waves on a 128x256 tile, single LDS buffer, 3 workgroups

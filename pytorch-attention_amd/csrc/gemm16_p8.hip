@@ -40,6 +40,8 @@ struct P8Plan {
     int left, split;       // R left-over tiles, each cut into S K-chunks (S >= 1; the chunk units go to workgroups 0 .. R*S-1)
     float* part;           // (R, S-1, 8 waves, 8192) fp32 partial accumulators
     unsigned* arrive;      // R words, zeroed by the launcher: waves of chunks s > 0 that have published
+    unsigned* herr;        // pinned host failure word (api.hip sync_err_word) or null
+    unsigned spin;         // poll budget of chunk 0 (sweeps of ~1 us)
 };
 namespace {
 
@@ -252,11 +254,19 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
             const bool is_chunk = out_tile >= nfull;
             if (is_chunk && pl.split > 1) {
                 // ---- K-chunk 0: wait for the 8 * (S-1) partner waves, add their partial accumulators ------------------------------------
+                // Bounded like every other inter-workgroup wait of the library: the partner chunks are workgroups of the SAME launch with
+                // one workgroup per CU, so they run unless the device offers fewer CUs than the grid; a wait that runs out reports
+                // through mi355_sync_status (code 4) instead of hanging the queue.
                 const unsigned want = 8u * (unsigned)(pl.split - 1);
+                unsigned spins = 0;
                 for (;;) {
                     const unsigned got = __hip_atomic_load(pl.arrive + ch_tile_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_readfirstlane(got) >= want) break;
                     __builtin_amdgcn_s_sleep(8);
+                    if (++spins > pl.spin) {
+                        if (lane == 0 && pl.herr) __hip_atomic_store(pl.herr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
                 for (int s = 0; s < pl.split - 1; ++s) {                    // sc1 loads: served below this CU's L1, coherent with the sc1 stores
                     const float* slab = pl.part + (((long)ch_tile_r * (pl.split - 1) + s) * 8 + wave) * 8192;
@@ -439,7 +449,10 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
         pl.split = 1;
         if (pl.full == 0) grid = pl.left;
     }
+    pl.herr = sync_err_word();
+    pl.spin = spin_limit();
     if (pl.split > 1) {
+        if (int rc = sync_pending("gemm16_p8")) return rc;
         pl.arrive = static_cast<unsigned*>(ws);
         pl.part = reinterpret_cast<float*>(static_cast<char*>(ws) + ab);
         hipError_t e = hipMemsetAsync(pl.arrive, 0, (size_t)pl.left * sizeof(unsigned), st);

@@ -154,3 +154,34 @@ def test_fused_proj_mlp_vs_fp64(M, C, prec, tol):
         ref = x1 + torch.nn.functional.gelu(u @ d(fc1.weight).t() + d(fc1.bias)) @ d(fc2.weight).t() + d(fc2.bias)
     assert torch.equal(y, y2)
     assert_parity(y.cpu(), ref.float(), tol, f"proj + MLP fused M={M} C={C}")
+
+
+def test_split_round_poll_timeout_is_reported():
+    """The reducer chunk of the split last round polls a counter the partner chunks increment; with a zero poll budget it gives up at
+    once, the launch still terminates, and the failure surfaces through mi355_sync_status / the next split launch (MI355_ESYNC)."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(3)
+    M, N, K = 50432, 768, 3072
+    x16 = torch.randn(M, K, device="cuda").half()
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    mi355attn.sync_status(wait=True)
+    old = mi355attn.get_option("spin_limit")
+    try:
+        mi355attn.set_option("spin_limit", 0)
+        F.linear16(x16, w16, precision=1)
+        torch.cuda.synchronize()
+        mi355attn.set_option("spin_limit", old)
+        try:
+            mi355attn.sync_status()
+            timed_out = False
+        except mi355attn.Mi355Error as e:
+            assert "split last round" in str(e)
+            timed_out = True
+    finally:
+        mi355attn.set_option("spin_limit", old)
+    # a partner can legitimately have published before the very first poll: then there is nothing to report and the result is right
+    y = F.linear16(x16, w16, precision=1)
+    mi355attn.sync_status(wait=True)
+    ref = x16[:64].double().cpu() @ w16.double().cpu().t()
+    assert_parity(y[:64].cpu(), ref.float(), 2e-6, "after the zero-budget launch (timed out: %s)" % timed_out)
