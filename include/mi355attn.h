@@ -126,6 +126,10 @@ int    mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const fl
 /* DoubleAttention.forward  (attention_mechanisms/double_attention.py:32-48)
  *   wA (cm,C) bA (cm) | wB (cn,C) bB (cn) | wV (cn,C) bV (cn) | wP (C,cm) bP (C);  x,y (B,C,H,W). */
 size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, int W);
+/* The same for one precision mode (any mode fits in the size above): the 16-bit modes at c_m = c_n = 128, C in {128, 256} run in two
+ * passes over the image (x read once, y written once, a 16-bit softmax(V) in between) and need a fraction of it.  Option "da_fused" = 0
+ * selects the seven-launch pipeline for every shape. */
+size_t mi355_double_attn_ws_bytes(int B, int C, int cm, int cn, int H, int W, int precision);
 int    mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB,
                              const float* wV, const float* bV, const float* wP, const float* bP, float* y,
                              int B, int C, int cm, int cn, int H, int W, int precision,

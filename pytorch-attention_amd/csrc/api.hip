@@ -20,6 +20,8 @@ static std::atomic<long> g_stem_direct{1};  // narrow conv stems: direct fp32 ke
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
 static std::atomic<long> g_spin_limit{1L << 22};   // poll budget of the exchange kernels (sweeps) before they give up with an error code
 static std::atomic<long> g_gemm_splitk{1};   // persistent GEMM: cut the tiles of the last partial round along K (gemm16_p8.hip)
+std::atomic<long> g_da_fused{1};       // DoubleAttention: two-pass kernels where they apply (double_attn_fused.hip)
+std::atomic<long> g_da_ranges{0};      // ... pixel ranges per image in pass 1: 0 = from the batch size, 1..32 = fixed
 static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
 
 char* err_buf() { return g_err; }
@@ -145,6 +147,8 @@ long opt_stem_direct() { return g_stem_direct.load(std::memory_order_relaxed); }
 long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 long opt_gemm_splitk() { return g_gemm_splitk.load(std::memory_order_relaxed); }
+long opt_da_fused() { return g_da_fused.load(std::memory_order_relaxed); }
+long opt_da_ranges() { return g_da_ranges.load(std::memory_order_relaxed); }
 }  // namespace mi355
 
 struct mi355_timer {
@@ -213,6 +217,16 @@ int mi355_set_option(const char* key, long value) {
         mi355::g_gemm_splitk.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
+    if (std::strcmp(key, "da_fused") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_da_fused.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
+    if (std::strcmp(key, "da_ranges") == 0) {
+        MI355_CHECK_ARG(value >= 0 && value <= 32);
+        mi355::g_da_ranges.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
     if (std::strcmp(key, "se_occ") == 0) {
         MI355_CHECK_ARG(value == 2 || value == 3);
         mi355::g_se_occ.store(value, std::memory_order_relaxed);
@@ -241,6 +255,8 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
     if (key && std::strcmp(key, "gemm_splitk") == 0) return mi355::opt_gemm_splitk();
+    if (key && std::strcmp(key, "da_fused") == 0) return mi355::opt_da_fused();
+    if (key && std::strcmp(key, "da_ranges") == 0) return mi355::opt_da_ranges();
     if (key && std::strcmp(key, "spin_limit") == 0) return (long)mi355::spin_limit();
     if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
     if (key && std::strcmp(key, "stem_direct") == 0) return mi355::opt_stem_direct();

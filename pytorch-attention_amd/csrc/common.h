@@ -18,6 +18,8 @@ long  opt_nt();
 long  opt_reverse();
 long  opt_gemm_variant();
 long  opt_gemm_splitk();
+long  opt_da_fused();
+long  opt_da_ranges();
 long  opt_eca_single();
 long  opt_se_single();
 long  opt_se_occ();
@@ -60,6 +62,11 @@ int   se_single(const float* x, const float* w1, const float* w2, float* y, int 
 bool  eca_single_applicable(int C, int k, int H, int W);
 int   eca_single(const float* x, const float* taps, float* y, int B, int C, int k, int H, int W, hipStream_t st);
 size_t fused_state_bytes(int B);
+// DoubleAttention in two passes over the image (double_attn_fused.hip): 16-bit operand modes, c_m = c_n = 128, C in {128, 256}
+bool   double_attn_fused_ok(int B, int C, int cm, int cn, int HW, int precision);
+size_t double_attn_fused_workspace(int B, int C, int HW);
+int    double_attn_fused(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV, const float* bV,
+                         const float* wP, const float* bP, float* y, int B, int C, int HW, int precision, void* ws, hipStream_t st);
 // GEMM engine (gemm.hip), shared by the other translation units.  NT: B is (N,K) K-contiguous; KN: B is (K,N) N-contiguous.
 int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
             int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st);

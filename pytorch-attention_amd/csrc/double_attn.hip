@@ -155,13 +155,23 @@ size_t mi355_double_attn_workspace_bytes(int B, int C, int cm, int cn, int H, in
            r16((size_t)B * HW * C * 2) + r16(M3 * C * 2);      // token-major 16-bit copy of x and the 16-bit weights of the fast first product
 }
 
+// The same for one precision mode: the two-pass path of the 16-bit modes (double_attn_fused.hip) needs the 16-bit V tensor and the
+// per-range partial results only -- 0.2 GB instead of 1.7 GB at (256, 256, 56, 56).
+size_t mi355_double_attn_ws_bytes(int B, int C, int cm, int cn, int H, int W, int precision) {
+    if (B > 0 && C > 0 && H > 0 && W > 0 && mi355::opt_da_fused() != 0 && mi355::double_attn_fused_ok(B, C, cm, cn, H * W, precision))
+        return mi355::double_attn_fused_workspace(B, C, H * W);
+    return mi355_double_attn_workspace_bytes(B, C, cm, cn, H, W);
+}
+
 int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV,
                           const float* bV, const float* wP, const float* bP, float* y, int B, int C, int cm, int cn, int H, int W,
                           int precision, void* ws, size_t ws_bytes, mi355_stream_t stream) {
     MI355_CHECK_ARG(x && wA && bA && wB && bB && wV && bV && wP && bP && y && ws);
     MI355_CHECK_ARG(B > 0 && C > 0 && cm > 0 && cn > 0 && H > 0 && W > 0);
-    MI355_CHECK_ARG(ws_bytes >= mi355_double_attn_workspace_bytes(B, C, cm, cn, H, W));
+    MI355_CHECK_ARG(ws_bytes >= mi355_double_attn_ws_bytes(B, C, cm, cn, H, W, precision));
     const int HW = H * W, M3 = cm + 2 * cn;
+    if (mi355::double_attn_fused_ok(B, C, cm, cn, HW, precision) && aligned16(x) && aligned16(y) && aligned16(ws) && mi355::opt_da_fused() != 0)
+        return mi355::double_attn_fused(x, wA, bA, wB, bB, wV, bV, wP, bP, y, B, C, HW, precision, ws, static_cast<hipStream_t>(stream));
     if ((HW & 3) || (C & 3) || (cm & 3) || (cn & 3) || !aligned16(x) || !aligned16(y) || !aligned16(ws))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_double_attn_fwd: H*W, C, c_m, c_n must be multiples of 4 (HW=%d C=%d cm=%d cn=%d)",
                            HW, C, cm, cn);

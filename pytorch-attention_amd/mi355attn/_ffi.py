@@ -45,6 +45,7 @@ SIGNATURES = {
     "mi355_cbam_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_cbam_fwd": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp, c_size, c_vp]),
     "mi355_double_attn_workspace_bytes": (c_size, [c_int] * 6),
+    "mi355_double_attn_ws_bytes": (c_size, [c_int] * 7),
     "mi355_double_attn_fwd": (c_int, [c_vp] * 10 + [c_int] * 7 + [c_vp, c_size, c_vp]),
     "mi355_linear_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
     "mi355_token_mix_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),

@@ -315,7 +315,7 @@ def double_attention_forward(x, wA, bA, wB, bB, wV, bV, wP, bP, precision=None):
     if wV.shape[0] != cn or wP.shape[1] != cm or wA.shape[1] != C:
         raise ValueError("DoubleAttention weight shapes are inconsistent")
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    n = lib().mi355_double_attn_workspace_bytes(B, C, cm, cn, H, W)
+    n = lib().mi355_double_attn_ws_bytes(B, C, cm, cn, H, W, _prec(precision))
     ws = workspace(n, x.device)
     check(lib().mi355_double_attn_fwd(dptr(x), dptr(wA), dptr(bA), dptr(wB), dptr(bB), dptr(wV), dptr(bV),
                                       dptr(wP), dptr(bP), dptr(y), B, C, cm, cn, H, W, _prec(precision),

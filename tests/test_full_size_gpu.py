@@ -12,7 +12,8 @@ test asserts:
   * run-to-run bit identity of the full-size launch;
   * batch independence: a 3-image batch of the sampled images gives the same rows as the 256-image run bit-for-bit (every GEMM
     variant keeps a row's K order); the one exception is the split last round of the persistent GEMM ("gemm_splitk"), with which
-    the rows agree to the operand format's rounding level and bit-for-bit again once it is switched off.
+    the rows agree to the operand format's rounding level and bit-for-bit again once it is switched off (DoubleAttention: the
+    pixel ranges of pass 1 follow the batch size unless "da_ranges" pins them).
 """
 import pytest
 import torch
@@ -46,7 +47,7 @@ def _device_batch(shape, slab=32):
     return x, host
 
 
-def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5):
+def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5, pin=("gemm_splitk", 0)):
     import mi355attn
     m = module.cuda()
     x, host = _device_batch(shape)
@@ -67,16 +68,18 @@ def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5):
         # at the operand format's rounding level downstream -- inside the parity tolerance by a factor of two at least.  With the
         # split off every row must be bit-identical whatever the batch around it.
         assert_parity(sub.cpu(), y[PICK].cpu(), 5e-4, name + " [batch independence, split-K on]")
-        mi355attn.set_option("gemm_splitk", 0)
+        # DoubleAttention's analogue: the number of pixel ranges an image is cut into follows the batch size ("da_ranges" pins it).
+        old_pin = mi355attn.get_option(pin[0])
+        mi355attn.set_option(*pin)
         try:
             with torch.no_grad():
                 y0 = m(x, *fwd_args)
                 sub0 = m(x[PICK].contiguous(), *fwd_args)
             torch.cuda.synchronize()
         finally:
-            mi355attn.set_option("gemm_splitk", 1)
-        assert torch.equal(y0[PICK], sub0), name + ": output of an image depends on its batch neighbours (split-K off)"
-        assert_parity(y0[PICK].cpu(), ref, tol, name + " [B=256, split-K off]")
+            mi355attn.set_option(pin[0], old_pin)
+        assert torch.equal(y0[PICK], sub0), name + f": output of an image depends on its batch neighbours ({pin[0]} = {pin[1]})"
+        assert_parity(y0[PICK].cpu(), ref, tol, name + f" [B=256, {pin[0]} = {pin[1]}]")
         del y0, sub0
     assert_parity(sub.cpu(), ref, tol, name + " [3-image batch]")
     del y2, sub
@@ -158,4 +161,4 @@ def test_double_attention_full_size():
     sd = _sd(m)
     keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight", "proj.bias")
     _check("DoubleAttention(256,128,128)@56x56", m, (B, 256, 56, 56),
-           lambda xs: O.double_attention_forward(xs, *[sd[k] for k in keys]))
+           lambda xs: O.double_attention_forward(xs, *[sd[k] for k in keys]), pin=("da_ranges", 1))

@@ -185,3 +185,43 @@ def test_split_round_poll_timeout_is_reported():
     mi355attn.sync_status(wait=True)
     ref = x16[:64].double().cpu() @ w16.double().cpu().t()
     assert_parity(y[:64].cpu(), ref.float(), 2e-6, "after the zero-budget launch (timed out: %s)" % timed_out)
+
+
+DA_SHAPES = [  # (B, C, H, W): c_m = c_n = 128 -- the two-pass path; pixel counts with and without a ragged last 32-pixel tile
+    (3, 256, 56, 56), (1, 256, 56, 56), (2, 256, 14, 14), (5, 128, 28, 28), (2, 256, 10, 10), (1, 128, 2, 2), (2, 256, 6, 10), (37, 256, 8, 8), (2, 256, 9, 12), (300, 128, 6, 6),
+]
+
+
+@pytest.mark.parametrize("prec,tol", [(1, 1e-3), (2, 8e-3)])
+@pytest.mark.parametrize("B,C,H,W", DA_SHAPES)
+def test_double_attention_two_pass_vs_oracle(B, C, H, W, prec, tol):
+    """DoubleAttention(C, 128, 128) through the two-pass kernels against the oracle, and against the seven-launch pipeline of the same
+    library (option da_fused = 0); run-to-run identical; an image's result does not depend on its batch neighbours' values."""
+    import mi355attn
+    from mi355attn import functional as F
+    from mi355attn.modules import DoubleAttention
+    torch.manual_seed(100 + B + C + H)
+    m = DoubleAttention(C, 128, 128).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight", "proj.bias")
+    x = torch.randn(B, C, H, W) * 1.5
+    ref = O.double_attention_forward(x, *[sd[k] for k in keys])
+    args = [x.cuda()] + [sd[k].cuda() for k in keys]
+    y = F.double_attention_forward(*args, precision=prec)
+    y2 = F.double_attention_forward(*args, precision=prec)
+    assert torch.equal(y, y2), "run-to-run"
+    assert_parity(y.cpu(), ref, tol, f"two-pass DoubleAttention B={B} C={C} {H}x{W}")
+    try:
+        mi355attn.set_option("da_fused", 0)
+        yu = F.double_attention_forward(*args, precision=prec)
+    finally:
+        mi355attn.set_option("da_fused", 1)
+    tol_u = tol if prec == 1 else 4e-2                          # bf16 through seven roundings of fp32 intermediates: looser on max |diff|
+    assert_parity(yu.cpu(), ref, tol_u, "seven-launch pipeline")
+    assert_parity(y.cpu(), yu.cpu(), tol_u, "two-pass vs seven-launch")
+    if B > 1:
+        xs = args[0].clone()
+        xs[1:] = torch.randn_like(xs[1:]) * 3
+        y3 = F.double_attention_forward(xs, *args[1:], precision=prec)
+        # the pixel ranges per image depend on B only, not on the data: image 0 is bit-identical
+        assert torch.equal(y3[0], y[0]), "image 0 changed with its neighbours' values"
