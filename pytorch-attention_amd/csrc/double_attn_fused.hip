@@ -41,6 +41,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)p;
 }
 
+// One 1 KB LDS-DMA (16 bytes per lane, lane-linear at `dst`) issued BEHIND THE COMPILER'S BACK.  Through the builtin, hipcc knows an
+// LDS-DMA is in flight and -- having no alias scopes for most LDS accesses -- puts `s_waitcnt vmcnt(0)` in front of some later,
+// unrelated ds_read / ds_write (which one changed with every edit of pass 1): that wait drains the whole prefetch ring once per
+// tile.  Pass 1 counts its own DMAs (vmcnt(N) before the barrier that publishes a tile), so the compiler does not need to know.
+__device__ __forceinline__ void lds_dma16(const void* src, const void* dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr(dst))) : "memory", "m0");
+}
+
 struct DaArgs {
     const float* x;            // (B, C, HW) fp32
     const void* w16;           // (3 * 128, C) 16 bit: WA | log2e WB | log2e WV
@@ -115,8 +123,7 @@ __global__ __launch_bounds__(512) void da_pass1_kernel(const DaArgs a) {
         for (int i = 0; i < NDMA; ++i) {
             const int blk = w * NDMA + i;
             const float* src = xb + (long)(blk * 8 + (lane >> 3)) * a.HW + px;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)&s_raw[buf][blk * RB], 16, 0, 0);
+            lds_dma16(src, &s_raw[buf][blk * RB]);
         }
     };
 
@@ -205,7 +212,10 @@ __global__ __launch_bounds__(512) void da_pass1_kernel(const DaArgs a) {
             afrag[i] = M_::cvt1(acc[0][0][i]);
             afrag[4 + i] = M_::cvt1(acc[1][0][i]);
         }
-        // B: online softmax over pixels of channel 16w + l15
+        // B: online softmax over pixels of channel 16w + l15; V: lane holds channels 16w + 4g + [0,4) of pixels 16 rb + l15, softmax
+        // over channels, first within the wave.  The three maxima (and later the two sums) cross the lane groups together: one LDS
+        // round trip per step instead of one per value.
+        f4 ev[2];
         {
             float e[8];
 #pragma unroll
@@ -216,8 +226,14 @@ __global__ __launch_bounds__(512) void da_pass1_kernel(const DaArgs a) {
                     if (tail && px0 + 16 * rb + 4 * g + i >= a.HW) e[4 * rb + i] = -INFINITY;
                 }
             float mx = fmaxf(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])), fmaxf(fmaxf(e[4], e[5]), fmaxf(e[6], e[7])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            float mv0 = fmaxf(fmaxf(acc[0][2].x, acc[0][2].y), fmaxf(acc[0][2].z, acc[0][2].w));
+            float mv1 = fmaxf(fmaxf(acc[1][2].x, acc[1][2].y), fmaxf(acc[1][2].z, acc[1][2].w));
+            {
+                const float a0 = __shfl_xor(mx, 16, WAVE), a1 = __shfl_xor(mv0, 16, WAVE), a2 = __shfl_xor(mv1, 16, WAVE);
+                mx = fmaxf(mx, a0); mv0 = fmaxf(mv0, a1); mv1 = fmaxf(mv1, a2);
+                const float b0 = __shfl_xor(mx, 32, WAVE), b1 = __shfl_xor(mv0, 32, WAVE), b2 = __shfl_xor(mv1, 32, WAVE);
+                mx = fmaxf(mx, b0); mv0 = fmaxf(mv0, b1); mv1 = fmaxf(mv1, b2);
+            }
             // the reference maximum of a channel moves only when the tile's maximum passes it by more than 2^8 (E <= 256 fits any 16-bit
             // format; G and the sum stay consistent because both are relative to the same reference): after the first tiles no
             // channel moves any more and the rescale of G below is skipped for the whole wave
@@ -229,9 +245,9 @@ __global__ __launch_bounds__(512) void da_pass1_kernel(const DaArgs a) {
             v8 ef;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float ev = ex2(e[k] - ms);
-                es += ev;
-                ef[k] = M_::cvt1(ev);
+                const float x = ex2(e[k] - ms);
+                es += x;
+                ef[k] = M_::cvt1(x);
             }
             lsum = lsum * alpha + es;
             m_run = m_new;
@@ -239,22 +255,20 @@ __global__ __launch_bounds__(512) void da_pass1_kernel(const DaArgs a) {
             if (g == 0) s_alpha[16 * w + l15] = alpha;
             const bool any = __ballot(move) != 0;
             if (lane == 0) s_flag[w] = any ? 1u : 0u;
-        }
-        // V: lane holds channels 16w + 4g + [0,4) of pixels 16 rb + l15; softmax over channels, first within the wave
-        f4 ev[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const f4 vv = acc[rb][2];
-            float m = fmaxf(fmaxf(vv.x, vv.y), fmaxf(vv.z, vv.w));
-            m = fmaxf(m, __shfl_xor(m, 16, WAVE));
-            m = fmaxf(m, __shfl_xor(m, 32, WAVE));
-            ev[rb] = f4{ex2(vv.x - m), ex2(vv.y - m), ex2(vv.z - m), ex2(vv.w - m)};
-            float s = (ev[rb].x + ev[rb].y) + (ev[rb].z + ev[rb].w);
-            s += __shfl_xor(s, 16, WAVE);
-            s += __shfl_xor(s, 32, WAVE);
+            ev[0] = f4{ex2(acc[0][2].x - mv0), ex2(acc[0][2].y - mv0), ex2(acc[0][2].z - mv0), ex2(acc[0][2].w - mv0)};
+            ev[1] = f4{ex2(acc[1][2].x - mv1), ex2(acc[1][2].y - mv1), ex2(acc[1][2].z - mv1), ex2(acc[1][2].w - mv1)};
+            float s0 = (ev[0].x + ev[0].y) + (ev[0].z + ev[0].w), s1 = (ev[1].x + ev[1].y) + (ev[1].z + ev[1].w);
+            {
+                const float a0 = __shfl_xor(s0, 16, WAVE), a1 = __shfl_xor(s1, 16, WAVE);
+                s0 += a0; s1 += a1;
+                const float b0 = __shfl_xor(s0, 32, WAVE), b1 = __shfl_xor(s1, 32, WAVE);
+                s0 += b0; s1 += b1;
+            }
             if (g == 0) {
-                s_stat[w][16 * rb + l15][0] = m;
-                s_stat[w][16 * rb + l15][1] = s;
+                s_stat[w][l15][0] = mv0;
+                s_stat[w][l15][1] = s0;
+                s_stat[w][16 + l15][0] = mv1;
+                s_stat[w][16 + l15][1] = s1;
             }
         }
         if (it + 3 < n)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");   // tile it+1 landed; it+2, it+3 may still fly
