@@ -19,3 +19,14 @@ for blk in "SELayer" "CBAM" "ECALayer" "ViT Attention" "CSWinBlock s1" "CSWinBlo
   rm -rf $R/gpurun_out/pmc_f_$tag $R/gpurun_out/pmc_w_$tag
 done
 cd $R
+# DoubleAttention (row a6; its own workload, not part of the default step): bench line + traffic of the (256,128,128)@56x56 block
+timeout 300 python bench.py --workload da --no-cpu > gpurun_out/r2_bench_da.json 2> gpurun_out/r2_bench_da.err
+cd /tmp
+blk="DoubleAttention(256"
+tag=DoubleAttention_256
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_f_$tag -o f -- python $R/bench.py --workload da --no-cpu --steps 3 --warmup 1 --only "$blk" > $R/gpurun_out/pmc_f_$tag.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_w_$tag -o w -- python $R/bench.py --workload da --no-cpu --steps 3 --warmup 1 --only "$blk" > $R/gpurun_out/pmc_w_$tag.log 2>&1
+name=$(python -c "import json,sys; d=json.loads([l for l in open('$R/gpurun_out/pmc_f_$tag.log') if l.startswith('{')][-1]); print(d['config']['blocks'][0]['block'])")
+python $R/tools/pmc_block_traffic.py "$name" $R/gpurun_out/pmc_f_$tag/f_results.db $R/gpurun_out/pmc_w_$tag/w_results.db 8 >> $R/gpurun_out/r2_pmc_blocks.jsonl 2>> $R/gpurun_out/r2_pmc_blocks.err
+rm -rf $R/gpurun_out/pmc_f_$tag $R/gpurun_out/pmc_w_$tag
+cd $R
