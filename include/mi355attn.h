@@ -403,6 +403,14 @@ int    mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const flo
 int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
                           float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
                           mi355_stream_t stream);
+/* The same with a scratch buffer: in the 16-bit operand modes the ViT form (cls + pos) at sizes that fill the chip runs as one im2col
+ * pass into the 16-bit operand format + the persistent GEMM with the position rows as a periodic residual (0.25 -> 0.15 ms at
+ * ViT-Base/16, B = 256).  workspace_bytes() returns 0 where that path does not apply; with ws == NULL or too small a buffer the call
+ * is mi355_patch_embed_fwd. */
+size_t mi355_patch_embed_workspace_bytes(int B, int Cin, int H, int W, int ps, int E, int precision);
+int mi355_patch_embed_ws_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
+                             float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
+                             void* ws, size_t ws_bytes, mi355_stream_t stream);
 
 /* General multi-head attention core (the plain softmax(QK^T*s)V pattern of setr.py:62-72, pvt.py:73-91,
  * segformer.py:33-50, cmt.py:93-111, moat.py:74-84, bvit.py:66-76 ...): any N_q / N_kv, online softmax over 64-key tiles.

@@ -16,6 +16,7 @@
 // is fetched into one L2 instead of eight.
 #include "common.h"
 #include "mma.h"
+#include "gemm16.h"
 
 namespace {
 
@@ -273,6 +274,49 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
     tokens[((long)b * (P + 1) + P) * E + e] = cls[e] + pos[(long)P * E + e];
 }
 
+// ---- patch embedding on the 16-bit engine (mi355_patch_embed_ws_fwd) ------------------------------------------------------------------
+// im2col in the operand format: block = (image b, patch row py, channel c); the ps image rows of that band (W floats each) are read as
+// whole rows into LDS and leave as the (c, ky, kx) slices of the band's W / ps token rows: ps * ps * 2 bytes contiguous per token.
+// With a cls row (ViT, cls LAST: row P of every image) that row of the operand is zero, so the product there is bias + table row P.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__ img, T* __restrict__ a16, int Cin, int H, int W, int ps,
+                                                       int rows_per_img, int K) {
+    extern __shared__ __attribute__((aligned(16))) float s_band[];         // ps x W
+    typedef T v8t __attribute__((ext_vector_type(8)));
+    const int gw = W / ps, gh = H / ps;
+    const int c = blockIdx.x % Cin, py = (blockIdx.x / Cin) % gh, b = blockIdx.x / (Cin * gh);
+    const float* src = img + (((long)b * Cin + c) * H + (long)py * ps) * W;
+    for (int i = threadIdx.x; i < ps * W / 4; i += 256) reinterpret_cast<f4*>(s_band)[i] = reinterpret_cast<const f4*>(src)[i];
+    __syncthreads();
+    const int cpr = ps / 8, cpp = ps * cpr;                                  // 16-byte chunks per patch row / per patch
+    for (int q = threadIdx.x; q < gw * cpp; q += 256) {
+        const int px = q / cpp, r = q - px * cpp, ky = r / cpr, kx0 = (r - ky * cpr) * 8;
+        const float* s = s_band + ky * W + px * ps + kx0;
+        v8t o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (T)s[k];
+        *reinterpret_cast<v8t*>(a16 + ((long)b * rows_per_img + py * gw + px) * K + (long)c * ps * ps + ky * ps + kx0) = o;
+    }
+    if (py == 0 && rows_per_img > gw * gh) {                                 // the zero row of the cls token
+        v8t z;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = (T)0.f;
+        for (int q = threadIdx.x; q < ps * ps / 8; q += 256)
+            *reinterpret_cast<v8t*>(a16 + ((long)b * rows_per_img + gw * gh) * K + (long)c * ps * ps + q * 8) = z;
+    }
+}
+
+// residual table of the product: rows p < P = pos[p], row P = cls + pos[P] - bias (the GEMM adds the bias to every row)
+__global__ void patch_table_kernel(const float* __restrict__ cls, const float* __restrict__ pos, const float* __restrict__ bias,
+                                   float* __restrict__ table, int P, int E) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)(P + 1) * E) return;
+    const int r = (int)(i / E), e = (int)(i % E);
+    table[i] = r < P ? pos[i] : cls[e] + pos[i] - bias[e];
+}
+
+inline size_t r256(size_t n) { return (n + 255) & ~(size_t)255; }
+
 template <int BMODE, int AMODE>
 int launch(const GemmArgs& g, int batch, int precision, hipStream_t st) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
@@ -367,6 +411,56 @@ int mi355_patch_embed_fwd(const float* img, const float* Wp, const float* bp, co
     }
     MI355_LAUNCH_CHECK();
     return MI355_OK;
+}
+
+// The same through the 16-bit engine when it pays: 16-bit operand modes, ViT form (cls + pos), K = Cin*ps*ps a multiple of 64, ps and E
+// multiples of 8.  im2col in the operand format (one pass over the image), then the
+// persistent GEMM with the position rows as a periodic residual table -- 0.25 ms -> 0.15 ms at ViT-Base/16, B = 256.  Everything
+// else, and any call with too small a workspace, takes mi355_patch_embed_fwd's implicit-GEMM kernel.
+static bool patch_embed_fast_ok(const float* cls, int B, int Cin, int H, int W, int ps, int E, int precision) {
+    if (!(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16) || cls == nullptr) return false;
+    const int K = Cin * ps * ps, P = (H / ps) * (W / ps);
+    (void)B;                    // any batch: every 16-bit GEMM kernel keeps a row's K order, so an image's bits do not depend on B
+    return !((K % 64) || K < 192 || (ps & 7) || (E & 7) || (W & 3) || P + 1 < 128 || (size_t)ps * W * 4 > 60000);
+}
+
+size_t mi355_patch_embed_workspace_bytes(int B, int Cin, int H, int W, int ps, int E, int precision) {
+    if (B <= 0 || Cin <= 0 || ps <= 0 || E <= 0 || H < ps || W < ps) return 0;
+    static const float dummy = 0.f;
+    if (!patch_embed_fast_ok(&dummy, B, Cin, H, W, ps, E, precision)) return 0;
+    const size_t K = (size_t)Cin * ps * ps, P = (size_t)(H / ps) * (W / ps);
+    return r256((size_t)B * (P + 1) * K * 2) + r256((size_t)E * K * 2) + r256((P + 1) * E * 4);
+}
+
+int mi355_patch_embed_ws_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos, float* tokens,
+                             int B, int Cin, int H, int W, int ps, int E, int precision, void* ws, size_t ws_bytes,
+                             mi355_stream_t stream) {
+    MI355_CHECK_ARG(img && Wp && bp && tokens);
+    MI355_CHECK_ARG((cls == nullptr) == (pos == nullptr));
+    MI355_CHECK_ARG(B > 0 && Cin > 0 && ps > 0 && E > 0 && H >= ps && W >= ps && H % ps == 0 && W % ps == 0);
+    const size_t need = cls ? mi355_patch_embed_workspace_bytes(B, Cin, H, W, ps, E, precision) : 0;
+    if (need == 0 || ws == nullptr || ws_bytes < need || !aligned16(ws) || !aligned16(img) || !aligned16(Wp) || !aligned16(tokens) ||
+        !aligned16(pos) || !aligned16(bp))
+        return mi355_patch_embed_fwd(img, Wp, bp, cls, pos, tokens, B, Cin, H, W, ps, E, precision, stream);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int K = Cin * ps * ps, P = (H / ps) * (W / ps);
+    char* p = static_cast<char*>(ws);
+    void* a16 = p;  p += r256((size_t)B * (P + 1) * K * 2);
+    void* w16 = p;  p += r256((size_t)E * K * 2);
+    float* table = reinterpret_cast<float*>(p);
+    int rc = mi355_cast16_fwd(Wp, w16, (size_t)E * K, precision, stream);
+    if (rc) return rc;
+    patch_table_kernel<<<cdiv((long)(P + 1) * E, 256), 256, 0, st>>>(cls, pos, bp, table, P, E);
+    const int blocks = B * (H / ps) * Cin;
+    const size_t shm = (size_t)ps * W * 4;
+    if (precision == MI355_PREC_FP16) im2col16_kernel<_Float16><<<blocks, 256, shm, st>>>(img, static_cast<_Float16*>(a16), Cin, H, W, ps, P + 1, K);
+    else                              im2col16_kernel<__bf16><<<blocks, 256, shm, st>>>(img, static_cast<__bf16*>(a16), Cin, H, W, ps, P + 1, K);
+    g16::G16Args g{};
+    g.A = a16; g.B = w16; g.C = tokens; g.bias = bp; g.resid = table; g.resid_period = P + 1;
+    g.M = B * (P + 1); g.N = E; g.K = K; g.lda = K; g.ldb = K; g.ldc = E; g.act = MI355_ACT_NONE;
+    rc = mi355::linear16_dispatch(g, 0, precision, nullptr, 0, st);
+    if (rc == MI355_EUNSUPPORTED) return mi355_patch_embed_fwd(img, Wp, bp, cls, pos, tokens, B, Cin, H, W, ps, E, precision, stream);
+    return rc;
 }
 
 // Conv2d as implicit GEMM (no im2col buffer): rows = output pixels, K = Cin*KH*KW gathered in the A-operand load with zero padding.

@@ -13,6 +13,8 @@ struct G16Args {
     int M, N, K, lda, ldb, ldc;
     int act;
     int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
+    int resid_period;   // gemm16_p8 fp32 outputs only, >= 128: the residual is a (resid_period, ldc) table read at row m % resid_period
+                        // (position rows of a patch embedding); 0 = one residual row per output row
     const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
     float ln_eps;
 };
@@ -33,4 +35,5 @@ __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin
 namespace mi355 {
 int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);     // gemm16_p8.hip
 size_t gemm16_p8_workspace_bytes(int M, int N, int K);
+int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
         for (int i = 0; i < MF; ++i) {
             const int m = m0 + wr * TM + i * 16 + l15;
             if (m >= g.M) continue;
+            const int mr = g.resid_period ? m % g.resid_period : m;      // periodic residual table (patch embedding)
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int n = n0 + wc * TN + j * 16 + g4;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
                 f4 v = acc[i][j] + bias4[j];
                 if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                 if (g.gamma) v = v * gam4[j];
-                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
+                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)mr * g.ldc + n);
                 if constexpr (OUT16) {
                     *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
                 } else {
@@ -621,8 +622,20 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
     G16Args g{};
     g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.gamma = gamma; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    return mi355::linear16_dispatch(g, out16, precision, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// Kernel choice of mi355_linear16_ws_fwd on a checked argument block (also the product of the patch embedding, gemm.hip, which
+// brings a periodic residual table: only the persistent and the plain tile kernels read one).
+int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int M = g.M, N = g.N, K = g.K;
     long variant = mi355::opt_gemm_variant();
+    if (g.resid_period) {
+        if (K == 64 || K == 128 || out16 || !g.resid) return MI355_EUNSUPPORTED;
+        if (variant >= 10 && variant <= 14) variant = 7;
+    }
     if (variant == 15) {                   // persistent 256 x 256 kernel (gemm16_p8.hip)
         const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
         if (rc == MI355_EUNSUPPORTED) return mi355::fail(rc, "mi355_linear16_fwd: persistent kernel does not take this shape");
@@ -654,7 +667,7 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant == 0 && (N & 7) == 0 && !(out16 && resid)) {
+    if (variant == 0 && (N & 7) == 0 && !(out16 && g.resid)) {
         // Persistent 256 x 256 kernel (gemm16_p8.hip) where its one-workgroup-per-CU rounds fill the chip: 16-bit outputs (light
         // epilogue) when the last round is >= 85 % full, fp32 + residual outputs only for long K (the epilogue of a lone workgroup
         // is exposed, the 3-workgroups-per-CU kernel below hides it behind its neighbours).  profiles/r02_gemm_p8.md
@@ -712,6 +725,8 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
+
+extern "C" {
 
 int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K,
                           int ldx, int rows_per_image, int precision, mi355_stream_t stream) {

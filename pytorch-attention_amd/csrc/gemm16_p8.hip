@@ -337,6 +337,8 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                 }
             } else {
                 // fp32: the slab holds 16 rows x 32 columns per step (two of the four column tiles)
+                // periodic residual table: the wave's 128 rows are consecutive, so one modulo per tile and a conditional subtract per row
+                const int per = g.resid_period, mr0 = per ? (m0 + wr * 128) % per : 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -345,7 +347,12 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {                   // residual of this step: in flight while the slab is written
                             const int m = m0 + wr * 128 + i * 16 + h * 8 + srow, n = ncol0 + jh * 32 + sch * 4;
-                            rr[h] = (g.resid && m < g.M && n < g.N) ? *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n)
+                            int mr = m;
+                            if (per) {
+                                mr = mr0 + i * 16 + h * 8 + srow;
+                                mr -= mr >= per ? per : 0;
+                            }
+                            rr[h] = (g.resid && m < g.M && n < g.N) ? *reinterpret_cast<const f4*>(g.resid + (long)mr * g.ldc + n)
                                                                     : f4{0.f, 0.f, 0.f, 0.f};
                         }
 #pragma unroll
@@ -439,7 +446,8 @@ size_t gemm16_p8_workspace_bytes(int M, int N, int K) {
 // Launch the persistent kernel when the shape suits it: called by mi355_linear16_fwd (gemm16.hip).  Returns MI355_EUNSUPPORTED
 // without touching anything when it does not apply.  `ws` (may be null) enables the split last round.
 int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st) {
-    if ((g.K % g16::BK) || (g.N & 7) || (out16 && g.resid)) return MI355_EUNSUPPORTED;   // 16-bit out + residual: rounding point differs
+    if ((g.K % g16::BK) || (g.N & 7) || (out16 && g.resid)) return MI355_EUNSUPPORTED;
+    if (g.resid_period && (g.resid_period < 128 || out16 || !g.resid)) return MI355_EUNSUPPORTED;   // 16-bit out + residual: rounding point differs
     if ((long)cdiv(g.M, 256) * cdiv(g.N, 256) > (1L << 30)) return MI355_EUNSUPPORTED;
     P8Plan pl{};
     int grid;

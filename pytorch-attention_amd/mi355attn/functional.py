@@ -723,6 +723,13 @@ def patch_embed(img, wp, bp, cls, pos, patch, precision=None):
     if pos is not None and pos.numel() != (P + 1) * E:
         raise ValueError("patch_embed: position embedding does not match the patch grid")
     tokens = torch.empty(B, P + (1 if cls is not None else 0), E, dtype=torch.float32, device=img.device)
+    n = lib().mi355_patch_embed_workspace_bytes(B, Cin, H, W, patch, E, _prec(precision)) if cls is not None else 0
+    if n:
+        ws = _ffi.workspace_named("patch_embed", n, img.device)
+        check(lib().mi355_patch_embed_ws_fwd(dptr(img), dptr(wp), dptr(bp), dptr(cls), dptr(pos), dptr(tokens), B, Cin, H, W,
+                                             patch, E, _prec(precision), dptr(ws), ws.numel(), stream_ptr(img.device)),
+              "mi355_patch_embed_ws_fwd")
+        return tokens
     check(lib().mi355_patch_embed_fwd(dptr(img), dptr(wp), dptr(bp), dptr(cls), dptr(pos), dptr(tokens), B, Cin, H, W,
                                       patch, E, _prec(precision), stream_ptr(img.device)), "mi355_patch_embed_fwd")
     return tokens

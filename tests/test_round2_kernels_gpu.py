@@ -225,3 +225,36 @@ def test_double_attention_two_pass_vs_oracle(B, C, H, W, prec, tol):
         y3 = F.double_attention_forward(xs, *args[1:], precision=prec)
         # the pixel ranges per image depend on B only, not on the data: image 0 is bit-identical
         assert torch.equal(y3[0], y[0]), "image 0 changed with its neighbours' values"
+
+
+@pytest.mark.parametrize("prec,tol", [(1, 1e-3), (2, 8e-3)])
+@pytest.mark.parametrize("B,HW,ps,E", [(256, 224, 16, 768), (3, 224, 16, 768), (300, 128, 8, 512), (5, 224, 16, 264)])
+def test_patch_embed_on_the_16bit_engine(B, HW, ps, E, prec, tol):
+    """mi355_patch_embed_ws_fwd: im2col into the operand format + persistent GEMM with the position rows as a periodic residual table,
+    against fp64 on sampled images and against the implicit-GEMM kernel of mi355_patch_embed_fwd (same operand roundings, fp32
+    summation order differs); the cls row (LAST row of every image) must be cls + pos[P] exactly up to one fp32 addition."""
+    import math
+    from mi355attn import functional as F
+    from mi355attn._ffi import lib
+    torch.manual_seed(E + B)
+    Cin = 3
+    img = torch.randn(B, Cin, HW, HW, device="cuda")
+    w, b = (torch.randn(E, Cin, ps, ps) / math.sqrt(Cin * ps * ps)).cuda(), torch.randn(E).cuda()
+    P = (HW // ps) ** 2
+    cls, pos = torch.randn(E).cuda(), torch.randn(P + 1, E).cuda()
+    assert lib().mi355_patch_embed_workspace_bytes(B, Cin, HW, HW, ps, E, prec) > 0, "shape chosen to take the 16-bit engine"
+    tok = F.patch_embed(img, w, b, cls, pos, ps, precision=prec)
+    tok2 = F.patch_embed(img, w, b, cls, pos, ps, precision=prec)
+    assert torch.equal(tok, tok2)
+    assert tok.shape == (B, P + 1, E)
+    # the implicit-GEMM kernel through the entry point without a workspace
+    old = torch.empty_like(tok)
+    from mi355attn._ffi import check, dptr, stream_ptr
+    check(lib().mi355_patch_embed_fwd(dptr(img), dptr(w.reshape(E, -1)), dptr(b), dptr(cls), dptr(pos), dptr(old), B, Cin, HW, HW, ps, E,
+                                      prec, stream_ptr(img.device)), "mi355_patch_embed_fwd")
+    assert_parity(tok.cpu(), old.cpu(), 2e-6 if prec == 1 else 2e-5, "16-bit engine vs implicit GEMM")
+    pick = [0, B // 2, B - 1]
+    ref = O.vit_patch_embed_forward(img[pick].cpu(), w.cpu(), b.cpu(), torch.float64)
+    ref = torch.cat([ref, cls.cpu().double().expand(len(pick), 1, E)], dim=1) + pos.cpu().double()
+    assert_parity(tok[pick].cpu(), ref.float(), tol, "patch_embed on the 16-bit engine")
+    assert_parity(tok[:, P].cpu(), (cls + pos[P]).cpu().expand(B, E), 1e-6, "cls rows")
