@@ -26,6 +26,7 @@
 //   their accumulators in register layout (1 KB per wave-instruction) into a caller-provided fp32 slab, release at agent scope and
 //   count themselves in on a per-tile word; chunk 0 polls that word (relaxed), acquires, adds the slabs and runs the normal
 //   epilogue -- N = 768 outputs (591 tiles on 256 CUs = 2.31 rounds) take 2.33 rounds instead of 3.  Without a workspace S = 1.
+#include <atomic>
 #include "gemm16.h"
 #include "bufops.h"
 
@@ -39,7 +40,9 @@ struct P8Plan {
     int full;              // F: whole tiles per workgroup
     int left, split;       // R left-over tiles, each cut into S K-chunks (S >= 1; the chunk units go to workgroups 0 .. R*S-1)
     float* part;           // (R, S-1, 8 waves, 8192) fp32 partial accumulators
-    unsigned* arrive;      // R words, zeroed by the launcher: waves of chunks s > 0 that have published
+    unsigned long long* arrive;   // (R, S-1, 8 waves) flags {tag, ~tag}: the wave of chunk s > 0 that has published its slab.  Never zeroed:
+                           // the tag is unique per launch, so whatever an earlier launch (or other data) left there cannot match
+    unsigned tag;
     unsigned* herr;        // pinned host failure word (api.hip sync_err_word) or null
     unsigned spin;         // poll budget of chunk 0 (sweeps of ~1 us)
 };
@@ -257,11 +260,13 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                 // Bounded like every other inter-workgroup wait of the library: the partner chunks are workgroups of the SAME launch with
                 // one workgroup per CU, so they run unless the device offers fewer CUs than the grid; a wait that runs out reports
                 // through mi355_sync_status (code 4) instead of hanging the queue.
-                const unsigned want = 8u * (unsigned)(pl.split - 1);
+                // lane s < S-1 of owner wave w watches the flag of partner (chunk s + 1, wave w): those are exactly the slabs this wave adds
+                const unsigned long long want = ((unsigned long long)(~pl.tag) << 32) | pl.tag;
+                const unsigned long long* fl = pl.arrive + ((long)ch_tile_r * (pl.split - 1) + (lane < pl.split - 1 ? lane : 0)) * 8 + wave;
                 unsigned spins = 0;
                 for (;;) {
-                    const unsigned got = __hip_atomic_load(pl.arrive + ch_tile_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__builtin_amdgcn_readfirstlane(got) >= want) break;
+                    const unsigned long long got = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__ballot(got != want) == 0) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > pl.spin) {
                         if (lane == 0 && pl.herr) __hip_atomic_store(pl.herr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -403,7 +408,9 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
         // fence here would write back every dirty line of the XCD's L2 -- megabytes of output tiles -- once per wave (measured: the
         // split round then cost more than a whole tile)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(pl.arrive + ch_tile_r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+            __hip_atomic_store(pl.arrive + ((long)ch_tile_r * (pl.split - 1) + (ch_s - 1)) * 8 + wave,
+                               ((unsigned long long)(~pl.tag) << 32) | pl.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // barrier balance: 1 + 8 * total_kt + my_count per wave (group 1: prologue shift + (my_count - 1) re-shifts; group 0: my_count re-alignments)
 #undef P8_MMA
@@ -414,7 +421,8 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
 
 namespace mi355 {
 
-// Workspace of the split last round: partial accumulators of the K-chunks s > 0 of the left-over tiles + one arrival word per tile.
+// Workspace of the split last round: partial accumulators of the K-chunks s > 0 of the left-over tiles + one 8-byte flag per
+// publishing wave.
 static void p8_plan(int M, int N, int K, int ncu, P8Plan& pl, int& grid, size_t& part_bytes, size_t& arrive_bytes) {
     pl.tiles_m = cdiv(M, 256); pl.tiles_n = cdiv(N, 256);
     const long ntiles = (long)pl.tiles_m * pl.tiles_n;
@@ -431,7 +439,7 @@ static void p8_plan(int M, int N, int K, int ncu, P8Plan& pl, int& grid, size_t&
     pl.split = S;
     if (pl.full == 0) grid = pl.left * S;                      // fewer tiles than CUs: only the chunk units exist
     part_bytes = (size_t)pl.left * (S - 1) * 8 * 8192 * sizeof(float);
-    arrive_bytes = ((size_t)pl.left * sizeof(unsigned) + 255) & ~(size_t)255;
+    arrive_bytes = ((size_t)pl.left * (S - 1) * 8 * sizeof(unsigned long long) + 255) & ~(size_t)255;
 }
 
 size_t gemm16_p8_workspace_bytes(int M, int N, int K) {
@@ -461,10 +469,10 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
     pl.spin = spin_limit();
     if (pl.split > 1) {
         if (int rc = sync_pending("gemm16_p8")) return rc;
-        pl.arrive = static_cast<unsigned*>(ws);
+        pl.arrive = static_cast<unsigned long long*>(ws);
         pl.part = reinterpret_cast<float*>(static_cast<char*>(ws) + ab);
-        hipError_t e = hipMemsetAsync(pl.arrive, 0, (size_t)pl.left * sizeof(unsigned), st);
-        if (e != hipSuccess) return fail(MI355_EHIP, "gemm16_p8: memset -> %s", hipGetErrorString(e));
+        static std::atomic<unsigned> launch_tag{0x5EED0000u};
+        do pl.tag = launch_tag.fetch_add(1u, std::memory_order_relaxed) + 1u; while (pl.tag == 0u);
     }
     if (precision == MI355_PREC_FP16) {
         if (out16) gemm16_p8_kernel<_Float16, true><<<grid, 512, 0, st>>>(g, pl);
