@@ -258,3 +258,22 @@ def test_patch_embed_on_the_16bit_engine(B, HW, ps, E, prec, tol):
     ref = torch.cat([ref, cls.cpu().double().expand(len(pick), 1, E)], dim=1) + pos.cpu().double()
     assert_parity(tok[pick].cpu(), ref.float(), tol, "patch_embed on the 16-bit engine")
     assert_parity(tok[:, P].cpu(), (cls + pos[P]).cpu().expand(B, E), 1e-6, "cls rows")
+
+
+def test_double_attention_two_pass_nan_poisons_one_image_only():
+    """One NaN pixel in image 1: softmax over H*W of every B row of that image is NaN in the reference, hence G and the whole output
+    of image 1; the other images must not notice (bit-identical to the clean run)."""
+    from mi355attn import functional as F
+    from mi355attn.modules import DoubleAttention
+    torch.manual_seed(77)
+    m = DoubleAttention(256, 128, 128).eval()
+    sd = {k: v.detach().clone().cuda() for k, v in m.state_dict().items()}
+    keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight", "proj.bias")
+    x = torch.randn(3, 256, 20, 20, device="cuda")
+    clean = F.double_attention_forward(x, *[sd[k] for k in keys], precision=1)
+    x[1, 17, 3, 5] = float("nan")
+    y = F.double_attention_forward(x, *[sd[k] for k in keys], precision=1)
+    ref = O.double_attention_forward(x.cpu(), *[sd[k].cpu() for k in keys])
+    assert torch.isnan(ref[1]).all() and torch.isfinite(ref[0]).all()
+    assert torch.isnan(y[1]).all(), "image with a NaN pixel must be NaN everywhere, as in the reference"
+    assert torch.equal(y[0], clean[0]) and torch.equal(y[2], clean[2])
