@@ -385,6 +385,9 @@ int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float
  *   per head: L2-normalise q,k over N; A = softmax((q^ k^T) * temp_h) (d x d); out = (A v)^T. */
 int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B, int N, int heads, int d,
                   int precision, mi355_stream_t stream);
+/* The same core with out in the 16-bit operand format of `precision` (1 / 2), ready for the proj GEMM (no cast pass over ctx). */
+int mi355_xca16_fwd(const float* qkv, const float* temperature, void* out16, int B, int N, int heads, int d,
+                    int precision, mi355_stream_t stream);
 
 /* XCiT LPI.forward (xcit.py:149-157) with BatchNorm2d in eval mode (running statistics):
  *   tokens (B,N=H*W,C) -> dw3x3(w1,b1) -> GELU -> (v - bn_mean)/sqrt(bn_var + bn_eps)*bn_w + bn_b -> dw3x3(w2,b2) -> tokens.

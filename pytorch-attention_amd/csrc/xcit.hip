@@ -22,9 +22,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int XCA_TC = 64;      // tokens per chunk
 
-template <int D>
+// OT: output element type (float, or the 16-bit operand type of the proj GEMM that follows: saves the cast pass over ctx)
+template <int D, typename OT = float>
 __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv, const float* __restrict__ temperature,
-                                                 float* __restrict__ out, int N, int heads) {
+                                                 OT* __restrict__ out, int N, int heads) {
     constexpr int P = D + 1;                 // LDS pitch (floats): odd -> conflict-free column walks
     constexpr int DT = D / 16, D4 = D / 4;
     constexpr int NLD = (XCA_TC * D4 + 255) / 256;          // float4 loads per thread per array per chunk
@@ -155,7 +156,10 @@ __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv,
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
             const int n = ch * XCA_TC + nt * 16 + l15;
-            if (n < N) *reinterpret_cast<f4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = acc;
+            if (n < N) {
+                typedef OT o4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<o4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = o4{(OT)acc.x, (OT)acc.y, (OT)acc.z, (OT)acc.w};
+            }
         }
         __syncthreads();
     }
@@ -259,6 +263,31 @@ int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B,
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
+// The same core with the context written in the 16-bit operand format of `precision` (1 = fp16, 2 = bf16): what the proj GEMM of the
+// 16-bit dataflow reads (xcit.py:248-249), without a separate cast pass.
+int mi355_xca16_fwd(const float* qkv, const float* temperature, void* out16, int B, int N, int heads, int d, int precision,
+                    mi355_stream_t stream) {
+    MI355_CHECK_ARG(qkv && temperature && out16 && B > 0 && N > 0 && heads > 0);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    MI355_CHECK_ARG(aligned16(qkv) && aligned16(out16));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = B * heads;
+#define XCA16(D_)                                                                                                              \
+    do {                                                                                                                       \
+        if (precision == MI355_PREC_FP16) xca_kernel<D_, _Float16><<<grid, 256, 0, st>>>(qkv, temperature, static_cast<_Float16*>(out16), N, heads); \
+        else                              xca_kernel<D_, __bf16><<<grid, 256, 0, st>>>(qkv, temperature, static_cast<__bf16*>(out16), N, heads);     \
+    } while (0)
+    switch (d) {
+        case 32: XCA16(32); break;
+        case 48: XCA16(48); break;
+        case 64: XCA16(64); break;
+        default: return mi355::fail(MI355_EUNSUPPORTED, "mi355_xca16_fwd: head dim %d (built: 32, 48, 64)", d);
+    }
+#undef XCA16
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
 
 size_t mi355_lpi_workspace_bytes(int, int, int, int) { return 16; }   // fully fused: no scratch needed
 

@@ -678,11 +678,17 @@ def cswin_lepe_attention(qkv, getv_w, getv_b, out, reso, c0, Cb, heads, Hsp, Wsp
     return out
 
 
-def xca_core(qkv, temperature, num_heads, precision=None):
+def xca_core(qkv, temperature, num_heads, precision=None, out16=False):
+    """`out16`: the context in the 16-bit operand format of `precision` (what linear16 reads) instead of fp32."""
     qkv = require_device_f32(qkv, "qkv")
     temperature = require_device_f32(temperature, "temperature").reshape(-1)
     B, N, C3 = qkv.shape
     C = C3 // 3
+    if out16:
+        out = torch.empty(B, N, C, dtype=dtype16(precision), device=qkv.device)
+        check(lib().mi355_xca16_fwd(dptr(qkv), dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
+                                    _prec(precision), stream_ptr(qkv.device)), "mi355_xca16_fwd")
+        return out
     out = torch.empty(B, N, C, dtype=torch.float32, device=qkv.device)
     check(lib().mi355_xca_fwd(dptr(qkv), dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
                               _prec(precision), stream_ptr(qkv.device)), "mi355_xca_fwd")
