@@ -385,8 +385,9 @@ int mi355_cswin_lepe_attn_fwd(const float* qkv, const float* getv_w, const float
  *   per head: L2-normalise q,k over N; A = softmax((q^ k^T) * temp_h) (d x d); out = (A v)^T. */
 int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B, int N, int heads, int d,
                   int precision, mi355_stream_t stream);
-/* The same core with out in the 16-bit operand format of `precision` (1 / 2), ready for the proj GEMM (no cast pass over ctx). */
-int mi355_xca16_fwd(const float* qkv, const float* temperature, void* out16, int B, int N, int heads, int d,
+/* The same core with out in the 16-bit operand format of `precision` (1 / 2), ready for the proj GEMM (no cast pass over ctx);
+ * qkv_is16 != 0: qkv is in that format too (16-bit output of the qkv GEMM).  Arithmetic is fp32 in every case. */
+int mi355_xca16_fwd(const void* qkv, int qkv_is16, const float* temperature, void* out16, int B, int N, int heads, int d,
                     int precision, mi355_stream_t stream);
 
 /* XCiT LPI.forward (xcit.py:149-157) with BatchNorm2d in eval mode (running statistics):

@@ -22,9 +22,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int XCA_TC = 64;      // tokens per chunk
 
-// OT: output element type (float, or the 16-bit operand type of the proj GEMM that follows: saves the cast pass over ctx)
-template <int D, typename OT = float>
-__global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv, const float* __restrict__ temperature,
+// OT: output element type (float, or the 16-bit operand type of the proj GEMM that follows: saves the cast pass over ctx);
+// IT: element type of qkv (float, or the 16-bit output of the qkv GEMM: halves the 3C-wide tensor the core streams twice).
+// The arithmetic is fp32 (exact-fp32 MFMA) either way.
+template <int D, typename OT = float, typename IT = float>
+__global__ __launch_bounds__(256) void xca_kernel(const IT* __restrict__ qkv, const float* __restrict__ temperature,
                                                  OT* __restrict__ out, int N, int heads) {
     constexpr int P = D + 1;                 // LDS pitch (floats): odd -> conflict-free column walks
     constexpr int DT = D / 16, D4 = D / 4;
@@ -38,7 +40,9 @@ __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv,
     const int h = lid % heads, b = lid / heads;
     const int C = heads * D;
     const long row3 = 3L * C;
-    const float* base = qkv + (long)b * N * row3 + h * D;
+    const IT* base = qkv + (long)b * N * row3 + h * D;
+    typedef IT i4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [&](const IT* p) { const i4 v = *reinterpret_cast<const i4*>(p); return f4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; };
     const int nchunks = (N + XCA_TC - 1) / XCA_TC;
 
     // which G tiles this wave accumulates (DT*DT tiles round-robin over the 4 waves, at most 4 each for D = 64)
@@ -57,8 +61,8 @@ __global__ __launch_bounds__(256) void xca_kernel(const float* __restrict__ qkv,
             ra[it] = f4{0.f, 0.f, 0.f, 0.f};
             rb[it] = f4{0.f, 0.f, 0.f, 0.f};
             if (idx < XCA_TC * D4 && n < N) {
-                ra[it] = *reinterpret_cast<const f4*>(base + (long)n * row3 + which_a * C + d4 * 4);
-                if (two) rb[it] = *reinterpret_cast<const f4*>(base + (long)n * row3 + which_b * C + d4 * 4);
+                ra[it] = ld4(base + (long)n * row3 + which_a * C + d4 * 4);
+                if (two) rb[it] = ld4(base + (long)n * row3 + which_b * C + d4 * 4);
             }
         }
 #pragma unroll
@@ -264,8 +268,9 @@ int mi355_xca_fwd(const float* qkv, const float* temperature, float* out, int B,
     return MI355_OK;
 }
 // The same core with the context written in the 16-bit operand format of `precision` (1 = fp16, 2 = bf16): what the proj GEMM of the
-// 16-bit dataflow reads (xcit.py:248-249), without a separate cast pass.
-int mi355_xca16_fwd(const float* qkv, const float* temperature, void* out16, int B, int N, int heads, int d, int precision,
+// 16-bit dataflow reads (xcit.py:248-249), without a separate cast pass; qkv_is16 != 0: qkv itself is in that format (the 16-bit
+// output of the qkv GEMM).
+int mi355_xca16_fwd(const void* qkv, int qkv_is16, const float* temperature, void* out16, int B, int N, int heads, int d, int precision,
                     mi355_stream_t stream) {
     MI355_CHECK_ARG(qkv && temperature && out16 && B > 0 && N > 0 && heads > 0);
     MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
@@ -274,8 +279,11 @@ int mi355_xca16_fwd(const float* qkv, const float* temperature, void* out16, int
     const int grid = B * heads;
 #define XCA16(D_)                                                                                                              \
     do {                                                                                                                       \
-        if (precision == MI355_PREC_FP16) xca_kernel<D_, _Float16><<<grid, 256, 0, st>>>(qkv, temperature, static_cast<_Float16*>(out16), N, heads); \
-        else                              xca_kernel<D_, __bf16><<<grid, 256, 0, st>>>(qkv, temperature, static_cast<__bf16*>(out16), N, heads);     \
+        if (qkv_is16) {                                                                                                        \
+            if (precision == MI355_PREC_FP16) xca_kernel<D_, _Float16, _Float16><<<grid, 256, 0, st>>>(static_cast<const _Float16*>(qkv), temperature, static_cast<_Float16*>(out16), N, heads); \
+            else                              xca_kernel<D_, __bf16, __bf16><<<grid, 256, 0, st>>>(static_cast<const __bf16*>(qkv), temperature, static_cast<__bf16*>(out16), N, heads);         \
+        } else if (precision == MI355_PREC_FP16) xca_kernel<D_, _Float16><<<grid, 256, 0, st>>>(static_cast<const float*>(qkv), temperature, static_cast<_Float16*>(out16), N, heads); \
+        else                              xca_kernel<D_, __bf16><<<grid, 256, 0, st>>>(static_cast<const float*>(qkv), temperature, static_cast<__bf16*>(out16), N, heads);     \
     } while (0)
     switch (d) {
         case 32: XCA16(32); break;

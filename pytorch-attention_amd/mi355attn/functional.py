@@ -679,16 +679,22 @@ def cswin_lepe_attention(qkv, getv_w, getv_b, out, reso, c0, Cb, heads, Hsp, Wsp
 
 
 def xca_core(qkv, temperature, num_heads, precision=None, out16=False):
-    """`out16`: the context in the 16-bit operand format of `precision` (what linear16 reads) instead of fp32."""
-    qkv = require_device_f32(qkv, "qkv")
+    """`out16`: the context in the 16-bit operand format of `precision` (what linear16 reads) instead of fp32; qkv may then be in that
+    format as well (the 16-bit output of the qkv GEMM)."""
     temperature = require_device_f32(temperature, "temperature").reshape(-1)
     B, N, C3 = qkv.shape
     C = C3 // 3
     if out16:
+        is16 = qkv.dtype == dtype16(precision)
+        if not is16:
+            qkv = require_device_f32(qkv, "qkv")
+        elif not (qkv.is_cuda and qkv.is_contiguous()):
+            raise ValueError("xca_core: 16-bit qkv must be a contiguous device tensor")
         out = torch.empty(B, N, C, dtype=dtype16(precision), device=qkv.device)
-        check(lib().mi355_xca16_fwd(dptr(qkv), dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
+        check(lib().mi355_xca16_fwd(dptr(qkv), 1 if is16 else 0, dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
                                     _prec(precision), stream_ptr(qkv.device)), "mi355_xca16_fwd")
         return out
+    qkv = require_device_f32(qkv, "qkv")
     out = torch.empty(B, N, C, dtype=torch.float32, device=qkv.device)
     check(lib().mi355_xca_fwd(dptr(qkv), dptr(temperature), dptr(out), B, N, num_heads, C // num_heads,
                               _prec(precision), stream_ptr(qkv.device)), "mi355_xca_fwd")

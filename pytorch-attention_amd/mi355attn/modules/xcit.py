@@ -67,10 +67,10 @@ class XCA(nn.Module):
         if _fast(self.precision, self.qkv, self.proj):
             p = F._prec(self.precision)      # GEMMs on 16-bit operands; the d x d covariance core itself is exact fp32
             if ln is not None:
-                qkv = F.ln_linear16(x, ln, self.qkv, out16=False, precision=p)
+                qkv = F.ln_linear16(x, ln, self.qkv, out16=True, precision=p)
             else:
                 x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
-                qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, precision=p)
+                qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
             ctx16 = F.xca_core(qkv, self.temperature, self.num_heads, precision=p, out16=True)
             return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid, precision=p)
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias, precision=self.precision)
