@@ -75,11 +75,17 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   Under hipGraph stream capture the granule-exchange kernels are not used at all (a recorded launch replays with the
  *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
  *                   kernels instead, so captured graphs are replay-safe by construction.
- *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status.
+ *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status:
+ *                   1024 .. 2^30 (default 2^22 ~ a second); 0 is accepted to force the time-out path in tests (every exchange then
+ *                   fails on its first unsuccessful poll).
  *   "gemm_splitk"   1 (default) = mi355_linear16_ws_fwd may cut the tiles of the persistent kernel's last partial round along K
  *                   (K >= 1536 only); the fp32 summation order of those tiles then differs from the unsplit order, so a row's
  *                   result can depend (at rounding level) on where its tile falls in the launch; 0 = never split: every output row
- *                   is bit-identical whatever the batch around it.
+ *                   is bit-identical whatever the batch around it.  Never split under hipGraph stream capture (a recorded launch
+ *                   replays its per-launch flag tag).
+ *   "gemm_pa"       1 (default) = fp32 (+ residual) outputs with M % 128 == 0, N % 256 == 0, K >= 640 run the two-accumulator
+ *                   persistent kernel (the epilogue of tile i rides in the main loop of tile i + 1; no inter-workgroup exchange, so it
+ *                   is capture-safe and every row is bit-identical whatever the batch); 0 = never.
  *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
  * Unknown key -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);

@@ -21,8 +21,10 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "mi355attn", "lib")
 LIB = os.path.join(LIBDIR, "libmi355attn.so")
 ARCH = "gfx950"
+# -Werror=inline-asm / -Werror=pass-failed: an asm statement the compiler objects to (e.g. a reserved register on a clobber list) or a
+# launch-bounds occupancy hint it cannot meet stops the build instead of scrolling by.
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-            "-ffp-contract=off"]
+            "-ffp-contract=off", "-Werror=inline-asm", "-Werror=pass-failed"]
 # Per-file additions.  -fno-honor-nans on the single-read CBAM kernel: its running maxima compile to v_max_f32 preceded by a
 # canonicalising v_max x, x, x per operand (IEEE maxnum must quiet signalling NaNs) and the DPP permutations cannot be folded into
 # them -- 190 of the kernel's 1880 VALU instructions per band, in a kernel whose bands spend 40 % of their SIMD time on VALU work.

@@ -19,6 +19,7 @@ static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace cont
 static std::atomic<long> g_stem_direct{1};  // narrow conv stems: direct fp32 kernel (stem_conv.hip) vs implicit GEMM
 static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
 static std::atomic<long> g_spin_limit{1L << 22};   // poll budget of the exchange kernels (sweeps) before they give up with an error code
+static std::atomic<long> g_gemm_pa{1};       // fp32-output GEMMs: two-accumulator persistent kernel where it applies (gemm16_pa.hip)
 static std::atomic<long> g_gemm_splitk{1};   // persistent GEMM: cut the tiles of the last partial round along K (gemm16_p8.hip)
 std::atomic<long> g_da_fused{1};       // DoubleAttention: two-pass kernels where they apply (double_attn_fused.hip)
 std::atomic<long> g_da_ranges{0};      // ... pixel ranges per image in pass 1: 0 = from the batch size, 1..32 = fixed
@@ -126,14 +127,30 @@ unsigned spin_limit() { return (unsigned)g_spin_limit.load(std::memory_order_rel
 int sync_pending(const char* who) {
     unsigned* w = sync_err_word();
     if (!w) return MI355_OK;
-    const unsigned code = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (!__atomic_load_n(w, __ATOMIC_ACQUIRE)) return MI355_OK;
+    const unsigned code = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);       // read AND clear: a code stored in between is not lost
     if (!code) return MI355_OK;
-    __atomic_store_n(w, 0u, __ATOMIC_RELEASE);
     static const char* const names[] = {"?", "SE (se_single_kernel)", "CBAM (cbam_single_kernel)", "channel-statistics gate (stat_single_kernel)",
                                         "the persistent GEMM's split last round (gemm16_p8_kernel)"};
     return fail(MI355_ESYNC, "%s: an inter-workgroup exchange of an EARLIER launch of %s ran out of its poll budget (%u sweeps): that launch's "
                 "output is invalid.  Typical cause: fewer workgroups resident than one image needs (partitioned / masked device)",
                 who, names[code < 5 ? code : 0], spin_limit());
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remember (kernel, device ordinal) pairs, not a
+// per-process flag -- a second GPU driven from the same process would otherwise launch with the default dynamic-LDS limit and fail.
+int func_dynamic_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned long long> done;      // kernel -> bit mask of device ordinals (< 64)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned long long& m = done[fn];
+    if (m & bit) return MI355_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(MI355_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) -> %s", bytes, hipGetErrorString(e));
+    m |= bit;
+    return MI355_OK;
 }
 int resident_slots(int per_cu) {
     int dev = 0, ncu = 256;
@@ -147,6 +164,7 @@ long opt_stem_direct() { return g_stem_direct.load(std::memory_order_relaxed); }
 long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
 long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 long opt_gemm_splitk() { return g_gemm_splitk.load(std::memory_order_relaxed); }
+long opt_gemm_pa() { return g_gemm_pa.load(std::memory_order_relaxed); }
 long opt_da_fused() { return g_da_fused.load(std::memory_order_relaxed); }
 long opt_da_ranges() { return g_da_ranges.load(std::memory_order_relaxed); }
 }  // namespace mi355
@@ -208,13 +226,20 @@ int mi355_set_option(const char* key, long value) {
         return MI355_OK;
     }
     if (std::strcmp(key, "spin_limit") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= (1L << 30));
+        // 0 is accepted for ONE purpose: forcing the time-out path in tests (every exchange then fails on its first unsuccessful poll);
+        // real budgets start at 1024 sweeps
+        MI355_CHECK_ARG(value == 0 || (value >= 1024 && value <= (1L << 30)));
         mi355::g_spin_limit.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
     if (std::strcmp(key, "gemm_splitk") == 0) {
         MI355_CHECK_ARG(value == 0 || value == 1);
         mi355::g_gemm_splitk.store(value, std::memory_order_relaxed);
+        return MI355_OK;
+    }
+    if (std::strcmp(key, "gemm_pa") == 0) {
+        MI355_CHECK_ARG(value == 0 || value == 1);
+        mi355::g_gemm_pa.store(value, std::memory_order_relaxed);
         return MI355_OK;
     }
     if (std::strcmp(key, "da_fused") == 0) {
@@ -255,6 +280,7 @@ long mi355_get_option(const char* key) {
     if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
     if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
     if (key && std::strcmp(key, "gemm_splitk") == 0) return mi355::opt_gemm_splitk();
+    if (key && std::strcmp(key, "gemm_pa") == 0) return mi355::opt_gemm_pa();
     if (key && std::strcmp(key, "da_fused") == 0) return mi355::opt_da_fused();
     if (key && std::strcmp(key, "da_ranges") == 0) return mi355::opt_da_ranges();
     if (key && std::strcmp(key, "spin_limit") == 0) return (long)mi355::spin_limit();

@@ -18,6 +18,7 @@ long  opt_nt();
 long  opt_reverse();
 long  opt_gemm_variant();
 long  opt_gemm_splitk();
+long  opt_gemm_pa();
 long  opt_da_fused();
 long  opt_da_ranges();
 long  opt_eca_single();
@@ -39,6 +40,7 @@ unsigned* sync_err_word();            // device-visible pinned host word (null i
 unsigned  spin_limit();
 int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
 int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
+int   func_dynamic_lds(const void* fn, int bytes);   // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): api.hip
 long  opt_zoo_single();
 long  opt_stem_direct();
 bool  stem_conv_applicable(int Cin, int Cout, int KH, int KW, int in_layout, const float* bias, const float* pos, const float* y);

@@ -45,8 +45,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // LDS-DMA is in flight and -- having no alias scopes for most LDS accesses -- puts `s_waitcnt vmcnt(0)` in front of some later,
 // unrelated ds_read / ds_write (which one changed with every edit of pass 1): that wait drains the whole prefetch ring once per
 // tile.  Pass 1 counts its own DMAs (vmcnt(N) before the barrier that publishes a tile), so the compiler does not need to know.
+// m0 (the LDS-DMA destination base) belongs to the compiler: it is saved and restored INSIDE the statement instead of being named
+// as a clobber (hipcc does not honour an "m0" clobber: "clobber list contains reserved registers"; cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void lds_dma16(const void* src, const void* dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr(dst))) : "memory", "m0");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr(dst)))
+                 : "memory");
 }
 
 struct DaArgs {

@@ -35,5 +35,6 @@ __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin
 namespace mi355 {
 int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);     // gemm16_p8.hip
 size_t gemm16_p8_workspace_bytes(int M, int N, int K);
+int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl = 0);                                 // gemm16_pa.hip
 int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }

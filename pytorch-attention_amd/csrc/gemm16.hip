@@ -643,6 +643,13 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
+    if (variant >= 16 && variant <= 21) {  // two-accumulator persistent 128 x 256 kernel (gemm16_pa.hip); 17..21: timing ablations
+        const int rc = mi355::gemm16_pa(g, out16, precision, st, (int)variant - 16);
+        if (rc == MI355_EUNSUPPORTED) return mi355::fail(rc, "mi355_linear16_fwd: the two-accumulator kernel does not take this shape");
+        if (rc != MI355_OK) return rc;
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     if (variant == 0 && (K == 64 || K == 128) && M >= 2048 && (!out16 || (N & 7) == 0)) {       // short-K, HBM-bound: weight-stationary streaming kernel
         int ncu = 256, dev = 0;
         (void)hipGetDevice(&dev);
@@ -667,14 +674,27 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
+    if (variant == 0 && !out16 && (g.resid || N <= 768) && mi355::opt_gemm_pa()) {
+        // fp32 (+ residual) outputs: the two-accumulator persistent kernel (gemm16_pa.hip) hides the residual / store round trips of
+        // tile i under the main loop of tile i + 1 (ViT-Base proj 0.130 -> 0.106 ms, fc2 0.266 -> 0.259; profiles/r03_gemm_pa.md).
+        // No inter-workgroup exchange: safe under hipGraph capture, and a row's bits never depend on where its tile falls.
+        const int ncu = mi355::resident_slots(1);
+        if ((long)cdiv(M, 128) * (N / 256) >= ncu) {
+            const int rc = mi355::gemm16_pa(g, out16, precision, st);
+            if (rc == MI355_OK) {
+                MI355_LAUNCH_CHECK();
+                return MI355_OK;
+            }
+            if (rc != MI355_EUNSUPPORTED) return rc;
+        }
+    }
     if (variant == 0 && (N & 7) == 0 && !(out16 && g.resid)) {
-        // Persistent 256 x 256 kernel (gemm16_p8.hip) where its one-workgroup-per-CU rounds fill the chip: 16-bit outputs (light
-        // epilogue) when the last round is >= 85 % full, fp32 + residual outputs only for long K (the epilogue of a lone workgroup
-        // is exposed, the 3-workgroups-per-CU kernel below hides it behind its neighbours).  profiles/r02_gemm_p8.md
+        // Persistent 256 x 256 kernel (gemm16_p8.hip) for every shape with at least one full round of tiles (one workgroup per CU)
+        // and K >= 256: it is >= the best 3-workgroups-per-CU variant on all 17 shapes of profiles/r02_gemm_p8.md except CSWin s3 fc1
+        // (inside the run-to-run band), shapes just above a round boundary included (the last partial round costs a whole tile time
+        // either way; long reductions cut it along K).
         const int ncu = mi355::resident_slots(1);
         const long ntiles = (long)cdiv(M, 256) * cdiv(N, 256);
-        const long rounds = (ntiles + ncu - 1) / ncu;
-        (void)rounds;
         if (ntiles >= ncu && K >= 256) {
             const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
             if (rc == MI355_OK) {

@@ -273,6 +273,12 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                         break;
                     }
                 }
+                // Ordering relied upon (MI355X_MICROARCH.md "Valid forms": sc1 stores AND sc1 loads on both sides + a drained queue in
+                // front of the flag): the producer's slab stores are write-through and complete (vmcnt(0)) before its flag store is
+                // issued; the slab loads below bypass this CU's L1 (sc1), so once the flag is seen they read what the producer wrote.
+                // The barrier keeps the COMPILER from hoisting the buffer loads above the poll loop (relaxed atomics do not order them).
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 for (int s = 0; s < pl.split - 1; ++s) {                    // sc1 loads: served below this CU's L1, coherent with the sc1 stores
                     const float* slab = pl.part + (((long)ch_tile_r * (pl.split - 1) + s) * 8 + wave) * 8192;
                     const rsrc_t rs = make_rsrc(slab, 32768u);
@@ -461,11 +467,17 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
     int grid;
     size_t pb, ab;
     p8_plan(g.M, g.N, g.K, resident_slots(1), pl, grid, pb, ab);
-    if (pl.split > 1 && (ws == nullptr || ws_bytes < pb + ab || !aligned16(ws))) {      // no workspace: whole left-over tiles
+    // The split round synchronises workgroups through flags that carry a per-launch tag from a host-side counter.  A launch recorded
+    // by hipGraph capture replays with the SAME arguments -- the same tag -- so on the second replay the flags of the first already
+    // match and chunk 0 would add stale or half-written slabs: under capture the left-over tiles run whole (as the exchange kernels
+    // of the channel-attention family step aside, api.hip stream_is_capturing).  The pinned error word is not allocated there either
+    // (hipHostMalloc is illegal during capture; without a split nothing reports through it).
+    const bool capturing = stream_is_capturing(st);
+    if (pl.split > 1 && (capturing || ws == nullptr || ws_bytes < pb + ab || !aligned16(ws))) {      // no workspace: whole left-over tiles
         pl.split = 1;
         if (pl.full == 0) grid = pl.left;
     }
-    pl.herr = sync_err_word();
+    pl.herr = capturing ? nullptr : sync_err_word();
     pl.spin = spin_limit();
     if (pl.split > 1) {
         if (int rc = sync_pending("gemm16_p8")) return rc;

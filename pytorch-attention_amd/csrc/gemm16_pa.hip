@@ -1,0 +1,511 @@
+// gemm16_pa.hip -- persistent 128 x 256 x 64 GEMM on the 16-bit engine with TWO accumulator sets: the epilogue of output tile i
+// (bias / GELU / residual, stores) is cut into pieces that ride in the MFMA intervals of tile i + 1's main loop, so the matrix pipe
+// never waits for an epilogue (gemm16_p8.hip exposes 5-20 us per tile: the GELU of fc1, the fp32 + residual round trips of proj / fc2).
+//
+//   Y (M x N) = resid + act( X16 (M x K) . W16^T (N x K) + bias )           same K order per output as gemm16.hip / gemm16_p8.hip:
+//                                                                            bit-identical results
+//
+// Geometry: ONE workgroup of 8 waves per CU, waves 2 (M) x 4 (N), 64 x 64 outputs each = 4 x 4 MFMA 16x16x32 tiles = 64 accumulator
+//   registers per set; set P receives tile i while set 1-P (tile i-1) drains.
+//   LDS 160 KB = 3 K-tile buffers x 3 slots of 16 KB (128 rows x 128 B, source-side XOR swizzle as in gemm16.hip) + 8 wave-private 2 KB
+//   slabs for the epilogue's layout change:  slot A = rows [0,64) of row group 0 | rows [0,64) of row group 1, slots B0 / B1 = columns
+//   [0,32) / [32,64) of the four column groups.
+//   K-tile = two phases, phase = [ds_read fragments + LDS-DMA issue] s_barrier [16 MFMAs (+ a piece of the previous tile's epilogue)]
+//   s_barrier; the two waves of a SIMD (row groups 0 / 1) run this program shifted by one barrier interval, so one of them feeds the
+//   matrix pipe while the other reads LDS and issues DMA (as in gemm16_p8.hip).
+//   phase 0: reads A (8 x b128) + B0 (4), DMA A of K-tile T+2;  phase 1: reads B1 (4), DMA B0 + B1 of K-tile T+2, then ONE counted
+//   wait: everything up to K-tile T+1 has landed.  K-tile T+2 goes to buffer (T+2) % 3 = the buffer of K-tile T-1, whose last reads
+//   (any wave, either row group) are >= 4 barrier intervals old when the first DMA into it is issued; K-tile T+1 is first read one
+//   full phase (two barriers) after the counted wait of every wave that staged a piece of it.
+// The vector-memory queue is counted BY HAND: every LDS-DMA, every bias / residual load of the epilogue pieces is issued from inline
+//   assembly (hipcc neither waits for them nor drains the queue in front of an unrelated LDS access: cdna_hip_programming.md 5.7), the
+//   stores go through the buffer-store builtin (hipcc never waits for a store here).  Queue order = program order; loads, stores and
+//   LDS-DMA retire in order on gfx9, so `s_waitcnt vmcnt(N)` with N = the number of operations issued AFTER the one needed is exact.
+//   An epilogue piece issues e0 vector-memory operations in its phase-0 MFMA interval and e1 in its phase-1 interval, hence the
+//   K-tile's wait is vmcnt(6 + e1(previous K-tile) + e0): those, A(T+2) x 2 and B0 / B1(T+2) x 4 may still fly.
+// Epilogue pieces (previous tile, its coordinates pm0 / pn0), K-tile E of the next tile's main loop:
+//   fp32 + residual output, unit u = (column half jh = u / 4, row tile i = u % 4), 16 rows x 32 columns = the 2 KB slab; a unit's
+//   residual is loaded TWO K-tiles before it is consumed (two register sets; with one K-tile of lead every K-tile waited for HBM):
+//     K-tile E    phase 0: F(E-2) wait for its residual, slab -> row lines + residual, 2 stores; E = 0 / 5: 2 bias loads (the bias of a
+//                          column half serves 4 units)
+//                 phase 1: E = 0 / 5: wait for the bias; C(E-1) bias (+ GELU) on 2 accumulator tiles -> slab (accumulator layout);
+//                          L(E) 2 residual loads into the set F(E-2) freed -- issued BEHIND this K-tile's B DMAs: a wave's loads and
+//                          DMAs retire in order, so an HBM-latency load in front of a DMA makes the next K-tile's counted wait an
+//                          HBM-latency wait (measured: 1.8 us per K-tile with the loads in phase 0); behind them it has 1.75 K-tiles
+//     K-tiles 8, 9: F(6), C(7), F(7)
+//   16-bit output, piece p = (row tile i = p / 2, column pair jp = p % 2), unit = row tile (16 rows x 64 columns x 2 B = the slab):
+//     K-tile p    phase 0: p == 0: the 4 bias loads of the tile; C1(p-1) second column tile of the previous piece -> slab; F(i-1) when
+//                          p is even (2 stores)
+//                 phase 1: p == 0: wait for the bias; C0(p) first column tile -> slab
+//     K-tile 8    phase 0: C1(7); F(3)
+//   so a tile needs nk >= 10 K-tiles (K >= 640); the last tile of a workgroup drains serially.  bias == null / resid == null are
+//   descriptors with zero records (the loads return 0): no branch inside an MFMA interval, the counts stay static.
+#include "gemm16.h"
+#include "bufops.h"
+
+namespace {
+using namespace g16;
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct IC { static constexpr int value = N; };
+
+struct PaPlan {
+    int tiles_n;
+    int full;      // whole rounds: every workgroup walks `full` tiles ...
+    int left;      // ... and workgroups 0 .. left-1 one more
+};
+
+__device__ __forceinline__ unsigned pa_lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)p;
+}
+// two 1 KB LDS-DMAs (16 B per lane, lane-linear at the wave-uniform LDS byte addresses d0 / d1) from the wave-uniform bases b0 / b1
+// + ONE 32-bit lane offset (scalar-base form: no per-lane 64-bit address arithmetic, one VGPR of address state per operand); m0 is
+// saved and restored inside the statement (the compiler owns m0 and does not expect an asm to change it: cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void pa_dma2(const void* b0, const void* b1, unsigned off, unsigned d0, unsigned d1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(b0), "s"(b1), "s"(d0), "s"(d1)
+                 : "memory");
+}
+// buffer descriptor as four plain dwords (an "s" operand of the asm loads): base, stride 0, num_records bytes, raw 32-bit format
+__device__ __forceinline__ u32x4_ pa_desc(const void* p, unsigned bytes) {
+    const unsigned long a = (unsigned long)p;
+    return u32x4_{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+template <int N>
+__device__ __forceinline__ void pa_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// counted waits that NAME the registers they protect (no use of them is scheduled above the statement)
+template <int N>
+__device__ __forceinline__ void pa_wait2(f4& a, f4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pa_wait4(f4& a, f4& b, f4& c, f4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+
+// ABL: timing-only ablation mask for tuning experiments (results are WRONG when non-zero): 1 = no LDS-DMA inside the loop, 2 = no
+// fragment reads inside the loop, 4 = no MFMAs, 8 = no barriers inside the loop.
+template <typename T, bool OUT16, bool GELU, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const PaPlan pl) {
+    using v8 = typename Vec8<T>::t;
+    using v4 = typename Vec8<T>::t4;
+    constexpr int SLOTB = 128 * BK * 2;                         // bytes per slot (16 KB)
+    constexpr int KTB = 3 * SLOTB;                              // bytes per K-tile buffer (48 KB): A | B0 | B1
+    constexpr int S_A = 0, S_B0 = SLOTB, S_B1 = 2 * SLOTB;
+    constexpr int SLABS = 3 * KTB;                              // the eight 2 KB slabs
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SLABS + 8 * 2048];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(pa_lds_addr(lds_raw));
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+    const int nk = g.K / BK;
+    const int tiles_n = pl.tiles_n;
+
+    // ---- this workgroup's tile list (n-fastest tile order; XCD x owns a contiguous range, its workgroups interleave inside it) -----
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int gq = gridDim.x >> 3, gr = gridDim.x & 7;
+    const int per_xcd = gq + (xcd < gr ? 1 : 0);
+    const int my_first = pl.full * (xcd * gq + (xcd < gr ? xcd : gr)) + slot_in_xcd;
+    const int nfull = pl.full;
+    const int my_count = nfull + ((int)blockIdx.x < pl.left ? 1 : 0);
+    if (my_count == 0) return;
+    const int total_kt = my_count * nk;
+    auto entry_tile = [&](int e) { return e < nfull ? my_first + e * per_xcd : nfull * (int)gridDim.x + (int)blockIdx.x; };
+
+    // ---- DMA sources.  One instruction = 8 rows x 128 B; lane -> (row = lane >> 3, physical chunk = lane & 7) holding logical
+    //      chunk (lane & 7) ^ row ---------------------------------------------------------------------------------------------------
+    const int lrow = lane >> 3, csw = ((lane & 7) ^ lrow) * 8;
+    // The lane part of a source address is the same for every tile (M % 128 == 0, N % 256 == 0: no clamps): row (wr*64 + wc*16 +
+    // lrow) of the tile's A rows / slot row wave*16 + lrow of its B columns, swizzled chunk csw; the second DMA of a pair is 8 rows
+    // further = a different scalar base.  The cursor itself is scalar state.
+    struct Cursor { const T* ta; const T* tb; int kt; int ent; };
+    const int rb0 = wave * 16 + lrow;
+    const unsigned la = (unsigned)((wr * 64 + wc * 16 + lrow) * g.lda + csw) * 2u;
+    const unsigned lbo = (unsigned)(((rb0 >> 5) * 64 + (rb0 & 31)) * g.ldb + csw) * 2u;
+    auto seek = [&](Cursor& c, int e) {
+        const int tile = entry_tile(e);
+        c.ta = A + (long)((tile / tiles_n) * 128) * g.lda;
+        c.tb = B + (long)((tile % tiles_n) * 256) * g.ldb;
+        c.kt = 0;
+        c.ent = e;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.kt == nk && c.ent + 1 < my_count) seek(c, c.ent + 1);      // past the end: never staged (callers test the stream index)
+    };
+    const unsigned dA = (unsigned)(S_A + (wr * 64 + wc * 16) * 128), dB = (unsigned)((wave * 16) * 128);
+    auto stage_a = [&](const Cursor& c, unsigned base) {
+        const T* s0 = c.ta + (long)c.kt * BK;
+        pa_dma2(s0, s0 + (long)8 * g.lda, la, base + dA, base + dA + 1024u);
+    };
+    auto stage_b = [&](const Cursor& c, unsigned base, int half) {
+        const unsigned d = base + (half ? S_B1 : S_B0) + dB;
+        const T* s0 = c.tb + (long)c.kt * BK + (half ? (long)32 * g.ldb : 0);
+        pa_dma2(s0, s0 + (long)8 * g.ldb, lbo, d, d + 1024u);
+    };
+
+    // ---- fragment reads ------------------------------------------------------------------------------------------------------------
+    v8 fa[4][2], fb[2][2];
+    if constexpr (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = v8{};
+        fb[0][0] = fb[0][1] = fb[1][0] = fb[1][1] = v8{};
+    }
+    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
+    const int off0 = (fq ^ fsw) * 16, off1 = ((4 + fq) ^ fsw) * 16;
+    const int ra = S_A + (wr * 64 + frow) * 128, rb = (wc * 32 + frow) * 128;
+    auto read_a = [&](const unsigned char* lb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *reinterpret_cast<const v8*>(lb + ra + i * 2048 + off0);
+            fa[i][1] = *reinterpret_cast<const v8*>(lb + ra + i * 2048 + off1);
+        }
+    };
+    auto read_b = [&](const unsigned char* lb, int half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *reinterpret_cast<const v8*>(lb + (half ? S_B1 : S_B0) + rb + j * 2048 + off0);
+            fb[j][1] = *reinterpret_cast<const v8*>(lb + (half ? S_B1 : S_B0) + rb + j * 2048 + off1);
+        }
+    };
+#define PA_BAR() do { if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier(); } while (0)
+
+    // ---- epilogue state of the tile that drains (coordinates pm0 / pn0) ------------------------------------------------------------
+    int pm0 = 0, pn0 = 0;
+    const int l15 = lane & 15, fq4 = lane >> 4, srow = lane >> 3, sch = lane & 7;
+    unsigned char* const slab = lds_raw + SLABS + wave * 2048;
+    const u32x4_ d_bias = pa_desc(g.bias, g.bias ? (unsigned)g.N * 4u : 0u);
+    const u32x4_ d_res = pa_desc(g.resid, g.resid ? (unsigned)((long)g.M * g.ldc * 4) : 0u);
+    const rsrc_t rs_c = make_rsrc(g.C, (bufops_u32)((long)g.M * g.ldc * (OUT16 ? 2 : 4)));
+    const unsigned vo_bias = (unsigned)fq4 * 16u;                                         // lane part of the bias offsets
+    const unsigned vo_row = (unsigned)(srow * g.ldc + sch * (OUT16 ? 8 : 4)) * (OUT16 ? 2u : 4u);   // lane part of the row-line offsets (C and resid)
+    f4 eb0, eb1, eb2, eb3, er0, er1, es0, es1;                                            // bias (16-bit path: all four column tiles) / two residual sets in flight
+    eb0 = eb1 = eb2 = eb3 = er0 = er1 = es0 = es1 = f4{0.f, 0.f, 0.f, 0.f};
+    const unsigned sw_w16 = (unsigned)(l15 * 128 + (((fq4 >> 1) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8);   // column tile j: ^ (j * 32)
+    const unsigned sw_w32 = (unsigned)(l15 * 128 + ((fq4 ^ (l15 & 7)) * 16));                           // column tile jj: ^ (jj * 64)
+    const unsigned sw_r = (unsigned)(srow * 128 + ((sch ^ (srow & 7)) * 16));                           // row h * 8 + srow: + h * 1024
+
+    // L (16-bit): the bias of the wave's four column tiles, once per tile
+    auto epi_load16 = [&]() {
+        const unsigned so0 = (unsigned)(pn0 + wc * 64) * 4u, so1 = so0 + 64u, so2 = so0 + 128u, so3 = so0 + 192u;
+        asm volatile("s_nop 4\n\t"
+                     "buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
+                     "buffer_load_dwordx4 %1, %4, %5, %7 offen\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5, %8 offen\n\t"
+                     "buffer_load_dwordx4 %3, %4, %5, %9 offen"
+                     : "=&v"(eb0), "=&v"(eb1), "=&v"(eb2), "=&v"(eb3)
+                     : "v"(vo_bias), "s"(d_bias), "s"(so0), "s"(so1), "s"(so2), "s"(so3)
+                     : "memory");
+    };
+    // L (fp32): residual row lines of unit (i, jh) [behind the bias of column half jh]
+    auto epi_load32_bias = [&](int jh) {
+        const unsigned so0 = (unsigned)(pn0 + wc * 64 + jh * 32) * 4u, so1 = so0 + 64u;
+        asm volatile("s_nop 4\n\t"
+                     "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3, %5 offen"
+                     : "=&v"(eb0), "=&v"(eb1)
+                     : "v"(vo_bias), "s"(d_bias), "s"(so0), "s"(so1)
+                     : "memory");
+    };
+    auto epi_load32_res = [&](int i, int jh, f4& r0, f4& r1) {
+        const unsigned sr0 = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u, sr1 = sr0 + (unsigned)(8 * g.ldc) * 4u;
+        asm volatile("s_nop 4\n\t"
+                     "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3, %5 offen"
+                     : "=&v"(r0), "=&v"(r1)
+                     : "v"(vo_row), "s"(d_res), "s"(sr0), "s"(sr1)
+                     : "memory");
+    };
+    auto act4 = [&](f4 v) {
+        if constexpr (GELU) v = gelu_fast4(v);
+        return v;
+    };
+    // C (16-bit): one accumulator tile (row tile i, column tile j) -> slab, accumulator layout (lane = row l15, 4 columns fq4*4..)
+    auto epi_c16 = [&](f4 a, f4 b, int j) {
+        const f4 v = act4(a + b);
+        unsigned wa = sw_w16;
+        asm volatile("" : "+v"(wa));                // keep the XOR at the use: four hoisted address registers would spill
+        *reinterpret_cast<v4*>(slab + (wa ^ (unsigned)(j * 32))) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+    };
+    // F (16-bit): the slab's 16 rows x 128 B leave as whole row lines
+    auto epi_f16 = [&](int i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned ub = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64) * 2u;
+        const u32x4_ o0 = *reinterpret_cast<const u32x4_*>(slab + sw_r), o1 = *reinterpret_cast<const u32x4_*>(slab + sw_r + 1024);
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rs_c, vo_row + ub, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, rs_c, vo_row + ub + (unsigned)(8 * g.ldc) * 2u, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // C (fp32): two accumulator tiles (row tile i, column tiles jh*2, jh*2+1) -> slab
+    auto epi_c32 = [&](f4 a0, f4 a1) {
+        const f4 v0 = act4(a0 + eb0), v1 = act4(a1 + eb1);
+        unsigned wa = sw_w32;
+        asm volatile("" : "+v"(wa));
+        *reinterpret_cast<f4*>(slab + wa) = v0;
+        *reinterpret_cast<f4*>(slab + (wa ^ 64u)) = v1;
+    };
+    // F (fp32): 16 rows x 32 columns leave as whole 128-byte row lines, residual added in the row layout
+    auto epi_f32 = [&](int i, int jh, f4 r0, f4 r1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned ub = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u;
+        const f4 o0 = *reinterpret_cast<const f4*>(slab + sw_r) + r0;
+        const f4 o1 = *reinterpret_cast<const f4*>(slab + sw_r + 1024) + r1;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o0), rs_c, vo_row + ub, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o1), rs_c, vo_row + ub + (unsigned)(8 * g.ldc) * 4u, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto bias_of = [&](int j) -> f4 { return j == 0 ? eb0 : (j == 1 ? eb1 : (j == 2 ? eb2 : eb3)); };
+    // vector-memory operations an epilogue piece issues in its phase-0 interval
+    auto e0_of = [](int E) constexpr {
+        if (E < 0) return 0;
+        if (OUT16) return E == 0 ? 4 : ((E >= 2 && (E & 1) == 0) ? 2 : 0);
+        return (E >= 2 ? 2 : 0) + ((E == 0 || E == 5) ? 2 : 0);
+    };
+    // ... and in its phase-1 interval (fp32: the residual loads of unit E)
+    auto e1_of = [](int E) constexpr { return (!OUT16 && E >= 0 && E < 8) ? 2 : 0; };
+    // phase-0 part of piece E of the draining accumulator set.  A residual load is behind the 4 B DMAs of its own K-tile and the 2 A
+    // DMAs of this one (or behind nothing: at the end of the stream the phases wait with a smaller count instead of issuing)
+    auto epi_even = [&](auto EC, f4 (&prv)[4][4]) {
+        constexpr int E = decltype(EC)::value;
+        if constexpr (E < 0) {
+        } else if constexpr (OUT16) {
+            if constexpr (E == 0) epi_load16();
+            if constexpr (E >= 1) epi_c16(prv[(E - 1) >> 1][((E - 1) & 1) * 2 + 1], bias_of(((E - 1) & 1) * 2 + 1), ((E - 1) & 1) * 2 + 1);
+            if constexpr (E >= 2 && (E & 1) == 0) epi_f16(E / 2 - 1);
+        } else {
+            // unit E-2 leaves: its residual was loaded at the end of K-tile E-2; behind it 2 A + e0(E-1) + 4 B + e1(E-1) of K-tile E-1
+            // and 2 A DMAs of this K-tile (at the end of the stream the phases wait vmcnt(0) instead of issuing)
+            if constexpr (E >= 2) {
+                constexpr int NV = 8 + ((E - 1) >= 2 ? 2 : 0) + (((E - 1) == 0 || (E - 1) == 5) ? 2 : 0) + ((E - 1) < 8 ? 2 : 0);
+                if constexpr ((E & 1) == 0) { pa_wait2<NV>(er0, er1); epi_f32((E - 2) & 3, (E - 2) >> 2, er0, er1); }
+                else                        { pa_wait2<NV>(es0, es1); epi_f32((E - 2) & 3, (E - 2) >> 2, es0, es1); }
+            }
+            if constexpr (E == 0 || E == 5) epi_load32_bias(E == 0 ? 0 : 1);
+        }
+    };
+    // phase-1 part: a bias load of phase 0 is behind at most the four B DMAs of this K-tile (and, fp32, the two residual loads)
+    auto epi_odd = [&](auto EC, f4 (&prv)[4][4]) {
+        constexpr int E = decltype(EC)::value;
+        if constexpr (E >= 0 && E < 8) {
+            if constexpr (OUT16) {
+                if constexpr (E == 0) pa_wait4<4>(eb0, eb1, eb2, eb3);
+                epi_c16(prv[E >> 1][(E & 1) * 2], bias_of((E & 1) * 2), (E & 1) * 2);
+            } else {
+                if constexpr (E == 0 || E == 5) pa_wait2<4>(eb0, eb1);
+                if constexpr (E >= 1) epi_c32(prv[(E - 1) & 3][((E - 1) >> 2) * 2], prv[(E - 1) & 3][((E - 1) >> 2) * 2 + 1]);
+                if constexpr ((E & 1) == 0) epi_load32_res(E & 3, E >> 2, er0, er1);
+                else                        epi_load32_res(E & 3, E >> 2, es0, es1);
+            }
+        }
+        if constexpr (!OUT16 && E == 8) epi_c32(prv[3][2], prv[3][3]);           // C(7)
+    };
+
+    // ---- one K-tile of the stream: T = stream index, buffer `buf`; cursor c2 stands at K-tile T + 2 (buffer `nbuf`) -----------------
+    int T_ = 0, buf = 0, nbuf = 2;
+    Cursor c2;
+    auto ktile = [&](auto EC, auto FC, f4 (&cur)[4][4], f4 (&prv)[4][4]) __attribute__((always_inline)) {
+        constexpr int E = decltype(EC)::value;
+        constexpr bool FIRST = decltype(FC)::value != 0;
+        const unsigned char* lb = lds_raw + buf * KTB;
+        const unsigned nb = lds0 + (unsigned)(nbuf * KTB);
+        const bool has2 = T_ + 2 < total_kt;
+        // ---- phase 0: A + B0 fragments; DMA A(T+2) ---------------------------------------------------------------------------------
+        if constexpr (!(ABL & 2)) {
+            read_b(lb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(lb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has2) { if constexpr (!(ABL & 1)) stage_a(c2, nb); }
+        else pa_wait<0>();                                       // last two K-tiles of the stream: the counts of the pieces assume DMAs that are not issued any more
+        PA_BAR();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        epi_even(EC, prv);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if constexpr (!(ABL & 4)) cur[i][j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        PA_BAR();
+        // ---- phase 1: B1 fragments; DMA B0 + B1 (T+2); retire K-tile T+1 -----------------------------------------------------------
+        if constexpr (!(ABL & 2)) read_b(lb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has2) {
+            if constexpr (!(ABL & 1)) {
+                stage_b(c2, nb, 0);
+                stage_b(c2, nb, 1);
+            }
+            advance(c2);
+            if constexpr (!(ABL & 1)) pa_wait<6 + e1_of(E - 1) + e0_of(E)>();
+        } else {
+            pa_wait<0>();
+        }
+        PA_BAR();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        epi_odd(EC, prv);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if constexpr (!(ABL & 4)) cur[i][2 + j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        PA_BAR();
+        ++T_;
+        buf = buf == 2 ? 0 : buf + 1;
+        nbuf = nbuf == 2 ? 0 : nbuf + 1;
+    };
+    // ---- one output tile: K-tiles 0 .. 8 carry the pieces of the previous tile's epilogue -------------------------------------------
+    int ent = 0;
+    auto tile = [&](f4 (&cur)[4][4], f4 (&prv)[4][4]) __attribute__((always_inline)) {
+        int kt;
+        if (ent > 0) {
+            ktile(IC<0>{}, IC<1>{}, cur, prv);
+            ktile(IC<1>{}, IC<0>{}, cur, prv);
+            ktile(IC<2>{}, IC<0>{}, cur, prv);
+            ktile(IC<3>{}, IC<0>{}, cur, prv);
+            ktile(IC<4>{}, IC<0>{}, cur, prv);
+            ktile(IC<5>{}, IC<0>{}, cur, prv);
+            ktile(IC<6>{}, IC<0>{}, cur, prv);
+            ktile(IC<7>{}, IC<0>{}, cur, prv);
+            ktile(IC<8>{}, IC<0>{}, cur, prv);
+            kt = 9;
+            if constexpr (!OUT16) {
+                ktile(IC<9>{}, IC<0>{}, cur, prv);
+                kt = 10;
+            }
+        } else {
+            ktile(IC<-1>{}, IC<1>{}, cur, prv);
+            kt = 1;
+        }
+        for (; kt < nk; ++kt) ktile(IC<-1>{}, IC<0>{}, cur, prv);
+        const int tl = entry_tile(ent);
+        pm0 = (tl / tiles_n) * 128;
+        pn0 = (tl % tiles_n) * 256;
+        ++ent;
+    };
+    // ---- serial drain (last tile of the workgroup): the same pieces back to back, nothing else in flight ----------------------------
+    auto drain = [&](f4 (&acc)[4][4]) __attribute__((always_inline)) {
+        if constexpr (OUT16) {
+            epi_load16();
+            pa_wait4<0>(eb0, eb1, eb2, eb3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) epi_c16(acc[i][j], bias_of(j), j);
+                epi_f16(i);
+            }
+        } else {
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                epi_load32_bias(jh);
+                pa_wait2<0>(eb0, eb1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    epi_load32_res(i, jh, er0, er1);
+                    pa_wait2<0>(er0, er1);
+                    epi_c32(acc[i][jh * 2], acc[i][jh * 2 + 1]);
+                    epi_f32(i, jh, er0, er1);
+                }
+            }
+        }
+    };
+
+    // ---- prologue: K-tiles 0 and 1 of the stream --------------------------------------------------------------------------------------
+    seek(c2, 0);
+    stage_a(c2, lds0); stage_b(c2, lds0, 0); stage_b(c2, lds0, 1);
+    advance(c2);
+    if (total_kt > 1) {
+        stage_a(c2, lds0 + KTB); stage_b(c2, lds0 + KTB, 0); stage_b(c2, lds0 + KTB, 1);
+        advance(c2);
+        pa_wait<6>();
+    } else {
+        pa_wait<0>();
+    }
+    PA_BAR();
+    if (wr == 1) PA_BAR();                                       // one-interval shift of the second row group
+
+    f4 acc0[4][4], acc1[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        tile(acc0, acc1);
+        if (ent == my_count) break;
+        tile(acc1, acc0);
+        if (ent == my_count) break;
+    }
+    if (wr == 0) PA_BAR();                                       // barrier balance: 1 + 4 * total_kt + 1 per wave
+    if (my_count & 1) drain(acc0);
+    else drain(acc1);
+#undef PA_BAR
+}
+
+}  // namespace
+
+namespace mi355 {
+
+// Launch the two-accumulator persistent kernel when the shape suits it; MI355_EUNSUPPORTED (nothing touched) otherwise.
+int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl) {
+    const int nk = g.K / g16::BK;
+    if ((g.K % g16::BK) || nk < (out16 ? 9 : 10) || (g.N & 255) || g.gamma || g.resid_period || (out16 && g.resid)) return MI355_EUNSUPPORTED;
+    if ((long)g.M * g.ldc * 4 >= (1L << 31) || (long)g.M * g.lda * 2 >= (1L << 32) || (long)g.N * g.ldb * 2 >= (1L << 32))
+        return MI355_EUNSUPPORTED;                                                                           // 32-bit buffer / lane offsets
+    if (g.M & 127) return MI355_EUNSUPPORTED;
+    PaPlan pl{};
+    pl.tiles_n = g.N / 256;
+    const long ntiles = (long)cdiv(g.M, 128) * pl.tiles_n;
+    if (ntiles > (1L << 30)) return MI355_EUNSUPPORTED;
+    const int ncu = resident_slots(1);
+    const int grid = ntiles < ncu ? (int)ntiles : ncu;
+    pl.full = (int)(ntiles / grid);
+    pl.left = (int)(ntiles - (long)pl.full * grid);
+    const bool gelu = g.act == MI355_ACT_GELU;
+    if (abl) {                                                  // tuning experiments only: fp16, 16-bit output, no GELU
+        switch (abl) {
+            case 1: gemm16_pa_kernel<_Float16, true, false, 1><<<grid, 512, 0, st>>>(g, pl); break;
+            case 2: gemm16_pa_kernel<_Float16, true, false, 2><<<grid, 512, 0, st>>>(g, pl); break;
+            case 3: gemm16_pa_kernel<_Float16, true, false, 3><<<grid, 512, 0, st>>>(g, pl); break;
+            case 4: gemm16_pa_kernel<_Float16, true, false, 4><<<grid, 512, 0, st>>>(g, pl); break;
+            default: gemm16_pa_kernel<_Float16, true, false, 11><<<grid, 512, 0, st>>>(g, pl); break;
+        }
+        return MI355_OK;
+    }
+#define PA_LAUNCH(T_, O_, G_) gemm16_pa_kernel<T_, O_, G_><<<grid, 512, 0, st>>>(g, pl)
+#define PA_BY_EPI(T_)                                                    \
+    do {                                                                 \
+        if (out16) { if (gelu) PA_LAUNCH(T_, true, true); else PA_LAUNCH(T_, true, false); }   \
+        else       { if (gelu) PA_LAUNCH(T_, false, true); else PA_LAUNCH(T_, false, false); } \
+    } while (0)
+    if (precision == MI355_PREC_FP16) PA_BY_EPI(_Float16);
+    else PA_BY_EPI(__bf16);
+#undef PA_BY_EPI
+#undef PA_LAUNCH
+    return MI355_OK;
+}
+
+}  // namespace mi355

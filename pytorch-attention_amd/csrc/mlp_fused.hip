@@ -414,12 +414,10 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
         const long niter = ((M + 15) / 16 + 15) / 16;
         const int grid2 = (int)(niter < ncu ? niter : ncu);
         if (precision == MI355_PREC_FP16) {
-            static bool at1 = false;
-            if (!at1) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at1 = true; }
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512>), (int)sm)) return rc;
             mlp_fused_stream_kernel<1, 128, 512><<<grid2, 1024, sm, st>>>(a);
         } else {
-            static bool at2 = false;
-            if (!at2) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at2 = true; }
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512>), (int)sm)) return rc;
             mlp_fused_stream_kernel<2, 128, 512><<<grid2, 1024, sm, st>>>(a);
         }
         MI355_LAUNCH_CHECK();
@@ -431,18 +429,10 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
     constexpr size_t smem = mlp_smem<64, 256>();
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (precision == MI355_PREC_FP16) {
-        static bool attr1 = false;
-        if (!attr1) {
-            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr1 = true;
-        }
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256>), (int)smem)) return rc;
         mlp_fused_kernel<1, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
     } else {
-        static bool attr2 = false;
-        if (!attr2) {
-            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr2 = true;
-        }
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256>), (int)smem)) return rc;
         mlp_fused_kernel<2, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
     }
     MI355_LAUNCH_CHECK();
@@ -469,12 +459,10 @@ extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const
         const long niter = ((M + 15) / 16 + 15) / 16;
         const int grid2 = (int)(niter < ncu ? niter : ncu);
         if (precision == MI355_PREC_FP16) {
-            static bool at1 = false;
-            if (!at1) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at1 = true; }
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512, true>), (int)sm)) return rc;
             mlp_fused_stream_kernel<1, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
         } else {
-            static bool at2 = false;
-            if (!at2) { MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); at2 = true; }
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512, true>), (int)sm)) return rc;
             mlp_fused_stream_kernel<2, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
         }
         MI355_LAUNCH_CHECK();
@@ -486,18 +474,10 @@ extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const
     constexpr size_t smem = mlp_smem<64, 256>(true);
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (precision == MI355_PREC_FP16) {
-        static bool attr1 = false;
-        if (!attr1) {
-            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr1 = true;
-        }
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256, true>), (int)smem)) return rc;
         mlp_fused_kernel<1, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
     } else {
-        static bool attr2 = false;
-        if (!attr2) {
-            MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr2 = true;
-        }
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256, true>), (int)smem)) return rc;
         mlp_fused_kernel<2, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
     }
     MI355_LAUNCH_CHECK();
