@@ -45,6 +45,7 @@ extern "C" {
 
 #define MI355_ACT_NONE 0
 #define MI355_ACT_GELU 1
+#define MI355_ACT_RELU 2   /* fp32-in engine only (mi355_linear_fwd, mi355_conv2d_tokens_fwd): relu with torch's NaN behaviour */
 
 typedef void* mi355_stream_t; /* hipStream_t */
 
@@ -210,6 +211,22 @@ enum {
 size_t mi355_bam_workspace_bytes(int B, int C, int Cr, int H, int W);
 int mi355_bam_fwd(const float* x, const float* const* params, float* y, int B, int C, int Cr, int H, int W, int dilation,
                   void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+/* The helper classes of these modules on their own (the reference exposes them as importable nn.Modules):
+ *   mi355_bam_gates_fwd        ChannelGate.forward bam.py:28-33 -> cg (B,C) and / or SpatialGate.forward :53-59 -> sg (B,H*W), both
+ *                              BEFORE their expand_as (a broadcast view is the caller's); either output may be NULL.  Parameters and
+ *                              workspace as for mi355_bam_fwd.
+ *   mi355_zpool_fwd            ZPool.forward triplet_attention.py:31-36: y (B,2,H,W) = [mean over channels, max over channels].
+ *   mi355_attention_gate_fwd   AttentionGate.forward :38-49: y = x * sigmoid(relu(bn(conv_kxk(ZPool(x))))); w (2,k,k), affine[0] / [1] =
+ *                              eval-BatchNorm scale / shift with the conv bias folded in; workspace of
+ *                              mi355_attention_gate_workspace_bytes.
+ * BasicConv2d.forward (:19-29, conv -> bn -> relu) is mi355_conv2d_tokens_fwd with act = MI355_ACT_RELU and the BatchNorm folded,
+ * followed by mi355_tokens_to_nchw_axpy_fwd. */
+int mi355_bam_gates_fwd(const float* x, const float* const* params, float* cg, float* sg, int B, int C, int Cr, int H, int W, int dilation,
+                        void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+int mi355_zpool_fwd(const float* x, float* y, int B, int C, int H, int W, mi355_stream_t stream);
+size_t mi355_attention_gate_workspace_bytes(int B, int H, int W);
+int mi355_attention_gate_fwd(const float* x, const float* w, const float* affine, float* y, int B, int C, int H, int W, int ksize,
+                             void* workspace, size_t workspace_bytes, mi355_stream_t stream);
 
 /*   sk        sk_module.py:41-56   u1 = relu(bn(conv3x3_grouped(x))), u2 = relu(bn(conv3x3_grouped_dilation2(x))), s = mean_hw(u1 + u2),
  *                                  z = relu(bn1d(fc s)), [a, b] = softmax over the two branches of [fc1 z, fc2 z], y = u1 a + u2 b.
@@ -421,6 +438,18 @@ size_t mi355_patch_embed_workspace_bytes(int B, int Cin, int H, int W, int ps, i
 int mi355_patch_embed_ws_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
                              float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
                              void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ViT Attention.forward as ONE call (ViT.py:79-89; SURVEY 8b lists `mhsa` among the exported ops):
+ *   y = resid + proj( concat_heads( softmax(q k^T scale) v ) ) + b_proj,   [q | k | v] = x Wqkv^T + b_qkv  viewed (B,N,3,heads,d)
+ * x (B,N,C): fp32 (x_is16 = 0: converted to the operand format first) or already in the 16-bit operand format of `precision`
+ * (x_is16 = 1: e.g. the output of mi355_layernorm16_fwd); Wqkv16 (3C,C) / Wproj16 (C,C): 16-bit copies of the weights in the same
+ * format (mi355_cast16_fwd makes them); b_qkv (3C) / b_proj (C) / resid (B,N,C) fp32 or NULL; y (B,N,C) fp32.  The same kernels the
+ * host composition launches (16-bit GEMM engine, K/V-resident core for d in {32,64} and N <= 224, the streaming core otherwise);
+ * q / k / v / context live in the workspace in 16 bit.  precision 1 (fp16) or 2 (bf16); C % 64 == 0, head_dim in {32,64,128,192,256}. */
+size_t mi355_mhsa_workspace_bytes(int B, int N, int C, int x_is16);
+int mi355_mhsa_fwd(const void* x, int x_is16, const void* Wqkv16, const float* b_qkv, const void* Wproj16, const float* b_proj,
+                   const float* resid, float* y, int B, int N, int C, int heads, float scale, int precision, void* workspace,
+                   size_t workspace_bytes, mi355_stream_t stream);
 
 /* General multi-head attention core (the plain softmax(QK^T*s)V pattern of setr.py:62-72, pvt.py:73-91,
  * segformer.py:33-50, cmt.py:93-111, moat.py:74-84, bvit.py:66-76 ...): any N_q / N_kv, online softmax over 64-key tiles.

@@ -14,7 +14,7 @@
 
 namespace {
 
-enum { AP_GC = 0, AP_COORD = 1, AP_TRIPLET = 2, AP_BAM = 3 };
+enum { AP_GC = 0, AP_COORD = 1, AP_TRIPLET = 2, AP_BAM = 3, AP_SPATIAL = 4 };
 
 // ---- reductions over the channel axis ---------------------------------------------------------------------------------------
 // MODE 0: out[b, k, p] = bias[k] + sum_c w[k*C + c] * x[b, c, p]  for k < K (K <= KMAX)
@@ -349,6 +349,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
             yv[e] = (xv[e] * s1 + xv[e] * g.b[plane * g.W + j + e] + xv[e] * g.c[img * HW + p + e]) * (1.0f / 3.0f);
+    } else if constexpr (MODE == AP_SPATIAL) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) yv[e] = xv[e] * g.c[img * HW + p + e];
     } else {
         const float cg = g.a[plane];
 #pragma unroll
@@ -800,28 +803,17 @@ size_t mi355_bam_workspace_bytes(int B, int C, int Cr, int H, int W) {
     return 4 * (2 * fl((size_t)B * C) + 2 * fl((size_t)B * Cr * hw) + fl((size_t)B * hw)) + 256;
 }
 
-int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C, int Cr, int H, int W, int dilation, void* workspace,
-                  size_t workspace_bytes, mi355_stream_t stream) {
-    MI355_CHECK_ARG(x && p && y && workspace && B > 0 && C > 0 && Cr > 0 && H > 0 && W > 0 && dilation > 0);
-    for (int q = 0; q < MI355_BAM_NPARAMS; ++q) MI355_CHECK_ARG(p[q] != nullptr);
-    MI355_CHECK_ARG(workspace_bytes >= mi355_bam_workspace_bytes(B, C, Cr, H, W) && aligned16(workspace));
-    if (Cr > 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: reduced width %d > 32", Cr);
-    {
-        const int kmax = Cr <= 4 ? 4 : (Cr <= 8 ? 8 : (Cr <= 16 ? 16 : 32));
-        if ((size_t)C * kmax * sizeof(float) > 65536)
-            return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: C = %d with reduced width %d exceeds the 64 KB weight stage", C, Cr);
-    }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+// The two gates of BAM (ChannelGate.forward bam.py:28-33, SpatialGate.forward :53-59) without the broadcast: cg (B,C) and / or
+// sg (B,HW); either output may be null.  t0 / t1: (B,Cr,HW) scratch, mean: (B,C) scratch.
+static int bam_gates(const float* x, const float* const* p, float* mean, float* cg, float* t0, float* t1, float* sg, int B, int C, int Cr,
+                     int H, int W, int dilation, hipStream_t st) {
     const long HW = (long)H * W;
-    float* ws = static_cast<float*>(workspace);
-    float* mean = ws;                                    // (B,C)      avgpool: bam.py:30
-    float* cg = mean + fl((size_t)B * C);                // (B,C)      bn(mlp(.)): :31-32
-    float* t0 = cg + fl((size_t)B * C);                  // (B,Cr,HW)  conv1: :55
-    float* t1 = t0 + fl((size_t)B * Cr * HW);            // (B,Cr,HW)  conv2 stages: :56
-    float* sg = t1 + fl((size_t)B * Cr * HW);            // (B,HW)     bn(conv3(.)): :57-58
-    launch_plane_dot(x, nullptr, mean, (long)B * C, C, HW, 1.0f / (float)HW, st);
-    bam_channel_kernel<<<B, 256, Cr * sizeof(float), st>>>(mean, p[MI355_BAM_FC1_W], p[MI355_BAM_FC1_B], p[MI355_BAM_FC2_W], p[MI355_BAM_FC2_B],
-                                                           p[MI355_BAM_BN1D_SCALE], p[MI355_BAM_BN1D_SHIFT], cg, C, Cr);
+    if (cg) {
+        launch_plane_dot(x, nullptr, mean, (long)B * C, C, HW, 1.0f / (float)HW, st);
+        bam_channel_kernel<<<B, 256, Cr * sizeof(float), st>>>(mean, p[MI355_BAM_FC1_W], p[MI355_BAM_FC1_B], p[MI355_BAM_FC2_W], p[MI355_BAM_FC2_B],
+                                                               p[MI355_BAM_BN1D_SCALE], p[MI355_BAM_BN1D_SHIFT], cg, C, Cr);
+    }
+    if (!sg) return MI355_OK;
 #define CR_DISPATCH(FN)                                  \
     do {                                                 \
         if (Cr <= 4) FN(4); else if (Cr <= 8) FN(8); else if (Cr <= 16) FN(16); else FN(32); \
@@ -849,9 +841,86 @@ int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C,
 #undef SCQ
 #undef CR_DISPATCH
     launch_chan_reduce<0, 1>(t0, p[MI355_BAM_CONV3_W], p[MI355_BAM_CONV3_B], sg, B, Cr, HW, 1, st);
+    return MI355_OK;
+}
+
+static int bam_check(const float* x, const float* const* p, int B, int C, int Cr, int H, int W, int dilation, const void* workspace,
+                     size_t workspace_bytes) {
+    MI355_CHECK_ARG(x && p && workspace && B > 0 && C > 0 && Cr > 0 && H > 0 && W > 0 && dilation > 0);
+    for (int q = 0; q < MI355_BAM_NPARAMS; ++q) MI355_CHECK_ARG(p[q] != nullptr);
+    MI355_CHECK_ARG(workspace_bytes >= mi355_bam_workspace_bytes(B, C, Cr, H, W) && aligned16(workspace));
+    if (Cr > 32) return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: reduced width %d > 32", Cr);
+    const int kmax = Cr <= 4 ? 4 : (Cr <= 8 ? 8 : (Cr <= 16 ? 16 : 32));
+    if ((size_t)C * kmax * sizeof(float) > 65536)
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_bam_fwd: C = %d with reduced width %d exceeds the 64 KB weight stage", C, Cr);
+    return MI355_OK;
+}
+
+int mi355_bam_fwd(const float* x, const float* const* p, float* y, int B, int C, int Cr, int H, int W, int dilation, void* workspace,
+                  size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(y != nullptr);
+    if (int rc = bam_check(x, p, B, C, Cr, H, W, dilation, workspace, workspace_bytes)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W;
+    float* ws = static_cast<float*>(workspace);
+    float* mean = ws;                                    // (B,C)      avgpool: bam.py:30
+    float* cg = mean + fl((size_t)B * C);                // (B,C)      bn(mlp(.)): :31-32
+    float* t0 = cg + fl((size_t)B * C);                  // (B,Cr,HW)  conv1: :55
+    float* t1 = t0 + fl((size_t)B * Cr * HW);            // (B,Cr,HW)  conv2 stages: :56
+    float* sg = t1 + fl((size_t)B * Cr * HW);            // (B,HW)     bn(conv3(.)): :57-58
+    if (int rc = bam_gates(x, p, mean, cg, t0, t1, sg, B, C, Cr, H, W, dilation, st)) return rc;
     ApplyArgs g{};
     g.x = x; g.y = y; g.a = cg; g.b = sg; g.C = C; g.H = H; g.W = W;
     launch_apply<AP_BAM>(g, B, st);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+// Stand-alone gates of BAM: cg (B,C) = ChannelGate.forward before its expand_as (bam.py:28-33), sg (B,HW) = SpatialGate.forward before
+// its expand_as (:53-59).  Either output may be null.  Workspace as for mi355_bam_fwd.
+int mi355_bam_gates_fwd(const float* x, const float* const* p, float* cg, float* sg, int B, int C, int Cr, int H, int W, int dilation,
+                        void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(cg || sg);
+    if (int rc = bam_check(x, p, B, C, Cr, H, W, dilation, workspace, workspace_bytes)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W;
+    float* ws = static_cast<float*>(workspace);
+    float* mean = ws;
+    float* t0 = mean + 2 * fl((size_t)B * C);
+    float* t1 = t0 + fl((size_t)B * Cr * HW);
+    if (int rc = bam_gates(x, p, mean, cg, t0, t1, sg, B, C, Cr, H, W, dilation, st)) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+// ZPool.forward (triplet_attention.py:31-36): y (B,2,H,W) = [mean over channels, max over channels] of x (B,C,H,W).
+int mi355_zpool_fwd(const float* x, float* y, int B, int C, int H, int W, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0);
+    launch_chan_reduce<1, 1>(x, nullptr, nullptr, y, B, C, (long)H * W, 2, static_cast<hipStream_t>(stream));
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
+// AttentionGate.forward (triplet_attention.py:38-49): y = x * sigmoid(relu(bn(conv_kxk(ZPool(x))))), x (B,C,H,W); w (2,k,k); affine[0] /
+// [1] = BatchNorm (eval) scale / shift with the conv bias folded in.  Workspace: 3 * B * H * W floats (+ alignment).
+size_t mi355_attention_gate_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return 4 * 3 * fl((size_t)B * H * W) + 256;
+}
+int mi355_attention_gate_fwd(const float* x, const float* w, const float* affine, float* y, int B, int C, int H, int W, int ksize,
+                             void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && w && affine && y && workspace && B > 0 && C > 0 && H > 0 && W > 0);
+    MI355_CHECK_ARG(ksize >= 1 && ksize <= 15 && (ksize & 1));
+    MI355_CHECK_ARG(workspace_bytes >= mi355_attention_gate_workspace_bytes(B, H, W) && aligned16(workspace));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long HW = (long)H * W;
+    float* zp = static_cast<float*>(workspace);            // (B,2,HW)
+    float* gate = zp + 2 * fl((size_t)B * HW);             // (B,HW)
+    launch_chan_reduce<1, 1>(x, nullptr, nullptr, zp, B, C, HW, 2, st);
+    launch_gate_conv(zp, zp + HW, 2 * HW, w, affine, gate, B, H, W, ksize, st);
+    ApplyArgs g{};
+    g.x = x; g.y = y; g.c = gate; g.C = C; g.H = H; g.W = W;
+    launch_apply<AP_SPATIAL>(g, B, st);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 if (g.bias) z += g.bias_per_row ? g.bias[m] : g.bias[n + c];
                 if constexpr (AMODE >= 1) { if (g.pos) z += g.pos[(long)(m % g.P) * g.N + n + c]; }
                 if (g.act == MI355_ACT_GELU) z = gelu_fast(z);
+                else if (g.act == MI355_ACT_RELU) z = relu_nan(z);
                 if (g.gamma) z *= g.gamma[n + c];
                 if (Rb) z += Rb[orow * g.ldc + n + c];
                 vv[c] = z;
@@ -364,7 +365,7 @@ int mi355_linear_fwd(const float* X, const float* W, const float* bias, const fl
                      int M, int N, int K, int ldx, int ldy, int act, int precision, mi355_stream_t stream) {
     MI355_CHECK_ARG(X && W && Y);
     MI355_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
-    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU || act == MI355_ACT_RELU);
     if ((K & 3) || (ldx & 3) || !aligned16(X) || !aligned16(W))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear_fwd: K and ldx must be multiples of 4 and X, W 16-byte aligned "
                                                "(K=%d ldx=%d)", K, ldx);
@@ -473,14 +474,14 @@ int mi355_conv2d_tokens_fwd(const float* x, const float* weight, const float* bi
                             mi355_stream_t stream) {
     MI355_CHECK_ARG(x && weight && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     MI355_CHECK_ARG(in_layout == 0 || in_layout == 1);
-    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU || act == MI355_ACT_RELU);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     MI355_CHECK_ARG(OH > 0 && OW > 0);
     const int Kreal = Cin * KH * KW, K = (Kreal + 3) & ~3;
     MI355_CHECK_ARG(ldw >= K && (ldw & 3) == 0);
     if (!aligned16(x) || !aligned16(weight) || (in_layout == 1 && (Cin & 3)))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_conv2d_tokens_fwd: 16-byte aligned buffers and, for token-major input, Cin %% 4 == 0 (Cin=%d)", Cin);
-    if (mi355::opt_stem_direct() && mi355::stem_conv_applicable(Cin, Cout, KH, KW, in_layout, bias, pos, y)) {
+    if (act != MI355_ACT_RELU && mi355::opt_stem_direct() && mi355::stem_conv_applicable(Cin, Cout, KH, KW, in_layout, bias, pos, y)) {
         const int rc = mi355::stem_conv(x, weight, bias, pos, y, B, Cin, H, W, Cout, KH, KW, stride, pad, ldw, in_layout, act,
                                         static_cast<hipStream_t>(stream));       // narrow stem layers: direct fp32 kernel (stem_conv.hip)
         if (rc) return rc;

@@ -83,6 +83,12 @@ SIGNATURES = {
     "mi355_triplet_fwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
     "mi355_bam_workspace_bytes": (ctypes.c_size_t, [c_int] * 5),
     "mi355_bam_fwd": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_bam_gates_fwd": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_zpool_fwd": (c_int, [c_vp, c_vp] + [c_int] * 4 + [c_vp]),
+    "mi355_attention_gate_workspace_bytes": (ctypes.c_size_t, [c_int] * 3),
+    "mi355_attention_gate_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_mhsa_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
+    "mi355_mhsa_fwd": (c_int, [c_vp, c_int] + [c_vp] * 6 + [c_int] * 4 + [c_float, c_int, c_vp, ctypes.c_size_t, c_vp]),
     "mi355_sk_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
     "mi355_sk_fwd": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp, ctypes.c_size_t, c_vp]),
     "mi355_cam_workspace_bytes": (ctypes.c_size_t, [c_int] * 2),

@@ -13,7 +13,7 @@ from . import _ffi
 from ._ffi import check, dptr, lib, require_device_f32, stream_ptr, workspace
 
 PREC_STRICT, PREC_FP16, PREC_BF16 = 0, 1, 2
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2     # ACT_RELU: fp32-in engine only (linear, conv2d_tokens)
 
 _default_precision = PREC_FP16
 
@@ -143,6 +143,46 @@ def bam_forward(x, params, Cr, dilation):
     y = torch.empty_like(x)
     check(lib().mi355_bam_fwd(dptr(x), ctypes.cast(table, ctypes.c_void_p), dptr(y), B, C, Cr, H, W, int(dilation), dptr(ws), ws.numel(),
                               stream_ptr(x.device)), "mi355_bam_fwd")
+    return y
+
+
+def bam_gates(x, params, Cr, dilation, channel=True, spatial=True):
+    """The gates of BAM before their broadcast: (cg (B,C) or None, sg (B,H*W) or None); `params` as for bam_forward."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    if len(params) != 16:
+        raise ValueError("bam_gates: expected 16 parameter tensors")
+    ps = [require_device_f32(t, f"bam parameter {i}") for i, t in enumerate(params)]
+    table = (ctypes.c_void_p * 16)(*[t.data_ptr() for t in ps])
+    ws = workspace(lib().mi355_bam_workspace_bytes(B, C, Cr, H, W), x.device)
+    cg = torch.empty(B, C, dtype=torch.float32, device=x.device) if channel else None
+    sg = torch.empty(B, H * W, dtype=torch.float32, device=x.device) if spatial else None
+    check(lib().mi355_bam_gates_fwd(dptr(x), ctypes.cast(table, ctypes.c_void_p), dptr(cg), dptr(sg), B, C, Cr, H, W, int(dilation),
+                                    dptr(ws), ws.numel(), stream_ptr(x.device)), "mi355_bam_gates_fwd")
+    return cg, sg
+
+
+def zpool(x):
+    """(B,C,H,W) -> (B,2,H,W): mean and max over the channel axis (triplet_attention.py:31-36)."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, 2, H, W, dtype=torch.float32, device=x.device)
+    check(lib().mi355_zpool_fwd(dptr(x), dptr(y), B, C, H, W, stream_ptr(x.device)), "mi355_zpool_fwd")
+    return y
+
+
+def attention_gate(x, w, affine, ksize):
+    """x * sigmoid(relu(bn(conv_kxk(zpool(x))))): w (2,k,k) conv weight, affine (2,) = folded BatchNorm scale / shift."""
+    x = require_device_f32(x, "x")
+    B, C, H, W = x.shape
+    w = require_device_f32(w, "w").reshape(-1)
+    affine = require_device_f32(affine, "affine").reshape(-1)
+    if w.numel() != 2 * ksize * ksize or affine.numel() != 2:
+        raise ValueError("attention_gate: w must be (1,2,k,k) and affine (2,)")
+    ws = workspace(lib().mi355_attention_gate_workspace_bytes(B, H, W), x.device)
+    y = torch.empty_like(x)
+    check(lib().mi355_attention_gate_fwd(dptr(x), dptr(w), dptr(affine), dptr(y), B, C, H, W, int(ksize), dptr(ws), ws.numel(),
+                                         stream_ptr(x.device)), "mi355_attention_gate_fwd")
     return y
 
 
@@ -628,6 +668,26 @@ def weight16_padk(w, K, precision=None):
         return out
     tag = (w._version, w.data_ptr(), tuple(w.shape))
     return _derived_get((w,), ("w16padk", K, _prec(precision)), tag, build)
+
+
+def mhsa16(x, wqkv16, bqkv, wproj16, bproj, num_heads, scale, resid=None, precision=None):
+    """ViT Attention.forward as one C call (mi355_mhsa_fwd): x (B,N,C) fp32 or already in the 16-bit operand format."""
+    p = _prec(precision)
+    x_is16 = x.dtype != torch.float32
+    x = _require16(x, "x", p) if x_is16 else require_device_f32(x, "x")
+    wqkv16, wproj16 = _require16(wqkv16, "wqkv16", p), _require16(wproj16, "wproj16", p)
+    B, N, C = x.shape
+    if tuple(wqkv16.shape) != (3 * C, C) or tuple(wproj16.shape) != (C, C):
+        raise ValueError("mhsa16: weight shapes do not match the embedding width")
+    bqkv, bproj, resid = _opt(bqkv, "qkv.bias"), _opt(bproj, "proj.bias"), _opt(resid, "resid")
+    if resid is not None and resid.numel() != x.numel():
+        raise ValueError("mhsa16: residual shape mismatch")
+    y = torch.empty(B, N, C, dtype=torch.float32, device=x.device)
+    nws = lib().mi355_mhsa_workspace_bytes(B, N, C, 1 if x_is16 else 0)
+    ws = _ffi.workspace_named("mhsa", nws, x.device)
+    check(lib().mi355_mhsa_fwd(dptr(x), 1 if x_is16 else 0, dptr(wqkv16), dptr(bqkv), dptr(wproj16), dptr(bproj), dptr(resid), dptr(y),
+                               B, N, C, int(num_heads), float(scale), p, dptr(ws), nws, stream_ptr(x.device)), "mi355_mhsa_fwd")
+    return y
 
 
 def sdpa16(qkv16, num_heads, scale, precision=None):

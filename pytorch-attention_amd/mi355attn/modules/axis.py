@@ -71,12 +71,22 @@ class BasicConv2d(nn.Module):
         self.act = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        raise NotImplementedError("BasicConv2d is a parameter container here; TripletAttention.forward runs the fused gates")
+        """conv -> bn -> relu (triplet_attention.py:25-29) on its own: the implicit-GEMM conv with the BatchNorm folded into its rows
+        and a ReLU epilogue, then the token rows back to NCHW.  (Inside TripletAttention the 2 -> 1 gates run fused instead.)"""
+        _eval_only(self)
+        ks = self.conv.kernel_size[0]
+        s, t = F.bn_fold(self.bn, self.conv.bias)
+        tag = (id(s), self.conv.weight._version, self.conv.weight.data_ptr())
+        rows = F._derived_get((self.conv.weight, self.bn), ("basicconv_rows",), tag,
+                              lambda: F._gemm_rows(self.conv.weight.detach() * s[:, None, None, None], 0))
+        B, _, H, W = x.shape
+        tok, (oh, ow) = F.conv2d_tokens(x, None, t, ks, 1, (ks - 1) // 2, 0, precision=F.PREC_STRICT, act=F.ACT_RELU, wrows=rows)
+        return F.tokens_to_nchw(tok, oh, ow)
 
 
 class ZPool(nn.Module):
     def forward(self, x):
-        raise NotImplementedError("ZPool is computed inside TripletAttention.forward")
+        return F.zpool(x)                                     # triplet_attention.py:31-36
 
 
 class AttentionGate(nn.Module):
@@ -87,7 +97,12 @@ class AttentionGate(nn.Module):
         self.activation = nn.Sigmoid()
 
     def forward(self, x):
-        raise NotImplementedError("AttentionGate is a parameter container here; TripletAttention.forward runs the fused gates")
+        """x * sigmoid(conv(compress(x))) (triplet_attention.py:45-49) on its own, through the same gate kernel TripletAttention uses."""
+        _eval_only(self)
+        s, t = F.bn_fold(self.conv.bn, self.conv.conv.bias)
+        tag = (id(s), id(t))
+        affine = F._derived_get((self.conv.bn,), ("gate_affine",), tag, lambda: torch.cat([s, t]).contiguous())
+        return F.attention_gate(x, self.conv.conv.weight, affine, self.conv.conv.kernel_size[0])
 
 
 class TripletAttention(nn.Module):
@@ -127,7 +142,14 @@ class ChannelGate(nn.Module):
         self.bn = nn.BatchNorm1d(channel)
 
     def forward(self, x):
-        raise NotImplementedError("ChannelGate is a parameter container here; BAM.forward runs the fused gates")
+        """bn(mlp(avgpool(x))) expanded over the image (bam.py:28-33), computed by the kernels of the fused BAM forward."""
+        _eval_only(self)
+        Cr = self.mlp[0].weight.shape[0]
+        bn1d = F.bn_fold(self.bn)
+        dummy = x.new_zeros(1)
+        params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, bn1d[0], bn1d[1]] + [dummy] * 10
+        cg, _ = F.bam_gates(x, params, Cr, 1, channel=True, spatial=False)
+        return cg.view(x.shape[0], x.shape[1], 1, 1).expand_as(x)
 
 
 class SpatialGate(nn.Module):
@@ -146,8 +168,25 @@ class SpatialGate(nn.Module):
         self.bn = nn.BatchNorm2d(1)
         self.kernel_size, self.dilation = kernel_size, dilation_val
 
+    def _folded(self):
+        """Parameters 6..15 of the BAM table: conv1, the two dilated convs with their BatchNorms folded, conv3 with bn folded."""
+        if self.kernel_size != 3:
+            raise ValueError("SpatialGate: the kernel is written for 3x3 dilated convolutions (bam.py:36)")
+        d1 = F.bn_fold(self.conv2[1], self.conv2[0].bias)
+        d2 = F.bn_fold(self.conv2[4], self.conv2[3].bias)
+        s, t = F.bn_fold(self.bn, self.conv3.bias)
+        tag = (id(s), self.conv3.weight._version, self.conv3.weight.data_ptr())
+        w3, b3 = F._derived_get((self.conv3.weight, self.bn), ("bam_conv3",), tag,
+                                lambda: ((self.conv3.weight.detach().reshape(-1) * s).contiguous(), t))
+        return [self.conv1.weight, self.conv1.bias, self.conv2[0].weight, d1[0], d1[1], self.conv2[3].weight, d2[0], d2[1], w3, b3]
+
     def forward(self, x):
-        raise NotImplementedError("SpatialGate is a parameter container here; BAM.forward runs the fused gates")
+        """bn(conv3(conv2(conv1(x)))) expanded over the channels (bam.py:53-59), computed by the kernels of the fused BAM forward."""
+        _eval_only(self)
+        Cr = self.conv1.weight.shape[0]
+        dummy = x.new_zeros(1)
+        _, sg = F.bam_gates(x, [dummy] * 6 + self._folded(), Cr, self.dilation, channel=False, spatial=True)
+        return sg.view(x.shape[0], 1, x.shape[2], x.shape[3]).expand_as(x)
 
 
 class BAM(nn.Module):
@@ -156,26 +195,12 @@ class BAM(nn.Module):
         self.channel_attn = ChannelGate(channel)
         self.spatial_attn = SpatialGate(channel)
 
-    def _conv3(self):
-        """conv3 with its BatchNorm2d(1) folded in: w' = w * s, b' = (b - mean) * s + beta."""
-        sp = self.spatial_attn
-        s, t = F.bn_fold(sp.bn, sp.conv3.bias)
-        tag = (id(s), sp.conv3.weight._version, sp.conv3.weight.data_ptr())
-        return F._derived_get((sp.conv3.weight, sp.bn), ("bam_conv3",), tag,
-                              lambda: ((sp.conv3.weight.detach().reshape(-1) * s).contiguous(), t))
-
     def forward(self, x):
         _eval_only(self)
         ch, sp = self.channel_attn, self.spatial_attn
-        if sp.kernel_size != 3:
-            raise ValueError("BAM: the spatial gate kernel is written for 3x3 dilated convolutions (bam.py:36)")
         Cr = sp.conv1.weight.shape[0]
         bn1d = F.bn_fold(ch.bn)
-        d1 = F.bn_fold(sp.conv2[1], sp.conv2[0].bias)
-        d2 = F.bn_fold(sp.conv2[4], sp.conv2[3].bias)
-        w3, b3 = self._conv3()
-        params = [ch.mlp[0].weight, ch.mlp[0].bias, ch.mlp[2].weight, ch.mlp[2].bias, bn1d[0], bn1d[1],
-                  sp.conv1.weight, sp.conv1.bias, sp.conv2[0].weight, d1[0], d1[1], sp.conv2[3].weight, d2[0], d2[1], w3, b3]
+        params = [ch.mlp[0].weight, ch.mlp[0].bias, ch.mlp[2].weight, ch.mlp[2].bias, bn1d[0], bn1d[1]] + sp._folded()
         return F.bam_forward(x, params, Cr, sp.dilation)
 
 

@@ -14,8 +14,16 @@ from .. import functional as F
 
 
 def _no_dropout(*rates):
-    if any(rates):
-        raise NotImplementedError("inference engine: dropout rates must be 0")
+    """Dropout rates are accepted as the reference accepts them: in eval mode nn.Dropout is the identity, so a model built with its
+    training configuration runs unchanged.  What the forward-only engine cannot do is the stochastic training-mode forward."""
+    for r in rates:
+        if not 0 <= float(r) <= 1:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {r}")
+
+
+def _dropout_is_identity(m):
+    if m.training and any(isinstance(c, nn.Dropout) and c.p > 0 for c in m.modules()):
+        raise RuntimeError("inference engine: a non-zero dropout rate is only the identity in eval mode; call .eval()")
 
 
 class Attention(nn.Module):
@@ -32,6 +40,7 @@ class Attention(nn.Module):
         self.precision = precision
 
     def forward(self, x):
+        _dropout_is_identity(self)
         C = x.shape[-1]
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias, precision=self.precision)
         ctx = F.sdpa_general(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.num_heads, self.scale, precision=self.precision)
@@ -66,6 +75,7 @@ class SRAttention(nn.Module):
         return F.dwconv_patch_tokens(x, conv.weight, conv.bias, bn, H, W, self.sr_ratio)
 
     def forward(self, x, H, W, relative_pos=None):
+        _dropout_is_identity(self)
         p = self.precision
         q = F.linear(x, self.q.weight, self.q.bias, precision=p)
         src = self._kv_source(x, H, W)
@@ -79,6 +89,7 @@ class SRAttentionRelPos(SRAttention):
     """cmt.py:75-111: `relative_pos` (heads, N, N') is a required forward argument, added to the scaled logits."""
 
     def forward(self, x, H, W, relative_pos):
+        _dropout_is_identity(self)
         return super().forward(x, H, W, relative_pos)
 
 
@@ -100,6 +111,7 @@ class SRConvAttention(nn.Module):
         self.precision = precision
 
     def forward(self, x, H, W):
+        _dropout_is_identity(self)
         p = self.precision
         C = x.shape[-1]
         q = F.linear(x, self.q.weight, self.q.bias, precision=p)
@@ -145,6 +157,7 @@ class GlobalAttention(nn.Module):
         self.precision = precision
 
     def forward(self, x):
+        _dropout_is_identity(self)
         B, H, W, C = x.shape
         out, _, _ = _fused_qkv_attention(x.reshape(B, H * W, C), self.qkv, self.proj, self.num_heads, C // self.num_heads, self.scale,
                                          self.precision)
@@ -167,6 +180,7 @@ class Broad_Attention(nn.Module):
         self.precision = precision
 
     def forward(self, x):
+        _dropout_is_identity(self)
         B, N, _ = x.shape
         h, d = self.heads, self.dim_head
         proj = self.to_out[0] if isinstance(self.to_out, nn.Sequential) else None
@@ -210,6 +224,7 @@ class QKVSplitAttention(nn.Module):
         return F._derived_get(tuple(ps), ("qk_v_fused", dp), tag, build)
 
     def forward(self, x):
+        _dropout_is_identity(self)
         B, N, C = x.shape
         h = self.num_heads
         dq, dv = self.query_dim // h, C // h
@@ -242,6 +257,7 @@ class KNNAttention(nn.Module):
         self.precision = precision
 
     def forward(self, x):
+        _dropout_is_identity(self)
         B, N, C = x.shape
         if self.topk > N:
             raise RuntimeError(f"KNNAttention: topk {self.topk} > sequence length {N} (torch.topk raises as well)")
@@ -288,6 +304,7 @@ class ConvAttention(nn.Module):
         return cur
 
     def forward(self, x):
+        _dropout_is_identity(self)
         if self.training:
             raise RuntimeError("inference engine: BatchNorm runs with its running statistics; call .eval()")
         B, C, H, W = x.shape
@@ -321,6 +338,7 @@ class PoolingAttention(nn.Module):
         self.precision = precision
 
     def forward(self, x, H, W, d_convs=None):
+        _dropout_is_identity(self)
         B, N, C = x.shape
         p, h = self.precision, self.num_heads
         d = C // h

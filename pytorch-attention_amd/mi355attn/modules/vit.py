@@ -86,11 +86,11 @@ class Attention(nn.Module):
             return out if resid is None else F.axpby(out, torch.empty_like(out), out.numel() // out.shape[-1], out.shape[-1],
                                                      out.shape[-1], out.shape[-1], u=resid, ldu=out.shape[-1])
         if self.fast_ok():
-            p = F._prec(self.precision)                                                     # q/k/v/ctx stay 16-bit in HBM
-            x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
-            qkv16 = F.linear16(x16, F.weight16(self.qkv.weight, p), _bias(self.qkv), out16=True, precision=p)
-            ctx16 = self._core(qkv16, True)
-            return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, resid=resid, precision=p)
+            # q / k / v / ctx stay 16-bit in HBM; the whole block is ONE C call (mi355_mhsa_fwd: cast -> qkv GEMM -> core -> proj GEMM,
+            # the same kernels the three-call composition of rounds 1-2 launched)
+            p = F._prec(self.precision)
+            return F.mhsa16(x, F.weight16(self.qkv.weight, p), _bias(self.qkv), F.weight16(self.proj.weight, p), self.proj.bias,
+                            self.num_heads, self.scale, resid=resid, precision=p)
         qkv = F.linear(x, self.qkv.weight, _bias(self.qkv), precision=self.precision)      # (B,N,3C)
         ctx = self._core(qkv, False)                                                        # (B,N,C)
         return F.linear(ctx, self.proj.weight, self.proj.bias, resid=resid, precision=self.precision)

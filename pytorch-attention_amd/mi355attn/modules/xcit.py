@@ -131,20 +131,28 @@ class PositionalEncodingFourier(nn.Module):
         self._cache = {}
 
     def features(self, H, W):
-        """(H*W, 2*hidden_dim) rows of cat(pos_y, pos_x) exactly as xcit.py:57-74 computes them (batch-independent)."""
-        ones = torch.ones(1, H, W, dtype=torch.bool)
-        y_embed = ones.cumsum(1, dtype=torch.float32)
-        x_embed = ones.cumsum(2, dtype=torch.float32)
-        eps = 1e-6
-        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
-        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
-        dim_t = torch.arange(self.hidden_dim, dtype=torch.float32)
-        dim_t = self.temperature ** (2 * (dim_t // 2) / self.hidden_dim)
-        pos_x = x_embed[:, :, :, None] / dim_t
-        pos_y = y_embed[:, :, :, None] / dim_t
-        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        return torch.cat((pos_y, pos_x), dim=3).reshape(H * W, 2 * self.hidden_dim)
+        """(H*W, 2*hidden_dim) rows [pos_y | pos_x] of xcit.py:57-74, batch-independent.  Closed form of the reference's cumsum-of-mask
+        construction: pixel (i, j) has the normalised coordinates (i+1) / (H + 1e-6) * 2 pi and (j+1) / (W + 1e-6) * 2 pi; feature pair p
+        of an axis holds sin / cos of coordinate / temperature^(2p / hidden_dim).  Every step is the same fp32 operation the reference
+        performs (the sums of ones are exact integers), so the table matches it to the bit."""
+        f32 = torch.float32
+        half = self.hidden_dim // 2
+
+        def axis(n):                                              # (n, hidden_dim): [sin f0, cos f0, sin f1, cos f1, ...]
+            coord = torch.arange(1, n + 1, dtype=f32) / (torch.tensor(float(n), dtype=f32) + 1e-6) * self.scale
+            freq = self.temperature ** (2 * torch.arange(half, dtype=f32) / self.hidden_dim)
+            ang = coord[:, None] / freq[None, :]
+            out = torch.empty(n, 2 * half, dtype=f32)
+            out[:, 0::2], out[:, 1::2] = ang.sin(), ang.cos()
+            return out
+
+        if self.hidden_dim % 2:
+            raise ValueError("PositionalEncodingFourier: hidden_dim must be even (sin / cos pairs)")
+        fy, fx = axis(H), axis(W)
+        feat = torch.empty(H, W, 2 * self.hidden_dim, dtype=f32)
+        feat[:, :, :self.hidden_dim] = fy[:, None, :]
+        feat[:, :, self.hidden_dim:] = fx[None, :, :]
+        return feat.reshape(H * W, 2 * self.hidden_dim)
 
     def tokens(self, H, W):
         """Position rows (H*W, dim) = token_projection(features), the layout forward_features adds to the patch tokens."""
@@ -159,7 +167,10 @@ class PositionalEncodingFourier(nn.Module):
         return hit[1]
 
     def forward(self, B, H, W):
-        raise NotImplementedError("use tokens(H, W): the engine adds the encoding inside the last patch-embedding conv")
+        """xcit.py:56-77: the encoding as a (B, dim, H, W) map.  (XCiT itself uses tokens(H, W): the rows are added inside the last
+        patch-embedding conv.)  The batch axis is a broadcast view, as every image gets the same table."""
+        pos = self.tokens(H, W)                                            # (H*W, dim) on the device
+        return F.tokens_to_nchw(pos.reshape(1, H * W, self.dim), H, W).expand(B, -1, -1, -1)
 
 
 def conv3x3(in_channels, out_channels, stride=1):

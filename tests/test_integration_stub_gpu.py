@@ -24,6 +24,12 @@ def _lib():
     lib.mi355_bam_workspace_bytes.argtypes = [_i] * 5
     lib.mi355_bam_fwd.restype = _i
     lib.mi355_bam_fwd.argtypes = [_vp, _vp, _vp] + [_i] * 6 + [_vp, _sz, _vp]
+    lib.mi355_cast16_fwd.restype = _i
+    lib.mi355_cast16_fwd.argtypes = [_vp, _vp, _sz, _i, _vp]
+    lib.mi355_mhsa_workspace_bytes.restype = _sz
+    lib.mi355_mhsa_workspace_bytes.argtypes = [_i] * 4
+    lib.mi355_mhsa_fwd.restype = _i
+    lib.mi355_mhsa_fwd.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _sz, _vp]
     lib.mi355_last_error.restype = ctypes.c_char_p
     return lib
 
@@ -77,3 +83,36 @@ def test_bam_stub(_lib):
                                 torch.cuda.current_stream().cuda_stream)
     assert rc == 0, _lib.mi355_last_error().decode()
     assert float((y.cpu() - ref).norm() / ref.norm()) < 3e-5
+
+
+def test_mhsa_stub(_lib):
+    """Attention.forward (ViT.py:79-89) through mi355_mhsa_fwd with nothing but ctypes."""
+    from mi355attn.modules import Attention                 # parameter container with the reference's names
+    torch.manual_seed(1234)
+    m = Attention(768, 12, qkv_bias=True).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(3, 197, 768)
+    ref = O.vit_attention_forward(x, sd, 12)
+    m = m.cuda(); x = x.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def w16(w):
+        out = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+        assert _lib.mi355_cast16_fwd(w.detach().contiguous().data_ptr(), out.data_ptr(), w.numel(), 1, st) == 0
+        return out
+
+    B, N, C = x.shape
+    wqkv, wproj = w16(m.qkv.weight), w16(m.proj.weight)
+    y = torch.empty_like(x)
+    nws = _lib.mi355_mhsa_workspace_bytes(B, N, C, 0)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    rc = _lib.mi355_mhsa_fwd(x.data_ptr(), 0, wqkv.data_ptr(), m.qkv.bias.data_ptr(), wproj.data_ptr(), m.proj.bias.data_ptr(), None,
+                             y.data_ptr(), B, N, C, 12, float(m.scale), 1, ws.data_ptr(), nws, st)
+    assert rc == 0, _lib.mi355_last_error().decode()
+    err = float((y.cpu() - ref).norm() / ref.norm())
+    assert err < 1e-3, err
+    # too small a workspace is refused before anything is launched
+    rc = _lib.mi355_mhsa_fwd(x.data_ptr(), 0, wqkv.data_ptr(), None, wproj.data_ptr(), None, None, y.data_ptr(), B, N, C, 12, float(m.scale), 1,
+                             ws.data_ptr(), 1024, st)
+    assert rc == -1 and b"invalid argument" in _lib.mi355_last_error()

@@ -174,3 +174,146 @@ def test_split_k_gemm_stress_varying_inputs():
     finally:
         mi355attn.set_option("gemm_pa", 1)
         mi355attn.set_option("gemm_splitk", 1)
+
+
+# ---- boundary completion: the ViT attention block as one C call, helper classes on their own -------------------------------------
+@pytest.mark.parametrize("B,N,C,heads,x16", [(3, 197, 768, 12, True), (2, 197, 768, 12, False), (2, 50, 768, 4, True), (1, 300, 384, 6, False),
+                                             (2, 64, 128, 4, True)])
+def test_mhsa_block_entry_matches_composition_and_oracle(B, N, C, heads, x16):
+    """mi355_mhsa_fwd (one C call) against the three-call composition it replaces (bit-identical: the same kernels) and against the
+    oracle's ViT Attention forward (1e-3)."""
+    import oracle as O
+    from mi355attn import functional as F
+    from mi355attn.modules import Attention
+    torch.manual_seed(1234)
+    m = Attention(C, heads, qkv_bias=True).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(B, N, C)
+    resid = torch.randn(B, N, C)
+    ref = O.vit_attention_forward(x, sd, heads) + resid
+    m = m.cuda()
+    xd, rd = x.cuda(), resid.cuda()
+    p = F._prec(None)
+    xin = F.cast16(xd, p) if x16 else xd
+    with torch.no_grad():
+        y = m(xin, resid=rd)
+        y2 = m(xin, resid=rd)
+        x16t = xin if x16 else F.cast16(xd, p)
+        qkv16 = F.linear16(x16t, F.weight16(m.qkv.weight, p), m.qkv.bias, out16=True, precision=p)
+        ctx16 = m._core(qkv16, True)
+        yc = F.linear16(ctx16, F.weight16(m.proj.weight, p), m.proj.bias, resid=rd, precision=p)
+    assert torch.equal(y, y2)
+    assert torch.equal(y, yc), "block entry differs from the composition of its own kernels"
+    assert_parity(y.cpu(), ref, 1e-3, "mhsa block vs oracle")
+
+
+def test_mhsa_block_entry_rejects_bad_arguments():
+    from mi355attn import functional as F
+    x = torch.randn(2, 10, 96, device="cuda")                   # C % 64 != 0
+    w = torch.randn(288, 96, device="cuda").half()
+    wp = torch.randn(96, 96, device="cuda").half()
+    with pytest.raises(RuntimeError, match="mi355_mhsa_fwd"):
+        F.mhsa16(x, w, None, wp, None, 3, 0.1, precision=1)
+
+
+def _bn_randomise(mod):
+    with torch.no_grad():
+        for c in mod.modules():
+            if isinstance(c, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                c.running_mean.normal_(0, 0.3)
+                c.running_var.uniform_(0.5, 1.5)
+                c.weight.uniform_(0.5, 1.5)
+                c.bias.normal_(0, 0.2)
+
+
+@pytest.mark.parametrize("B,C,H,W,ks", [(2, 64, 32, 32, 7), (3, 20, 9, 13, 3), (1, 7, 5, 6, 5)])
+def test_triplet_helper_classes_stand_alone(B, C, H, W, ks):
+    """ZPool / BasicConv2d / AttentionGate forwards (triplet_attention.py:19-49) against the same math in torch on the CPU."""
+    from mi355attn.modules.axis import AttentionGate, BasicConv2d, ZPool
+    torch.manual_seed(7)
+    x = torch.randn(B, C, H, W)
+    z = ZPool()(x.cuda())
+    zr = torch.cat([x.mean(dim=1, keepdim=True), x.max(dim=1, keepdim=True)[0]], dim=1)
+    assert_parity(z.cpu(), zr, 1e-6, "ZPool")
+    g = AttentionGate(ks).eval()
+    _bn_randomise(g)
+    c = g.conv
+    with torch.no_grad():
+        gr = x * torch.sigmoid(torch.relu(c.bn(c.conv(zr))))
+        gy = g.cuda()(x.cuda())
+    assert_parity(gy.cpu(), gr, 2e-6, "AttentionGate")
+    bc = BasicConv2d(C, 12, ks).eval()
+    _bn_randomise(bc)
+    with torch.no_grad():
+        br = torch.relu(bc.bn(bc.conv(x)))
+        by = bc.cuda()(x.cuda())
+    assert by.shape == br.shape
+    assert_parity(by.cpu(), br, 5e-5, "BasicConv2d")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 32, 32), (3, 32, 9, 14)])
+def test_bam_gates_stand_alone(B, C, H, W):
+    """ChannelGate / SpatialGate forwards (bam.py:16-61) against the same math in torch on the CPU, and consistency with BAM.forward."""
+    from mi355attn.modules.axis import BAM
+    torch.manual_seed(9)
+    m = BAM(C).eval()
+    _bn_randomise(m)
+    x = torch.randn(B, C, H, W)
+    ch, sp = m.channel_attn, m.spatial_attn
+    with torch.no_grad():
+        cr = ch.bn(ch.mlp(x.mean(dim=(2, 3)))).view(B, C, 1, 1).expand_as(x)
+        sr = sp.bn(sp.conv3(sp.conv2(sp.conv1(x)))).expand_as(x)
+        yr = x + x * torch.sigmoid(cr + sr)
+        m = m.cuda()
+        cy = m.channel_attn(x.cuda())
+        sy = m.spatial_attn(x.cuda())
+        yy = m(x.cuda())
+    assert cy.shape == x.shape and sy.shape == x.shape
+    assert_parity(cy.cpu(), cr, 1e-5, "ChannelGate")
+    assert_parity(sy.cpu(), sr, 1e-4, "SpatialGate")
+    assert_parity(yy.cpu(), yr, 1e-5, "BAM")
+
+
+def test_fourier_position_encoding_forward():
+    """PositionalEncodingFourier.forward(B, H, W) (xcit.py:56-77) as a (B, dim, H, W) map against torch's conv on the engine's own
+    feature table (the table itself is pinned against the reference in tests/test_helper_modules.py)."""
+    from mi355attn.modules.xcit import PositionalEncodingFourier
+    torch.manual_seed(3)
+    m = PositionalEncodingFourier(hidden_dim=32, dim=96).eval()
+    B, H, W = 3, 14, 9
+    feat = m.features(H, W)
+    with torch.no_grad():
+        ref = m.token_projection(feat.reshape(1, H, W, 64).permute(0, 3, 1, 2)).expand(B, -1, -1, -1)
+        y = m.cuda()(B, H, W)
+    assert tuple(y.shape) == (B, 96, H, W)
+    assert_parity(y.cpu(), ref, 5e-5, "PositionalEncodingFourier.forward")
+
+
+def test_dropout_rates_do_not_change_an_eval_forward():
+    from mi355attn.modules import mhsa
+    torch.manual_seed(5)
+    a = mhsa.Attention(64, num_heads=2, qkv_bias=True).eval().cuda()
+    b = mhsa.Attention(64, num_heads=2, qkv_bias=True, attn_drop=0.3, proj_drop=0.1).eval().cuda()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 50, 64, device="cuda")
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
+    b.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        b(x)
+
+
+def test_relu_epilogue_of_the_fp32_engine():
+    from mi355attn import functional as F
+    torch.manual_seed(2)
+    x = torch.randn(300, 132, device="cuda")
+    w = torch.randn(72, 132, device="cuda") / 11
+    b = torch.randn(72, device="cuda")
+    y = F.linear(x, w, b, act=F.ACT_RELU, precision=F.PREC_STRICT)
+    ref = torch.relu(x.double().cpu() @ w.double().cpu().t() + b.double().cpu())
+    assert_parity(y.cpu(), ref.float(), 5e-5, "linear + relu")
+    xn = x.clone()
+    xn[3, 5] = float("nan")
+    yn = F.linear(xn, w, b, act=F.ACT_RELU, precision=F.PREC_STRICT)
+    assert torch.isnan(yn[3]).all() and not torch.isnan(yn[4]).any(), "relu must keep a NaN like torch.relu"
