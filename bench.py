@@ -11,6 +11,8 @@ Default workload "all" = every north-star target in ONE step (BASELINE.json conf
   C2  SELayer(256), CBAM(256), ECALayer(256)        x = (256,256,56,56) fp32                      HBM-bound
   C3  ViT Attention(768, heads 12)                  x = (256,197,768)                              MFMA-bound
   C4  CSWinBlock s1..s4, XCABlock(384,8), XCA       x = (256,3136,64) ... (256,49,512), (256,196,384)
+  +   DoubleAttention(64,32,32) @ (256,64,32,32), DoubleAttention(256,128,128) @ (256,256,56,56), MixerLayer(512,196) @ (256,196,512):
+      the remaining class-surface rows of north_star (no BASELINE config of their own; round 3)
   C5  VisionTransformer ViT-Base/16                 x = (256,3,224,224); logits all-gathered over RCCL when N > 1
 One "step" = one forward of each block over the per-GPU batch (inputs resident in HBM, H2D excluded).  `value` = images/s through
 the whole step, aggregated over all ranks (weak scaling: per-GPU batch fixed, batch-sharded, no data-path collective except the
@@ -44,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="all")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-strict", action="store_true", help="skip the per-block strict-mode (fp32-class) timing passes")
     ap.add_argument("--cpu-sample", type=int, default=None, help="override the per-block CPU-baseline sample size (images)")
     ap.add_argument("--chunk-images", type=int, default=None, help="override the Infinity-Cache chunk size")
     ap.add_argument("--nt", type=int, default=None, help="channel-attention final pass: bit0 NT loads, bit1 NT stores")
@@ -108,6 +111,37 @@ def _seeded(ctor, seed=1234):
     return ctor().eval()
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, the public header), first 16 hex digits: what a PMC traffic table was measured
+    against.  (The GPU box gets the tree without .git, so a commit id is not available there; the source hash is.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "pytorch-attention_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "pytorch-attention_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "mi355attn.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic():
+    """(block name -> bytes below L2 per forward, note).  profiles/pmc_traffic.json is produced by separate rocprofv3 --pmc passes
+    (tools/gpu_round3.sh) and stamped with csrc_fingerprint(); a table measured against other kernel sources is NOT relayed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}, "no profiles/pmc_traffic.json"
+    try:
+        tab = json.load(open(path))
+    except Exception as e:                                   # noqa: BLE001
+        return {}, "unreadable profiles/pmc_traffic.json: %s" % e
+    have, want = tab.get("_csrc_sha16"), csrc_fingerprint()
+    if have != want:
+        return {}, "stale: profiles/pmc_traffic.json was measured at csrc %s, this tree is %s -- traffic not reported" % (have, want)
+    return dict(tab.get("all", {})), "PMC FETCH_SIZE x 2 + WRITE_SIZE per block forward (separate rocprofv3 passes, tools/gpu_round3.sh) at csrc %s" % want
+
+
 # ------------------------------------------------------------------------------------------------------------
 # workloads: each returns dict(name, blocks, dtype); a block = dict(name, module, x, fwd_args, bound "hbm"|"mfma",
 #            work = algorithmic bytes or FLOPs per call, cpu(callable on a host sample), cpu_n, gather)
@@ -143,10 +177,12 @@ def workload_c2(B, dev):
 def workload_all(B, dev):
     """BASELINE.json configs[1..4] in one step: C2 + C3 + C4 + C5 (module docstring)."""
     import bench_workloads as W
-    parts = [workload_c2(B, dev), W.workload_c3(B, dev), W.workload_c4(B, dev), W.workload_c5(B, dev)]
+    parts = [workload_c2(B, dev), W.workload_c3(B, dev), W.workload_c4(B, dev), W.workload_da(B, dev), W.workload_mixer(B, dev),
+             W.workload_c5(B, dev)]
     blocks = [b for p in parts for b in p["blocks"]]
     return dict(name="north-star step: SELayer+CBAM+ECALayer (C2) + ViT Attention (C3) + CSWinBlock s1-s4 + XCABlock/XCA (C4) + "
-                     "ViT-Base/16 full forward with logits all-gather (C5), B=%d per GPU (BASELINE configs[1..4])" % B,
+                     "DoubleAttention x2 + MixerLayer (class-surface rows without a BASELINE config) + ViT-Base/16 full forward with "
+                     "logits all-gather (C5), B=%d per GPU (BASELINE configs[1..4])" % B,
                 blocks=blocks, dtype="f32/f16")
 
 
@@ -232,12 +268,13 @@ def main(argv=None):
     if args.precision is not None:
         mi355attn.set_default_precision(args.precision)
 
-    comm, gather_kind = None, "none (single rank)"
+    comm, gather_kind, comm_ok = None, "none (single rank)", False
     if dist is not None:
         gather_kind = "torch.distributed all_gather_into_tensor (RCCL)"
         if args.gather in ("auto", "capi"):
             comm, why = make_comm(dist, dev, rank, world)
             if comm is not None:
+                comm_ok = True
                 gather_kind = "mi355_allgather_f32 (RCCL behind the C ABI)"
             elif args.gather == "capi":
                 raise SystemExit("--gather capi: " + why)
@@ -280,40 +317,50 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # per-block durations with HIP events on the launch stream (un-timed extra passes)
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            for wk, tab in json.load(open(pmc_path)).items():
-                if isinstance(tab, dict):
-                    for bk, v in tab.items():
-                        pmc.setdefault(bk, v)
-        except Exception:
-            pmc = {}
-    per_block = []
-    for b in blocks:
+    pmc, pmc_note = load_pmc_traffic()
+
+    def time_block(b, reps):
         with torch.no_grad():
             run_block(b)
         torch.cuda.synchronize()
         tm = StreamTimer(dev)
         tm.start()
         with torch.no_grad():
-            for _ in range(args.steps):
+            for _ in range(reps):
                 run_block(b)
-        ms = tm.stop_ms() / args.steps
+        return tm.stop_ms() / reps
+
+    per_block = []
+    for b in blocks:
+        ms = time_block(b, args.steps)
         if b["bound"] == "hbm":
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
-        per_block.append(dict(block=b["name"], ms=round(ms, 4), images_per_s=round(args.batch / (ms * 1e-3), 1),
-                              bound=b["bound"], achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
-                              traffic=pmc.get(b["name"])))
+        rec = dict(block=b["name"], ms=round(ms, 4), images_per_s=round(args.batch / (ms * 1e-3), 1),
+                   bound=b["bound"], achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                   traffic=pmc.get(b["name"]))
+        if b.get("alt_work"):                                 # mixed blocks: the FLOP rate next to the HBM figure
+            rec["alt_achieved_TFLOPs"] = round(b["alt_work"] / (ms * 1e-3) / 1e12, 2)
+            rec["alt_frac_mfma"] = round(b["alt_work"] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        per_block.append(rec)
+    # the fp32-class cost of the MFMA blocks (precision 0: bf16 hi/lo split, three MFMAs per product): a few un-timed passes per block
+    if mi355attn.default_precision() != 0 and not args.no_strict and not args.only:
+        try:
+            mi355attn.set_default_precision(0)
+            for b, rec in zip(blocks, per_block):
+                if b["bound"] == "mfma" or b.get("alt_work"):
+                    rec["strict_ms"] = round(time_block(b, max(3, args.steps // 4)), 4)
+        finally:
+            mi355attn.set_default_precision(1 if args.precision is None else args.precision)
+    dominant = None if args.only else dominant_kernel_probe(blocks, dev, args)     # --only runs feed the PMC passes: block kernels only
 
     # achievable-bandwidth yardstick: float4 streaming copy of the same footprint
     copy_gbs = None
@@ -332,6 +379,14 @@ def main(argv=None):
             copy_gbs = round(2 * src.numel() * 4 / (cms * 1e-3) / 1e9, 1)
             del dst
 
+    rank_ms, ranks_seen = [round(local_elapsed / args.steps * 1e3, 4)], [rank]
+    if dist is not None:
+        ms_all = [None] * world
+        dist.all_gather_object(ms_all, (rank, round(local_elapsed / args.steps * 1e3, 4), torch.cuda.current_device()))
+        ranks_seen = sorted(r for r, _, _ in ms_all)
+        rank_ms = [m for _, m, _ in sorted(ms_all)]
+    if comm is not None:
+        comm.close()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -352,9 +407,14 @@ def main(argv=None):
                    "chunk_images": mi355attn.get_option("chunk_images"), "nt": mi355attn.get_option("nt"),
                    "reverse": mi355attn.get_option("reverse"),
                    "precision": {0: "strict(bf16x3)", 1: "fp16-mfma", 2: "bf16-mfma"}[mi355attn.default_precision()],
-                   "gather": gather_kind, "blocks": per_block, "stream_copy_GBps": copy_gbs},
+                   "gather": gather_kind, "ranks_seen": ranks_seen, "ms_per_step_by_rank": rank_ms,
+                   "rccl_self_test": ("passed on every rank" if comm_ok else ("not run (single rank)" if world == 1 else "FAILED or skipped: see gather")),
+                   "blocks": per_block, "stream_copy_GBps": copy_gbs, "traffic_source": pmc_note},
+        # `roofline` grades the slowest BLOCK of the step (a block is many launches: `block` names it); `dominant_kernel` is the one
+        # kernel that takes the largest share of that block, timed on its own in this process
         "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                     "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["block"], "ms": dom["ms"]},
+                     "frac": dom["frac"], "traffic": dom["traffic"], "block": dom["block"], "kernel": dom["block"], "ms": dom["ms"],
+                     "dominant_kernel": dominant},
     }
 
     if world == 1 and not args.no_cpu:
@@ -362,6 +422,47 @@ def main(argv=None):
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dominant_kernel_probe(blocks, dev, args):
+    """The single kernel that dominates the slowest block, on its own: when the step contains the ViT-Base forward that is the
+    persistent 256 x 256 GEMM with 16-bit output (gemm16_p8_kernel<f16, out16>: the qkv and fc1 launches, 24 of the 48 GEMM
+    launches and the largest share of the forward).  Each of its two shapes is launched back to back on synthetic operands of the
+    timed size and bracketed with HIP events on the launch stream: one launch = one kernel, so the interval / launches is the
+    kernel's average duration (the rocprofv3 table under profiles/ lists the same kernel; it must agree).  FLOPs = 2 M N K."""
+    import torch
+    import mi355attn
+    from mi355attn import StreamTimer
+    from mi355attn import functional as F
+    if not any(b["name"].startswith("VisionTransformer") for b in blocks) or mi355attn.default_precision() != 1:
+        return None
+    M = args.batch * 197
+    out, tot_flop, tot_ms, n = [], 0.0, 0.0, 0
+    for tag, N, K, gelu, per_fwd in (("qkv 2304x768", 2304, 768, False, 12), ("fc1 3072x768 + erf-GELU", 3072, 768, True, 12)):
+        torch.manual_seed(0)
+        x16 = torch.randn(M, K, device=dev).half()
+        w16 = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+        bias = torch.randn(N, device=dev)
+        act = F.ACT_GELU if gelu else F.ACT_NONE
+        for _ in range(3):
+            F.linear16(x16, w16, bias, act=act, out16=True, precision=1)
+        torch.cuda.synchronize()
+        tm = StreamTimer(dev)
+        tm.start()
+        reps = 20
+        for _ in range(reps):
+            F.linear16(x16, w16, bias, act=act, out16=True, precision=1)
+        ms = tm.stop_ms() / reps
+        flop = 2.0 * M * N * K
+        out.append({"shape": tag, "avg_us": round(ms * 1e3, 1), "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "launches_per_forward": per_fwd})
+        tot_flop += flop * per_fwd
+        tot_ms += ms * per_fwd
+        n += per_fwd
+    ach = tot_flop / (tot_ms * 1e-3) / 1e12
+    return {"name": "gemm16_p8_kernel<_Float16, out16=true> (csrc/gemm16_p8.hip)", "block": "VisionTransformer(ViT-Base/16, h12)",
+            "launches_per_forward": n, "avg_us": round(tot_ms / n * 1e3, 1), "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "shapes": out,
+            "source": "HIP events around 20 back-to-back launches per shape in this process (one launch = one kernel)"}
 
 
 def make_comm(dist, dev, rank, world):
@@ -393,38 +494,41 @@ def cpu_baseline(blocks, args):
     warm-up.  value = images/s through the same step = 1 / sum_b (t_b / n_b)."""
     import torch
     cores, threads, model = host_cpu_info()
-    # pick the torch thread count that is fastest on this host (all SMT threads is often NOT it on big dual-socket boxes)
-    probe = blocks[0]
-    n0 = min(args.cpu_sample or probe.get("cpu_n", 16), probe["x"].shape[0])
-    xs0 = probe["x"][:n0].cpu()
-    best_t, best_n = None, None
-    for nthr in sorted({min(threads, n) for n in (16, 32, 64, cores, threads)}):
-        torch.set_num_threads(nthr)
-        probe["cpu"](xs0)
-        t1 = time.perf_counter()
-        probe["cpu"](xs0)
-        dt = time.perf_counter() - t1
-        if best_t is None or dt < best_t:
-            best_t, best_n = dt, nthr
-    torch.set_num_threads(best_n)
-    per_image, reps, detail = 0.0, 3, []
+    # The torch thread count that is fastest differs per block on a big dual-socket host (all 128 cores suit the streaming channel
+    # attention, 16-32 the transformer blocks: with 128 threads ViT-Base ran 6x slower than with 32), so it is probed PER BLOCK:
+    # one pass per candidate count on the block's sample, then median of 3 at the best one.
+    cands = sorted({min(threads, n) for n in (16, 32, 64, cores)})
+    per_image, reps, detail, used = 0.0, 3, [], 0
     for b in blocks:
         ns = min(args.cpu_sample or b.get("cpu_n", 16), b["x"].shape[0])
         xs = b["x"][:ns].cpu()
+        torch.set_num_threads(cands[0])
         b["cpu"](xs)                                           # warm-up
-        ts = []
-        for _ in range(reps):
+        best_t, best_n = None, cands[0]
+        for nthr in cands:
+            torch.set_num_threads(nthr)
+            t1 = time.perf_counter()
+            b["cpu"](xs)
+            dt = time.perf_counter() - t1
+            if best_t is None or dt < best_t:
+                best_t, best_n = dt, nthr
+        torch.set_num_threads(best_n)
+        used = max(used, best_n)
+        ts = [best_t]
+        for _ in range(reps - 1):
             t1 = time.perf_counter()
             b["cpu"](xs)
             ts.append(time.perf_counter() - t1)
         ts.sort()
         per_image += ts[len(ts) // 2] / ns
-        detail.append({"block": b["name"], "images": ns, "images_per_s": round(ns / ts[len(ts) // 2], 1)})
-    return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+        detail.append({"block": b["name"], "images": ns, "threads": best_n, "images_per_s": round(ns / ts[len(ts) // 2], 1),
+                       "note": b.get("cpu_note", "oracle restatement (same math as the reference forward, not its exact operator sequence)")})
+    return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
             "host_cores": cores, "host_threads": threads, "host_cpu": model, "blocks": detail,
             "sample": "oracle (torch-CPU restatement of the reference forward; the reference checkout does not exist on the GPU box) "
                       "on the first n images of the same batch per block (n listed per block), median of %d after 1 warm-up, torch "
-                      "threads = cores field (fastest of a probe over thread counts), host has %d cores / %d hardware threads"
+                      "threads probed per block over {16, 32, 64, all cores} (listed per block; `cores` = the largest count used), host has "
+                      "%d cores / %d hardware threads"
                       % (reps, cores, threads)}
 
 

@@ -27,7 +27,8 @@ from .transformer import (layernorm, gelu, linear, vit_attention_forward, vit_ml
                           mixer_layer_forward, sdpa_core, mixer_forward, mhsa_forward, global_attention_forward,
                           broad_attention_forward, qk_v_attention_forward, knn_attention_forward, conv_attention_forward,
                           pooling_attention_forward)
-from .cswin import lepe_attention_forward, cswin_block_forward, window_token_index, cswin_forward
+from .cswin import (lepe_attention_forward, cswin_block_forward, window_token_index, cswin_forward,  # noqa: F401
+                    cswin_block_forward_aten, lepe_attention_forward_aten)
 from .xcit import (xca_forward, lpi_forward, xca_block_forward, xcit_forward, conv_patch_embed_forward, fourier_position_rows,
                    class_attention_block_forward)
 from .params import seeded_module_inputs, strip_prefix

@@ -131,3 +131,61 @@ def cswin_forward(img, p, embed_dim=64, depth=(1, 2, 21, 1), split_size=(1, 2, 7
                                     dtype=dtype)
     x = layernorm(x, _t(p["norm.weight"], dtype), _t(p["norm.bias"], dtype))
     return linear(x.mean(dim=1), _t(p["head.weight"], dtype), _t(p["head.bias"], dtype))
+
+
+# ---- the same block in the reference's ATen op sequence (bench.py's CPU leg) ----------------------------------------------------------
+def _windows(t, reso, H_sp, W_sp):
+    """(B, L, C) token-major image -> (B * nWin, T, C): the partition of img2windows (cswin.py:199-206) applied to token rows (the
+    reference goes through a (B, C, H, W) view first, :80-83; the row order inside a window and the window order are the same)."""
+    B, L, C = t.shape
+    return t.reshape(B, reso // H_sp, H_sp, reso // W_sp, W_sp, C).transpose(2, 3).reshape(-1, H_sp * W_sp, C)
+
+
+def _unwindows(w, B, reso, H_sp, W_sp):
+    """inverse of _windows: windows2img (cswin.py:208-216) in token-major form."""
+    C = w.shape[-1]
+    return w.reshape(B, reso // H_sp, reso // W_sp, H_sp, W_sp, C).transpose(2, 3).reshape(B, reso * reso, C)
+
+
+def lepe_attention_forward_aten(qkv, get_v_w, get_v_b, reso, idx, split_size, num_heads):
+    """LePEAttention.forward (cswin.py:101-127) with the operator sequence the reference executes on the CPU: strided window views +
+    one copy per operand, batched matmul, softmax, batched matmul, a grouped conv2d for LePE (get_lepe :86-99) -- instead of the
+    index tables of lepe_attention_forward above, which are easy to audit but cost ~2x on a CPU.  Same arithmetic, fp32."""
+    import torch.nn.functional as TF
+    _, B, L, C = qkv.shape
+    H_sp, W_sp = _stripe_shape(reso, idx, split_size)
+    T, d = H_sp * W_sp, C // num_heads
+    scale = d ** -0.5
+
+    def heads(t):                                                    # (B*nWin, T, C) -> (B*nWin, h, T, d)
+        return t.reshape(-1, T, num_heads, d).transpose(1, 2)
+
+    qw, kw, vw = (_windows(qkv[i], reso, H_sp, W_sp) for i in range(3))
+    vimg = vw.transpose(1, 2).reshape(-1, C, H_sp, W_sp)             # the window as a (C, H_sp, W_sp) image
+    lepe = TF.conv2d(vimg, get_v_w, get_v_b, stride=1, padding=1, groups=C)
+    lepe = lepe.reshape(-1, num_heads, d, T).transpose(2, 3)         # (B*nWin, h, T, d)
+    attn = torch.softmax((heads(qw) * scale) @ heads(kw).transpose(-2, -1), dim=-1)
+    out = attn @ heads(vw) + lepe
+    return _unwindows(out.transpose(1, 2).reshape(-1, T, C), B, reso, H_sp, W_sp)
+
+
+def cswin_block_forward_aten(x, p, reso, num_heads, split_size, last_stage=False):
+    """CSWinBlock.forward (cswin.py:176-197) on torch's fused CPU operators (layer_norm, linear, gelu) and
+    lepe_attention_forward_aten: what bench.py times as the CPU baseline of the CSWin blocks, so that the stand-in does not
+    understate the reference (the index-table form above ran at half the reference's speed at stage 1).  Checked against
+    cswin_block_forward in tests/test_oracle_golden.py."""
+    import torch.nn.functional as TF
+    B, L, C = x.shape
+    if reso == split_size:
+        last_stage = True
+    u = TF.layer_norm(x, (C,), p["norm1.weight"], p["norm1.bias"])
+    qkv = TF.linear(u, p["qkv.weight"], p.get("qkv.bias")).reshape(B, L, 3, C).permute(2, 0, 1, 3)
+    if last_stage:
+        att = lepe_attention_forward_aten(qkv, p["attns.0.get_v.weight"], p["attns.0.get_v.bias"], reso, -1, split_size, num_heads)
+    else:
+        half = C // 2
+        att = torch.cat([lepe_attention_forward_aten(qkv[..., :half], p["attns.0.get_v.weight"], p["attns.0.get_v.bias"], reso, 0, split_size, num_heads // 2),
+                         lepe_attention_forward_aten(qkv[..., half:], p["attns.1.get_v.weight"], p["attns.1.get_v.bias"], reso, 1, split_size, num_heads // 2)], dim=2)
+    x = x + TF.linear(att, p["proj.weight"], p["proj.bias"])
+    u = TF.layer_norm(x, (C,), p["norm2.weight"], p["norm2.bias"])
+    return x + TF.linear(TF.gelu(TF.linear(u, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])

@@ -48,22 +48,51 @@ class RcclComm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             buf = ctypes.create_string_buffer(box[0], 128)
         self._h = ctypes.c_void_p()
+        self._shape_checked = set()
         with torch.cuda.device(self.device):
             _ffi.check(_ffi.lib().mi355_comm_init(buf, 128, self.rank, self.world, ctypes.byref(self._h)), "mi355_comm_init")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):                                     # the ncclComm_t and the C handle are not garbage-collected by anybody else
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001  (interpreter shutdown: the library may be gone already)
+            pass
+
+    def _check_equal_shards(self, shape):
+        """ncclAllGather needs the same count on every rank: verified once per shape through the torch.distributed group (a host-side
+        object all-gather, outside any timed region: call sites warm up first)."""
+        if self.world == 1 or shape in self._shape_checked or not (dist.is_available() and dist.is_initialized()):
+            return
+        shapes = [None] * self.world
+        dist.all_gather_object(shapes, tuple(shape))
+        if any(s != tuple(shape) for s in shapes):
+            raise ValueError(f"RcclComm.all_gather: shard shapes differ across ranks: {shapes} (equal shards only; use gather_batch with "
+                             "global_batch for ragged batches)")
+        self._shape_checked.add(shape)
 
     def all_gather(self, y_local):
         """(n, ...) fp32 on every rank -> (world * n, ...) in rank order on every rank (equal shards)."""
         f = self._ffi
+        if not self._h:
+            raise RuntimeError("RcclComm.all_gather: communicator already closed")
         y_local = f.require_device_f32(y_local, "y_local")
+        self._check_equal_shards(tuple(y_local.shape))
         out = torch.empty((self.world * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=torch.float32, device=y_local.device)
         f.check(f.lib().mi355_allgather_f32(self._h, f.dptr(y_local), f.dptr(out), y_local.numel(), f.stream_ptr(y_local.device)),
                 "mi355_allgather_f32")
         return out
 
     def close(self):
-        if self._h:
-            self._ffi.check(self._ffi.lib().mi355_comm_destroy(self._h), "mi355_comm_destroy")
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._ffi.check(self._ffi.lib().mi355_comm_destroy(h), "mi355_comm_destroy")
 
 
 def gather_batch(y_local, global_batch=None, group=None, comm=None):

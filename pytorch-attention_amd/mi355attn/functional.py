@@ -451,7 +451,7 @@ def _ln_folded16(ln, lin, p):
     def build():
         w = lin.weight.detach()
         b = lin.bias.detach() if lin.bias is not None else torch.zeros(N, dtype=torch.float32, device=w.device)
-        b = b + w @ ln.bias.detach()
+        b = linear(ln.bias.detach().reshape(1, -1).contiguous(), w.contiguous(), b, precision=PREC_STRICT).reshape(-1)   # b + W ln.bias on the library's own engine (no vendor BLAS launch)
         return cast16((w * ln.weight.detach()[None, :]).contiguous(), p), b.contiguous()
 
     parts = [lin.weight] + ([] if lin.bias is None else [lin.bias]) + [ln.weight, ln.bias]
@@ -547,7 +547,7 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None, ctx16=None, proj=None
         w1 = fc1.weight.detach()
         b1 = fc1.bias.detach() if fc1.bias is not None else torch.zeros(Hd, dtype=torch.float32, device=w1.device)
         if ln is not None:
-            b1 = b1 + w1 @ ln.bias.detach()
+            b1 = linear(ln.bias.detach().reshape(1, -1).contiguous(), w1.contiguous(), b1, precision=PREC_STRICT).reshape(-1)    # b1 + W1 ln.bias, no vendor BLAS
             w1 = w1 * ln.weight.detach()[None, :]
         return cast16(w1.contiguous(), p), b1.contiguous()
 

@@ -147,3 +147,25 @@ def test_oracle_vs_live_reference_lepe_all_modes():
             ref = m(qkv)
         got = O.lepe_attention_forward(qkv, m.get_v.weight, m.get_v.bias, reso, idx, split, heads)
         assert rel_fro(got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("dim,reso,heads,split,last", [(64, 56, 2, 1, False), (128, 28, 4, 2, False), (256, 14, 8, 7, False), (512, 7, 16, 7, True),
+                                                     (32, 8, 2, 2, False), (64, 6, 2, 3, False)])
+def test_cswin_aten_sequence_restatement_equals_the_index_table_oracle(dim, reso, heads, split, last):
+    """bench.py times the CSWin CPU leg with the ATen-operator-sequence restatement (oracle/cswin.py cswin_block_forward_aten); it
+    must be the same function as the auditable index-table oracle the parity tests use."""
+    import oracle as O
+    torch.manual_seed(11)
+    C = dim
+    p = {"norm1.weight": torch.rand(C) + 0.5, "norm1.bias": torch.randn(C) * 0.1, "norm2.weight": torch.rand(C) + 0.5, "norm2.bias": torch.randn(C) * 0.1,
+         "qkv.weight": torch.randn(3 * C, C) / C ** 0.5, "qkv.bias": torch.randn(3 * C) * 0.1, "proj.weight": torch.randn(C, C) / C ** 0.5,
+         "proj.bias": torch.randn(C) * 0.1, "mlp.fc1.weight": torch.randn(4 * C, C) / C ** 0.5, "mlp.fc1.bias": torch.randn(4 * C) * 0.1,
+         "mlp.fc2.weight": torch.randn(C, 4 * C) / (4 * C) ** 0.5, "mlp.fc2.bias": torch.randn(C) * 0.1}
+    cb = C if (last or reso == split) else C // 2
+    for i in range(1 if (last or reso == split) else 2):
+        p[f"attns.{i}.get_v.weight"] = torch.randn(cb, 1, 3, 3) * 0.3
+        p[f"attns.{i}.get_v.bias"] = torch.randn(cb) * 0.1
+    x = torch.randn(3, reso * reso, C)
+    a = O.cswin_block_forward_aten(x, p, reso, heads, split, last)
+    b = O.cswin_block_forward(x, p, reso, heads, split, last)
+    assert rel_fro(a, b) <= 1e-6
