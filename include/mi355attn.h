@@ -38,6 +38,7 @@ extern "C" {
 #define MI355_EUNSUPPORTED -2
 #define MI355_EHIP         -3
 #define MI355_ESYNC        -4   /* an inter-workgroup exchange of an earlier launch timed out: see mi355_sync_status */
+#define MI355_ERANGE (-5)  /* a finite value saturated to inf in an fp16 operand tensor: mi355_range_status */
 
 #define MI355_PREC_STRICT 0
 #define MI355_PREC_FP16   1
@@ -101,6 +102,14 @@ int         mi355_workspace_forget(const void* ws, size_t ws_bytes);
  * the start of every later mi355_se_fwd / mi355_se_ex_fwd / mi355_cbam_fwd / gate call, which then fails instead of launching.
  * Launches also refuse shapes whose per-image workgroup set cannot be resident at once (they take the multi-pass kernels). */
 int         mi355_sync_status(void);
+/* fp16 range guard.  The default operand format (precision 1) is IEEE half: a finite fp32 value of magnitude >= 65520 becomes inf where
+ * the fp32 reference stays finite.  The producers of fp16 operand tensors -- mi355_cast16_fwd, mi355_layernorm16_fwd and every GEMM
+ * epilogue with a 16-bit output (mi355_linear16*_fwd, mi355_mhsa_fwd's qkv, the patch embedding) -- watch the magnitudes they convert
+ * and, on the first saturation, store a code into a pinned host word.  mi355_range_status() reads that word WITHOUT a device
+ * synchronisation: MI355_OK = nothing pending; MI355_ERANGE = some launch that has already executed produced inf from finite values
+ * (cleared by the report).  A host that wants certainty for a forward synchronises the stream first.  Remedy: run the module in
+ * precision 0 (strict: bf16 hi/lo split, fp32 range) or precision 2 (bf16).  bf16 operands are never flagged. */
+int         mi355_range_status(void);
 
 /* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
 

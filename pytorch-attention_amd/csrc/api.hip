@@ -123,6 +123,20 @@ unsigned* sync_err_word() {
     });
     return g_sync_word;
 }
+unsigned* range_word(hipStream_t st) {
+    if (!g_sync_word && stream_is_capturing(st)) return nullptr;          // never allocate pinned memory inside a capture
+    unsigned* w = sync_err_word();
+    return w ? w + 4 : nullptr;                                            // second quarter of the 64-byte pinned block
+}
+int range_pending(const char* who) {
+    unsigned* w = g_sync_word ? g_sync_word + 4 : nullptr;
+    if (!w || !__atomic_load_n(w, __ATOMIC_ACQUIRE)) return MI355_OK;
+    const unsigned code = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+    if (!code) return MI355_OK;
+    static const char* const names[] = {"?", "mi355_cast16_fwd", "mi355_layernorm16_fwd", "a 16-bit-output GEMM epilogue (mi355_linear16_fwd family)"};
+    return fail(MI355_ERANGE, "%s: an EARLIER launch of %s converted a finite value of magnitude >= 65520 to fp16: that tensor holds inf "
+                "where the fp32 reference is finite.  Run the module in precision 0 (strict) or 2 (bf16)", who, names[code < 4 ? code : 0]);
+}
 unsigned spin_limit() { return (unsigned)g_spin_limit.load(std::memory_order_relaxed); }
 int sync_pending(const char* who) {
     unsigned* w = sync_err_word();
@@ -293,6 +307,7 @@ long mi355_get_option(const char* key) {
 }
 
 int mi355_sync_status(void) { return mi355::sync_pending("mi355_sync_status"); }
+int mi355_range_status(void) { return mi355::range_pending("mi355_range_status"); }
 
 int mi355_event_time_begin(mi355_stream_t stream, void** handle) {
     MI355_CHECK_ARG(handle != nullptr);

@@ -37,6 +37,13 @@ long  opt_cbam_single();
 // exchange kernel -- and mi355_sync_status() -- looks at that word first and fails with MI355_ESYNC instead of returning OK over
 // garbage.  spin_limit() is the poll budget (option "spin_limit", default 1 << 22 sweeps ~ a second).
 unsigned* sync_err_word();            // device-visible pinned host word (null if the allocation failed: reporting falls back to the workspace word)
+// fp16 range guard (round 3): the producers of fp16 OPERAND tensors (mi355_cast16_fwd, mi355_layernorm16_fwd, the 16-bit-output GEMM
+// epilogues) keep the largest magnitude they convert; a finite value that saturates to inf in fp16 (|v| >= 65520) stores a code into
+// a second pinned host word.  mi355_range_status() reads it WITHOUT a device synchronisation (like mi355_sync_status); the Python
+// binding raises before the next 16-bit launch.  bf16 operands have the fp32 range and are not checked.  Null under hipGraph
+// capture when the word does not exist yet (hipHostMalloc is illegal there): the launch then runs unguarded.
+unsigned* range_word(hipStream_t st);
+int   range_pending(const char* who);  // MI355_OK or MI355_ERANGE (reported once)
 unsigned  spin_limit();
 int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
 int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
@@ -127,6 +134,15 @@ __device__ __forceinline__ float relu_nan(float v) {
     return ((__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u) ? v : r;
 }
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+// ---- fp16 range guard (device side): running |max| of the values a lane converts to fp16; v_max ignores NaN operands --------------
+typedef float rg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float rg_absmax4(float m, rg_f4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// 65520 = the smallest magnitude that rounds to inf in IEEE half; an inf that was already inf in fp32 is the input's, not ours
+__device__ __forceinline__ void rg_report(float m, unsigned* word, unsigned code) {
+    if (word && m >= 65520.0f && m < __builtin_inff()) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ float se_gate(float z, int kind) {
     if (!kind) return sigmoidf_(z);
     const float h = fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f;                    // relu6 clamps; torch's clamp keeps a NaN

@@ -15,6 +15,7 @@ struct G16Args {
     int tr_rows;        // TR kernels only: rows per image (see the TR epilogue)
     int resid_period;   // gemm16_p8 fp32 outputs only, >= 128: the residual is a (resid_period, ldc) table read at row m % resid_period
                         // (position rows of a patch embedding); 0 = one residual row per output row
+    unsigned* ovf;      // fp16 range guard word (common.h rg_report) or null; set by the entry points for 16-bit fp16 outputs
     const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
     float ln_eps;
 };

@@ -12,6 +12,7 @@
 // the DMA writes lane-linear; bank conflicts of the fragment reads are removed by an XOR swizzle applied on the SOURCE address
 // (chunk ^= row & 7) and again on the ds_read (cdna_hip_programming.md rule 21).  One LDS buffer + two barriers per K-step and
 // three resident workgroups per CU (24 waves) measured faster than double buffering at two workgroups per CU.
+#include <type_traits>
 #include "gemm16.h"
 
 namespace {
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
         float* Cf = static_cast<float*>(g.C);
         T* Ch = static_cast<T*>(g.C);
         const int l15 = lane & 15, g4 = (lane >> 4) * 4;
+        float rgmax = 0.f;                                     // fp16 range guard (common.h)
         f4 bias4[NF], gam4[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -179,210 +181,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
                 if (g.gamma) v = v * gam4[j];
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)mr * g.ldc + n);
                 if constexpr (OUT16) {
+                    if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);
                     *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
                 } else {
                     *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
                 }
             }
         }
+        if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report(rgmax, g.ovf, 3u);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Ping-pong schedule (variant 10): 256 x 256 x 64 tile, ONE workgroup of 8 waves per CU, 128 KB LDS = two whole K-tiles.
-// The two waves that share a SIMD (wave w and w+4: row groups wr = 0 / 1) run the same 8-slot program per K-tile, shifted by one
-// slot with an extra raw s_barrier, so that in every slot one of them feeds the matrix pipe (16 MFMAs = one 64 x 32 quadrant of
-// its 128 x 64 output over K = 64) while the other pulls its next fragments from LDS:
-//     slot        0      1      2      3      4      5      6            7
-//     group 0   R(A0,B0) M(q00) R(B1)  M(q01) R(A1)  M(q11) issue t+2    M(q10) + wait(t+1)
-//     group 1   M'(q10)  R(A0,B0) M(q00) R(B1) M(q01) R(A1) M(q11)+issue  wait(t+1)        (M' = previous tile)
-// LDS-DMA for tile t+2 is issued only after the barrier that closes slot 5 (the last ds_read of tile t's buffer, retired by an
-// explicit lgkmcnt(0) before that barrier), and tile t+1 is first read one slot after the counted vmcnt + barrier that
-// retires it (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it").  Raw s_barrier only:
-// __syncthreads() would drain the DMA queue.
-// ---------------------------------------------------------------------------------------------------------------------------
-// ABL: timing-only ablation mask for tuning experiments (results are WRONG when non-zero): 1 = no LDS fragment reads inside the
-// loop, 2 = no barriers inside the loop, 4 = no LDS-DMA inside the loop.
-template <typename T, bool OUT16, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm16_pp_kernel(const G16Args g) {
-    using v8 = typename Vec8<T>::t;
-    using v4 = typename Vec8<T>::t4;
-    constexpr int BM = 256, BN = 256;
-    constexpr int TILE = (BM + BN) * BK;                        // elements per K-tile buffer (64 KB)
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * TILE * 2];
-    T* lds = reinterpret_cast<T*>(lds_raw);
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = wave >> 2, wc = wave & 3;                    // 2 (M) x 4 (N) waves, 128 x 64 outputs each
-    const int tiles_n = (g.N + BN - 1) / BN;
-    int wg;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
-    const T* __restrict__ A = static_cast<const T*>(g.A);
-    const T* __restrict__ B = static_cast<const T*>(g.B);
-
-    // DMA sources: per K-tile every wave moves 4 x 8 rows of A and 4 x 8 rows of B (8 instructions of 1 KB)
-    const int lrow = lane >> 3, pch = lane & 7;
-    const int csw = (pch ^ lrow) * 8;
-    const T* a_src[4];
-    const T* b_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ma = m0 + (wave * 4 + i) * 8 + lrow; if (ma >= g.M) ma = g.M - 1;
-        int nb = n0 + (wave * 4 + i) * 8 + lrow; if (nb >= g.N) nb = g.N - 1;
-        a_src[i] = A + (long)ma * g.lda + csw;
-        b_src[i] = B + (long)nb * g.ldb + csw;
-    }
-    auto issue = [&](int buf, int k0) {
-        T* sA = lds + buf * TILE + (wave * 32) * BK;
-        T* sB = lds + buf * TILE + BM * BK + (wave * 32) * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sA + i * 8 * BK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sB + i * 8 * BK), 16, 0, 0);
-        }
-    };
-
-    f4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    v8 fa[4][2], fb[4][2];                                      // A: 4 m-frags x 2 k-halves (one 64-row half); B: 4 n-frags x 2
-
-    const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
-    const int off0 = ((fq ^ fsw) * 8), off1 = (((4 + fq) ^ fsw) * 8);
-    auto read_a = [&](int buf, int mh) {                        // rows wr*128 + mh*64 + i*16 + frow
-        const T* sA = lds + buf * TILE + (wr * 128 + mh * 64 + frow) * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i][0] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off0);
-            fa[i][1] = *reinterpret_cast<const v8*>(sA + i * 16 * BK + off1);
-        }
-    };
-    auto read_b = [&](int buf, int nh) {                        // cols wc*64 + nh*32 + j*16 + frow -> fb[nh*2 + j]
-        const T* sB = lds + buf * TILE + BM * BK + (wc * 64 + nh * 32 + frow) * BK;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fb[nh * 2 + j][0] = *reinterpret_cast<const v8*>(sB + j * 16 * BK + off0);
-            fb[nh * 2 + j][1] = *reinterpret_cast<const v8*>(sB + j * 16 * BK + off1);
-        }
-    };
-#define PP_MMA(MH, NH)                                                                                          \
-    do {                                                                                                        \
-        __builtin_amdgcn_s_setprio(1);                                                                          \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-                    acc[(MH) * 4 + i][(NH) * 2 + j] = mma16<T>(fb[(NH) * 2 + j][kk], fa[i][kk], acc[(MH) * 4 + i][(NH) * 2 + j]); \
-        __builtin_amdgcn_s_setprio(0);                                                                          \
-    } while (0)
-#define PP_BAR() do { if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } while (0)
-#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define PP_RA(B_, H_) do { if constexpr (!(ABL & 1)) read_a(B_, H_); } while (0)
-#define PP_RB(B_, H_) do { if constexpr (!(ABL & 1)) read_b(B_, H_); } while (0)
-#define PP_ISSUE(B_, K_) do { if constexpr (!(ABL & 4)) issue(B_, K_); } while (0)
-
-    const int nk = g.K / BK;
-    issue(0, 0);
-    if (nk > 1) {
-        issue(1, BK);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed, tile 1 may still fly
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    PP_BAR();
-    if (wr == 1) PP_BAR();                                      // one-slot shift of the second row group
-    if constexpr (ABL & 1) { read_a(0, 0); read_b(0, 0); read_b(0, 1); }
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 2 < nk;
-        // position 0: R(A0, B0)
-        PP_RA(cur, 0);
-        PP_RB(cur, 0);
-        PP_LGKM0();
-        PP_BAR();
-        // position 1: M(q00)
-        PP_MMA(0, 0);
-        PP_BAR();
-        // position 2: R(B1)
-        PP_RB(cur, 1);
-        PP_LGKM0();
-        PP_BAR();
-        // position 3: M(q01)
-        PP_MMA(0, 1);
-        PP_BAR();
-        // position 4: R(A1)      (last LDS read of this buffer by this wave; retired before the barrier)
-        PP_RA(cur, 1);
-        PP_LGKM0();
-        PP_BAR();
-        // position 5: M(q11)     group 1 is in global slot 6 here: buffer `cur` is free for every wave -> refill it
-        if (wr == 1 && more) PP_ISSUE(cur, (kt + 2) * BK);
-        PP_MMA(1, 1);
-        PP_BAR();
-        // position 6: (no reads) group 0 is in global slot 6: refill; group 1 is in slot 7: retire tile kt+1
-        if (wr == 0 && more) PP_ISSUE(cur, (kt + 2) * BK);
-        if (wr == 1) {
-            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        PP_BAR();
-        // position 7: M(q10)     group 0 is in slot 7: retire tile kt+1 before the closing barrier
-        PP_MMA(1, 0);
-        if (wr == 0) {
-            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        PP_BAR();
-    }
-    if (wr == 0) PP_BAR();                                      // balance the shift: every wave executed 8*nk + 2 barriers
-    PP_BAR();                                                   // everybody is done with the K-tile buffers
-#undef PP_MMA
-#undef PP_LGKM0
-#undef PP_RA
-#undef PP_RB
-#undef PP_ISSUE
-
-    // ---- epilogue straight from the accumulators (transposed MFMA tiles: lane = one row, 4 consecutive columns) -------------------
-    {
-        float* Cf = static_cast<float*>(g.C);
-        T* Ch = static_cast<T*>(g.C);
-        const int l15 = lane & 15, g4 = (lane >> 4) * 4;
-        f4 bias4[4], gam4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + g4;
-            bias4[j] = (g.bias && n < g.N) ? *reinterpret_cast<const f4*>(g.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
-            gam4[j] = (g.gamma && n < g.N) ? *reinterpret_cast<const f4*>(g.gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + l15;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + g4;
-                if (n >= g.N) continue;
-                f4 v = acc[i][j] + bias4[j];
-                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
-                if (g.gamma) v = v * gam4[j];
-                if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
-                if constexpr (OUT16) {
-                    *reinterpret_cast<v4*>(Ch + (long)m * g.ldc + n) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
-                } else {
-                    *reinterpret_cast<f4*>(Cf + (long)m * g.ldc + n) = v;
-                }
-            }
-        }
-    }
-#undef PP_BAR
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -475,6 +282,7 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
     const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7, l15 = frow, g4 = fq * 4;
     float* Cf = static_cast<float*>(g.C);
     T* Ch = static_cast<T*>(g.C);
+    float rgmax = 0.f;                                         // fp16 range guard over every 16-bit value this thread converts
 
     int mt = worker;
     if constexpr (LNA) {
@@ -536,6 +344,7 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
                         const int m = m0 + wr * TM + i * 16 + l15;
                         if (g.resid && m < g.M) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);
                     }
+                    if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);
                     *reinterpret_cast<v4*>(slab + l15 * SP + (((j * 2 + (fq >> 1)) ^ (l15 & 7)) * 8) + (fq & 1) * 4) =
                         v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
                 }
@@ -571,19 +380,27 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
         }
         }
     }
+    if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report(rgmax, g.ovf, 3u);
 }
 
 // fp32 -> 16-bit operand format, 8 elements per thread (2 x 16-B loads, 1 x 16-B store)
 template <typename T>
-__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, T* __restrict__ dst, long n8, long n) {
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, T* __restrict__ dst, long n8, long n, unsigned* ovf) {
     using v8 = typename Vec8<T>::t;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
+    float rgmax = 0.f;                                         // fp16 range guard (common.h): free in a bandwidth-bound pass
     for (; i < n8; i += stride) {
         const f4 a = reinterpret_cast<const f4*>(src)[2 * i], b = reinterpret_cast<const f4*>(src)[2 * i + 1];
+        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rg_absmax4(rgmax, a), b);
         reinterpret_cast<v8*>(dst)[i] = v8{(T)a.x, (T)a.y, (T)a.z, (T)a.w, (T)b.x, (T)b.y, (T)b.z, (T)b.w};
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = (T)src[n8 * 8 + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const float v = src[n8 * 8 + threadIdx.x];
+        if constexpr (std::is_same<T, _Float16>::value) rgmax = fmaxf(rgmax, fabsf(v));
+        dst[n8 * 8 + threadIdx.x] = (T)v;
+    }
+    if constexpr (std::is_same<T, _Float16>::value) rg_report(rgmax, ovf, 1u);
 }
 
 }  // namespace
@@ -596,8 +413,9 @@ int mi355_cast16_fwd(const float* src, void* dst16, size_t n, int precision, mi3
     const long n8 = (long)(n / 8);
     const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 + 1 : 4096);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (precision == MI355_PREC_FP16) cast16_kernel<_Float16><<<grid, 256, 0, st>>>(src, static_cast<_Float16*>(dst16), n8, (long)n);
-    else                              cast16_kernel<__bf16><<<grid, 256, 0, st>>>(src, static_cast<__bf16*>(dst16), n8, (long)n);
+    unsigned* ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
+    if (precision == MI355_PREC_FP16) cast16_kernel<_Float16><<<grid, 256, 0, st>>>(src, static_cast<_Float16*>(dst16), n8, (long)n, ovf);
+    else                              cast16_kernel<__bf16><<<grid, 256, 0, st>>>(src, static_cast<__bf16*>(dst16), n8, (long)n, ovf);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
@@ -622,6 +440,7 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
     G16Args g{};
     g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.gamma = gamma; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
+    if (out16 && precision == MI355_PREC_FP16) g.ovf = mi355::range_word(static_cast<hipStream_t>(stream));    // fp16 range guard
     return mi355::linear16_dispatch(g, out16, precision, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
@@ -634,7 +453,6 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
     long variant = mi355::opt_gemm_variant();
     if (g.resid_period) {
         if (K == 64 || K == 128 || out16 || !g.resid) return MI355_EUNSUPPORTED;
-        if (variant >= 10 && variant <= 14) variant = 7;
     }
     if (variant == 15) {                   // persistent 256 x 256 kernel (gemm16_p8.hip)
         const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
@@ -727,11 +545,6 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
             case 6: LAUNCH(T_, O_, 256, 128, 4, 2, true, 1); break;        \
             case 7: LAUNCH(T_, O_, 128, 256, 2, 4, true, 1); break;        \
             case 9: LAUNCH(T_, O_, 256, 64, 4, 1, true, 1); break;         \
-            case 10: gemm16_pp_kernel<T_, O_><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
-            case 11: gemm16_pp_kernel<T_, O_, 1><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
-            case 12: gemm16_pp_kernel<T_, O_, 2><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
-            case 13: gemm16_pp_kernel<T_, O_, 4><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
-            case 14: gemm16_pp_kernel<T_, O_, 7><<<cdiv(M, 256) * cdiv(N, 256), 512, 0, st>>>(g); break; \
             default: LAUNCH(T_, O_, 128, 128, 2, 2, false, 2); break;      \
         }                                                                  \
     } while (0)
@@ -780,6 +593,7 @@ int mi355_ln_linear16_fwd(const float* X, const void* W16, const float* bias, vo
     g.Af = X; g.B = W16; g.C = Y; g.bias = bias; g.ln_eps = eps;
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out16 && precision == MI355_PREC_FP16) g.ovf = mi355::range_word(st);
     int ncu = 256, dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

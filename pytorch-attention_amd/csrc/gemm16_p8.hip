@@ -27,6 +27,7 @@
 //   count themselves in on a per-tile word; chunk 0 polls that word (relaxed), acquires, adds the slabs and runs the normal
 //   epilogue -- N = 768 outputs (591 tiles on 256 CUs = 2.31 rounds) take 2.33 rounds instead of 3.  Without a workspace S = 1.
 #include <atomic>
+#include <type_traits>
 #include "gemm16.h"
 #include "bufops.h"
 
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float rgmax = 0.f;                                          // fp16 range guard over the 16-bit values this lane converts (common.h)
     v8 fa[4][2], fb[4][2];
     const int frow = lane & 15, fq = lane >> 4, fsw = lane & 7;
     const int off0 = ((fq ^ fsw) * 8), off1 = (((4 + fq) ^ fsw) * 8);
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                         f4 v = acc[i][j] + bias4[j];
                         if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
                         if (g.gamma) v = v * gam4[j];
+                        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);
                         *reinterpret_cast<v4*>(slab + l15 * 128 + (((j * 2 + (fq4 >> 1)) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8) =
                             v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
                     }
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
             __hip_atomic_store(pl.arrive + ((long)ch_tile_r * (pl.split - 1) + (ch_s - 1)) * 8 + wave,
                                ((unsigned long long)(~pl.tag) << 32) | pl.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report(rgmax, g.ovf, 3u);
     // barrier balance: 1 + 8 * total_kt + my_count per wave (group 1: prologue shift + (my_count - 1) re-shifts; group 0: my_count re-alignments)
 #undef P8_MMA
 #undef P8_BAR

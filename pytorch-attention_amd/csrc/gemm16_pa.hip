@@ -40,6 +40,7 @@
 //     K-tile 8    phase 0: C1(7); F(3)
 //   so a tile needs nk >= 10 K-tiles (K >= 640); the last tile of a workgroup drains serially.  bias == null / resid == null are
 //   descriptors with zero records (the loads return 0): no branch inside an MFMA interval, the counts stay static.
+#include <type_traits>
 #include "gemm16.h"
 #include "bufops.h"
 
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     const rsrc_t rs_c = make_rsrc(g.C, (bufops_u32)((long)g.M * g.ldc * (OUT16 ? 2 : 4)));
     const unsigned vo_bias = (unsigned)fq4 * 16u;                                         // lane part of the bias offsets
     const unsigned vo_row = (unsigned)(srow * g.ldc + sch * (OUT16 ? 8 : 4)) * (OUT16 ? 2u : 4u);   // lane part of the row-line offsets (C and resid)
+    float rgmax = 0.f;
     f4 eb0, eb1, eb2, eb3, er0, er1, es0, es1;                                            // bias (16-bit path: all four column tiles) / two residual sets in flight
     eb0 = eb1 = eb2 = eb3 = er0 = er1 = es0 = es1 = f4{0.f, 0.f, 0.f, 0.f};
     const unsigned sw_w16 = (unsigned)(l15 * 128 + (((fq4 >> 1) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8);   // column tile j: ^ (j * 32)
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // C (16-bit): one accumulator tile (row tile i, column tile j) -> slab, accumulator layout (lane = row l15, 4 columns fq4*4..)
     auto epi_c16 = [&](f4 a, f4 b, int j) {
         const f4 v = act4(a + b);
+        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);        // fp16 range guard (common.h)
         unsigned wa = sw_w16;
         asm volatile("" : "+v"(wa));                // keep the XOR at the use: four hoisted address registers would spill
         *reinterpret_cast<v4*>(slab + (wa ^ (unsigned)(j * 32))) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     if (wr == 0) PA_BAR();                                       // barrier balance: 1 + 4 * total_kt + 1 per wave
     if (my_count & 1) drain(acc0);
     else drain(acc1);
+    if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report(rgmax, g.ovf, 3u);
 #undef PA_BAR
 }
 

@@ -31,7 +31,8 @@ __device__ __forceinline__ void store4(OT* p, v4f v) {
 template <int LPR, int NV, typename OT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, OT* __restrict__ y, long rows, int cols,
-                                                       float eps) {
+                                                       float eps, unsigned* ovf) {
+    float rgmax = 0.f;                                  // fp16 range guard (common.h): a large LayerNorm gain can saturate the operand
     constexpr int RPW = 64 / LPR;                       // rows per wave
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -67,17 +68,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const int i = sub + LPR * j;
             if (i < n4) {
                 const v4f ww = reinterpret_cast<const v4f*>(w)[i], bb = reinterpret_cast<const v4f*>(b)[i];
-                store4<OT>(yr + 4 * i, (v[j] - mean) * rstd * ww + bb);
+                const v4f o = (v[j] - mean) * rstd * ww + bb;
+                if constexpr (std::is_same<OT, _Float16>::value) rgmax = rg_absmax4(rgmax, o);
+                store4<OT>(yr + 4 * i, o);
             }
         }
     }
+    if constexpr (std::is_same<OT, _Float16>::value) rg_report(rgmax, ovf, 2u);
 }
 
 // any width / alignment: three sweeps over the (cache-resident) row
 template <typename OT>
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ b, OT* __restrict__ y, long rows,
-                                                               int cols, float eps) {
+                                                               int cols, float eps, unsigned* ovf) {
+    float rgmax = 0.f;
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     for (long row = wave0; row < rows; row += nwaves) {
@@ -88,18 +93,24 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         float q = 0.f;
         for (int i = lane; i < cols; i += 64) { const float d = xr[i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
-        for (int i = lane; i < cols; i += 64) y[row * cols + i] = (OT)((xr[i] - mean) * rstd * w[i] + b[i]);
+        for (int i = lane; i < cols; i += 64) {
+            const float o = (xr[i] - mean) * rstd * w[i] + b[i];
+            if constexpr (std::is_same<OT, _Float16>::value) rgmax = fmaxf(rgmax, fabsf(o));
+            y[row * cols + i] = (OT)o;
+        }
     }
+    if constexpr (std::is_same<OT, _Float16>::value) rg_report(rgmax, ovf, 2u);
 }
 
 template <typename OT>
 int launch_ln(const float* x, const float* weight, const float* bias, OT* y, int rows, int cols, float eps, hipStream_t st) {
+    unsigned* ovf = std::is_same<OT, _Float16>::value ? mi355::range_word(st) : nullptr;
     const bool vec = (cols % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) && aligned16(bias);
 #define LN(LPR_, NV_)                                                                                                \
     do {                                                                                                             \
         const long waves = ((long)rows + (64 / LPR_) - 1) / (64 / LPR_);                                            \
         const int grid = (int)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);                                    \
-        layernorm_kernel<LPR_, NV_, OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);                \
+        layernorm_kernel<LPR_, NV_, OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps, ovf);                \
     } while (0)
     if (vec && cols <= 64)        LN(16, 1);
     else if (vec && cols <= 128)  LN(32, 1);
@@ -109,7 +120,7 @@ int launch_ln(const float* x, const float* weight, const float* bias, OT* y, int
     else if (vec && cols <= 2048) LN(64, 8);
     else {
         const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
-        layernorm_generic_kernel<OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps);
+        layernorm_generic_kernel<OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps, ovf);
     }
 #undef LN
     return MI355_OK;

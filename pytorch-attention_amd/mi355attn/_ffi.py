@@ -37,6 +37,7 @@ SIGNATURES = {
     "mi355_get_option": (ctypes.c_long, [ctypes.c_char_p]),
     "mi355_workspace_forget": (c_int, [c_vp, ctypes.c_size_t]),
     "mi355_sync_status": (c_int, []),
+    "mi355_range_status": (c_int, []),
     "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_se_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "mi355_se_ex_fwd": (c_int, [c_vp] * 6 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),
@@ -121,6 +122,10 @@ SIGNATURES = {
 
 class Mi355Error(RuntimeError):
     pass
+
+
+class Mi355RangeError(Mi355Error):
+    """A finite value saturated to inf in an fp16 operand tensor of an earlier launch (include/mi355attn.h mi355_range_status)."""
 
 
 def lib():

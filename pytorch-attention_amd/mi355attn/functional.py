@@ -48,6 +48,53 @@ def sync_status(wait=False):
     check(lib().mi355_sync_status(), "mi355_sync_status")
 
 
+def range_status(wait=False):
+    """Raise Mi355RangeError if a 16-bit producer (cast16, layernorm16, a GEMM epilogue with 16-bit output) that has ALREADY executed
+    converted a finite value of magnitude >= 65520 to fp16 -- the tensor then holds inf where the fp32 reference is finite
+    (mi355_range_status: a pinned host word, read without a device synchronisation).  `wait=True` synchronises first, so that the check
+    covers every launch issued so far.  bf16 and strict mode cannot overflow this way."""
+    if wait:
+        torch.cuda.synchronize()
+    code = lib().mi355_range_status()
+    if code != 0:
+        msg = lib().mi355_last_error()
+        raise _ffi.Mi355RangeError(f"fp16 range guard (code {code}): {msg.decode() if msg else '?'}")
+
+
+def _range_check():
+    """Before every launch of the 16-bit dataflow: report an overflow of any EARLIER launch now instead of computing on inf.
+    MI355_CHECK_RANGE=1 waits for the device first (debugging aid: the check then covers everything issued so far)."""
+    import os
+    range_status(wait=os.environ.get("MI355_CHECK_RANGE") == "1")
+
+
+def guarded_forward(module, *args, **kwargs):
+    """Run `module(*args)` in the package's default precision; if the fp16 range guard fires, warn and run it again in strict mode
+    (precision 0: bf16 hi / lo split, fp32 range and fp32-class accuracy at a third of the MFMA rate).  Synchronises the device once
+    per call -- a convenience for checkpoints with outlier activations, not the fast path."""
+    import warnings
+    try:
+        range_status(wait=True)                               # nothing pending from earlier work
+    except _ffi.Mi355RangeError:
+        pass
+    try:
+        y = module(*args, **kwargs)                           # a later launch of the same forward may already see the report
+        range_status(wait=True)
+        return y
+    except _ffi.Mi355RangeError as e:
+        warnings.warn(f"{type(module).__name__}: fp16 operands overflowed ({e}); re-running in strict mode", RuntimeWarning)
+    try:
+        range_status(wait=True)                               # launches of the abandoned forward that were still in flight may report too
+    except _ffi.Mi355RangeError:
+        pass
+    old = default_precision()
+    try:
+        set_default_precision(PREC_STRICT)
+        return module(*args, **kwargs)
+    finally:
+        set_default_precision(old)
+
+
 def _sync_check():
     """After every exchange-kernel launch: report a failure of any EARLIER launch now (the library does the same check before it
     launches).  MI355_CHECK_SYNC=1 waits for the device first -- a debugging aid that makes the check cover this very launch."""
@@ -489,6 +536,7 @@ def _require16(t, name, precision):
 
 def cast16(x, precision=None):
     """fp32 -> MFMA operand format (round-to-nearest-even), same shape."""
+    _range_check()
     x = require_device_f32(x, "x")
     y = torch.empty(x.shape, dtype=dtype16(precision), device=x.device)
     check(lib().mi355_cast16_fwd(dptr(x), dptr(y), x.numel(), _prec(precision), stream_ptr(x.device)), "mi355_cast16_fwd")
@@ -600,6 +648,7 @@ def ln_linear16(x, ln, lin, act=ACT_NONE, out16=True, precision=None):
 
 
 def layernorm16(x, weight, bias, eps=1e-5, precision=None):
+    _range_check()
     x = require_device_f32(x, "x")
     weight = require_device_f32(weight, "weight")
     bias = require_device_f32(bias, "bias")
@@ -612,6 +661,7 @@ def layernorm16(x, weight, bias, eps=1e-5, precision=None):
 
 def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=False, precision=None):
     """Y = resid + gamma * act(x16 @ w16^T + bias); 16-bit operands, fp32 or 16-bit result."""
+    _range_check()
     x16 = _require16(x16, "x16", precision)
     w16 = _require16(w16, "w16", precision)
     bias, gamma, resid = _opt(bias, "bias"), _opt(gamma, "gamma"), _opt(resid, "resid")
@@ -672,6 +722,7 @@ def weight16_padk(w, K, precision=None):
 
 def mhsa16(x, wqkv16, bqkv, wproj16, bproj, num_heads, scale, resid=None, precision=None):
     """ViT Attention.forward as one C call (mi355_mhsa_fwd): x (B,N,C) fp32 or already in the 16-bit operand format."""
+    _range_check()
     p = _prec(precision)
     x_is16 = x.dtype != torch.float32
     x = _require16(x, "x", p) if x_is16 else require_device_f32(x, "x")
