@@ -51,8 +51,12 @@ struct AttnPair {
 // 98 -> 6, 56 / 49 -> 3); their scores skip the key-validity mask (two of ~17 VALU instructions per score in a VALU-bound kernel).
 // -1 = unknown, every tile is masked.  (Eight key tiles with LePE need 88-96 registers: five workgroups per CU is what the allocator
 // reaches, so that is what is asked for; the build treats an unmet occupancy hint as an error.)
+#ifndef MI355_ATTN_FMA_SM
+#define MI355_ATTN_FMA_SM 1
+#endif
 template <int PREC, int D, int KT, bool LEPE, bool IO16, int NW, int OCC = 1, int TFULL = -1>
 __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair pr) {
+    constexpr bool FMA_SM = MI355_ATTN_FMA_SM != 0;
     // XCD-aware block order: hardware hands consecutive block ids to the 8 XCDs round-robin, but consecutive LOGICAL ids are the heads
     // of one window, whose q / k / v slices are adjacent 64-byte (d = 32) pieces of the same token rows -- neighbours that should
     // meet in one XCD's L2.  XCD k therefore works on the contiguous logical range [k * n/8, (k+1) * n/8) (bijective for any n).
@@ -236,13 +240,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                 }
             }
         }
+        f4 o[D / 16];
+        float sum;
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
         // S^T tiles: lane holds S^T[key = kt*16 + g*4 + r][q = l15]
         f4 s[KT];
-        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             f4 acc = zero4;                                       // first MFMA of the chain takes the constant as its C operand
-            if (kt * 16 < T) {
+            if (kt < TFULL || kt * 16 < T) {                     // kt < TFULL folds at compile time: no branch, constant C operand
 #pragma unroll
                 for (int ks = 0; ks < D / 32; ++ks) {
                     v8 kf[NS];
@@ -260,35 +266,62 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
         // bit-exact index tests rely on (one-hot attention must reproduce V rows exactly).
         const float post = (a.pre_scale ? 1.0f : a.scale) * 1.44269504088896340736f;
         float m = -INFINITY;
+        sum = 0.f;
+        if constexpr (PREC != 0 && FMA_SM) {
+            // fp16 / bf16 operand modes: maximum over the RAW scores (post > 0), then p = 2^(s * post - m * post) with ONE fma per score
+            // in front of the v_exp (the separate multiply pass is gone: 56 VALU instructions per query tile).  The row maximum maps to
+            // 2^(rounding residue of m * post) = 1 +- 1e-7 instead of exactly 1 -- invisible once P is rounded to 16 bit; the strict
+            // mode keeps the exact form for the bit-exact index tests.
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                const float v = (kt < TFULL || key < T) ? s[kt][r] * post : -INFINITY;      // kt < TFULL folds at compile time
-                s[kt][r] = v;
-                m = fmaxf(m, v);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16, WAVE));
-        m = fmaxf(m, __shfl_xor(m, 32, WAVE));
-        float sum = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + g * 4 + r;
+                    const float v = (kt < TFULL || key < T) ? s[kt][r] : -INFINITY;
+                    s[kt][r] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, WAVE));
+            m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+            const float mneg = -(m * post);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);      // 2^(-inf) = 0 for masked keys
-                s[kt][r] = p;
-                sum += p;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], post, mneg));     // fma(-inf, post, .) = -inf -> 0
+                    s[kt][r] = p;
+                    sum += p;
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + g * 4 + r;
+                    const float v = (kt < TFULL || key < T) ? s[kt][r] * post : -INFINITY;      // kt < TFULL folds at compile time
+                    s[kt][r] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, WAVE));
+            m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);      // 2^(-inf) = 0 for masked keys
+                    s[kt][r] = p;
+                    sum += p;
+                }
+        }
         sum += __shfl_xor(sum, 16, WAVE);
         sum += __shfl_xor(sum, 32, WAVE);
-        // O = P.V : A = P (row q = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = V^T same enumeration
-        f4 o[D / 16];
+        // O^T = V^T . P^T : A = V^T (row d = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = P^T, the S^T
+    // accumulators re-packed in-lane (column q = l15, same key enumeration) -> lane holds O[q = l15][d = nt*16 + g*4 + r]
 #pragma unroll
         for (int nt = 0; nt < D / 16; ++nt) o[nt] = zero4;
 #pragma unroll
         for (int kb = 0; kb < KT / 2; ++kb) {
-            if (kb * 32 < T) {
+            if (2 * kb < TFULL || kb * 32 < T) {                  // compile-time true for the full key tiles
                 v8 pf[NS];
                 {
                     const f4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
@@ -309,32 +342,33 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                         const v4 a1 = *reinterpret_cast<const v4*>(vr + 16);
                         vf[sp] = v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                     }
-                    o[nt] = mma_step<PREC>(pf, vf, o[nt]);
+                    o[nt] = mma_step<PREC>(vf, pf, o[nt]);      // O^T = V^T . P^T
                 }
             }
         }
-        // normalise: o[nt][r] belongs to query row g*4 + r, whose row sum lives in lanes with l15 == g*4 + r
-        float inv[4];
+        // normalise.  O was accumulated TRANSPOSED (O^T = V^T . P^T, below): lane (l15, g) holds O[query l15][channel nt*16 + g*4 + r],
+        // i.e. the accumulator rows are the rows of the softmax statistics -- the row sum is already in this lane (no shuffles), one
+        // reciprocal per lane, and a lane's four values are four consecutive channels of one token: one 8- / 16-byte slab write per
+        // tile (the query-major accumulator layout of rounds 1-2 needed 4 shuffles + 4 reciprocals + sixteen 2-byte writes here)
+        const float inv = __builtin_amdgcn_rcpf(sum);               // 1 ulp; the result is rounded to 16 bit or scaled once
+        // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo; tap offsets from s_tap
+        int off[LEPE ? 9 : 1];
+        bool qlive = false;
+        if constexpr (LEPE) {
+            const int qslot = qt * 16 + l15;
+            qlive = qslot < T;
+            const unsigned short* tp = s_tap + (qlive ? qslot : 0) * 9;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) inv[r] = __builtin_amdgcn_rcpf(__shfl(sum, g * 4 + r, WAVE));   // 1 ulp; the result is rounded to 16 bit or scaled once
+            for (int i = 0; i < 9; ++i) off[i] = tp[i];
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // locally-enhanced positional encoding: dw 3x3 over the (Hsp x Wsp) window image of V, zero halo; tap offsets from s_tap
-            int off[LEPE ? 9 : 1];
-            bool qlive = false;
+        for (int nt = 0; nt < D / 16; ++nt) {
+            f4 val = o[nt] * inv;
             if constexpr (LEPE) {
-                const int qslot = qt * 16 + g * 4 + r;
-                qlive = qslot < T;
-                const unsigned short* tp = s_tap + (qlive ? qslot : 0) * 9;
+                if (qlive) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) off[i] = tp[i];
-            }
-#pragma unroll
-            for (int nt = 0; nt < D / 16; ++nt) {
-                float val = o[nt][r] * inv[r];
-                if constexpr (LEPE) {
-                    if (qlive) {
-                        const int d = nt * 16 + l15;                              // channel inside this head
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = nt * 16 + g * 4 + r;                        // channel inside this head
                         const float* lwp = s_lw + d * 10;
                         const char* vrow = reinterpret_cast<const char*>(s_v + d * VP);
                         float acc = lwp[9];
@@ -344,12 +378,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                             if constexpr (NS == 2) vv += (float)(*reinterpret_cast<const el*>(vrow + V_EL * 2 + off[i]));
                             acc = __builtin_fmaf(lwp[i], vv, acc);
                         }
-                        val += acc;
+                        val[r] += acc;
                     }
                 }
-                if constexpr (IO16) *reinterpret_cast<el*>(slab + (g * 4 + r) * OP + nt * 16 + l15) = M_::cvt1(val);
-                else slab[(g * 4 + r) * OP + nt * 16 + l15] = val;
             }
+            if constexpr (IO16) *reinterpret_cast<v4*>(slab + l15 * OP + nt * 16 + g * 4) = M_::cvt(val);
+            else *reinterpret_cast<f4*>(slab + l15 * OP + nt * 16 + g * 4) = val;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Same-process A/B of two builds of libmi355attn.so on one op (box-to-box variance on the pool is 10-20 %, so cross-run comparisons of
+small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|xca16 [baseline.so]`.
+The baseline library defaults to tools/bin/libmi355attn_r2.so (built from the round-2 head in a scratch worktree)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-attention_amd"))
+import torch  # noqa: E402
+import mi355attn  # noqa: E402
+
+vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+op = sys.argv[1] if len(sys.argv) > 1 else "sdpa16"
+base = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tools", "bin", "libmi355attn_r2.so")
+libs = {"base": ctypes.CDLL(base), "new": ctypes.CDLL(mi355attn.LIB_PATH)}
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+torch.manual_seed(0)
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+if op == "sdpa16":
+    qkv = torch.randn(256, 197, 2304, device=dev).half()
+    outs = {}
+    def mk(lib, out):
+        lib.mi355_sdpa16_fwd.restype = ci
+        lib.mi355_sdpa16_fwd.argtypes = [vp, vp, ci, ci, ci, ci, cf, ci, vp]
+        return lambda: lib.mi355_sdpa16_fwd(qkv.data_ptr(), out.data_ptr(), 256, 197, 12, 64, 0.125, 1, st)
+    fns = {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty(256, 197, 768, device=dev, dtype=torch.float16)
+        fns[k] = mk(lib, outs[k])
+elif op in ("se", "cbam", "eca"):
+    x = torch.randn(256, 256, 56, 56, device=dev)
+    w1, w2 = torch.randn(16, 256, device=dev) / 16, torch.randn(256, 16, device=dev) / 4
+    wc = torch.randn(1, 2, 7, 7, device=dev) / 7
+    taps = torch.randn(5, device=dev)
+    outs, fns, wss = {}, {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty_like(x)
+        lib.mi355_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+        lib.mi355_set_option(b"ws_persistent", 1)
+        if op == "se":
+            lib.mi355_se_workspace_bytes.restype = sz; lib.mi355_se_workspace_bytes.argtypes = [ci] * 4
+            lib.mi355_se_fwd.restype = ci; lib.mi355_se_fwd.argtypes = [vp, vp, vp, vp] + [ci] * 5 + [vp, sz, vp]
+            n = lib.mi355_se_workspace_bytes(256, 256, 56, 56)
+            wss[k] = torch.zeros(n, dtype=torch.uint8, device=dev)
+            fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_se_fwd(x.data_ptr(), w1.data_ptr(), w2.data_ptr(), outs[k].data_ptr(), 256, 256, 16, 56, 56, wss[k].data_ptr(), n, st))
+        elif op == "cbam":
+            lib.mi355_cbam_workspace_bytes.restype = sz; lib.mi355_cbam_workspace_bytes.argtypes = [ci] * 4
+            lib.mi355_cbam_fwd.restype = ci; lib.mi355_cbam_fwd.argtypes = [vp] * 5 + [ci] * 7 + [vp, sz, vp]
+            n = lib.mi355_cbam_workspace_bytes(256, 256, 56, 56)
+            wss[k] = torch.zeros(n, dtype=torch.uint8, device=dev)
+            fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_cbam_fwd(x.data_ptr(), w1.data_ptr(), w2.data_ptr(), wc.data_ptr(), outs[k].data_ptr(), 256, 256, 16, 56, 56, 7, 0, wss[k].data_ptr(), n, st))
+        else:
+            lib.mi355_eca_workspace_bytes.restype = sz; lib.mi355_eca_workspace_bytes.argtypes = [ci] * 4
+            lib.mi355_eca_fwd.restype = ci; lib.mi355_eca_fwd.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, sz, vp]
+            n = lib.mi355_eca_workspace_bytes(256, 256, 56, 56)
+            wss[k] = torch.zeros(max(n, 256), dtype=torch.uint8, device=dev)
+            fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_eca_fwd(x.data_ptr(), taps.data_ptr(), outs[k].data_ptr(), 256, 256, 5, 56, 56, wss[k].data_ptr(), n, st))
+else:
+    raise SystemExit("unknown op " + op)
+
+for k, f in fns.items():
+    rc = f()
+    assert rc == 0, (k, rc)
+torch.cuda.synchronize()
+for rnd in range(4):
+    print("round", rnd, {k: round(timeit(f), 1) for k, f in fns.items()}, "us", flush=True)
+d = (outs["base"].float() - outs["new"].float()).abs()
+print("max abs diff", float(d.max()), "fraction of elements differing", float((d > 0).float().mean()))
