@@ -430,6 +430,15 @@ int    mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const flo
                      const float* bn_mean, const float* bn_var, float bn_eps, const float* w2, const float* b2,
                      const float* gamma, const float* resid, float* y, int B, int H, int W, int C,
                      void* ws, size_t ws_bytes, mi355_stream_t stream);
+/* The same block with the LayerNorm in front of it fused in (XCABlock.forward xcit.py:292: x + gamma3 * LPI(norm3(x))):
+ *   y = resid + gamma * LPI( LayerNorm(x; ln_w, ln_b, ln_eps) ).
+ * A row-statistics pass writes (mean, rstd) per token into the workspace (mi355_lpi_workspace_bytes), the stencil kernel normalises
+ * the rows as it parks them in LDS: the normalised tensor never exists in HBM; pass resid = x for the block's residual (the rows the
+ * kernel has just read).  Bit-identical to mi355_layernorm_fwd followed by mi355_lpi_fwd. */
+int    mi355_ln_lpi_fwd(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* w1, const float* b1,
+                        const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, const float* w2,
+                        const float* b2, const float* gamma, const float* resid, float* y, int B, int H, int W, int C, void* ws,
+                        size_t ws_bytes, mi355_stream_t stream);
 
 /* ViT PatchEmbedding + token assembly (ViT.py:101-105,183-185):
  *   tokens[b, p, :] = patch_p(img_b) . Wp^T + bp + pos[p]   for p < P = (H/ps)*(W/ps);

@@ -171,67 +171,101 @@ __global__ __launch_bounds__(256) void xca_kernel(const IT* __restrict__ qkv, co
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // LPI: workgroup = (image, 32 channels); 256 threads = 32 token lanes x 8 channel quads (16-byte LDS / HBM accesses).
+// Round 3: ONE LDS tile with a zero halo.  The first conv's results of a thread's (at most 8) tokens wait in registers until every
+// thread has read its 3x3 neighbourhoods, then overwrite the tile's interior in place -- 32 KB instead of 50 KB per workgroup at 14x14
+// (four to five workgroups per CU instead of three), and the stencils are nine unconditional 16-byte LDS reads + 36 FMAs per token
+// (the round-1 form tested every tap against the grid border and divided by W per token and conv).
+// Optional LayerNorm on the way in (XCABlock: x + gamma3 * LPI(norm3(x)), xcit.py:292): `stats` holds (mean, rstd) per token from
+// ln_stats_kernel, the rows are normalised as they are parked in LDS -- the normalised tensor never exists in HBM and the residual is
+// the very row the workgroup has just read.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int LPI_CG = 32;
+constexpr int LPI_TMAX = 8;      // tokens per thread (N <= 256)
 
-__global__ __launch_bounds__(256) void lpi_kernel(const float* __restrict__ x, const float* __restrict__ w1,
-                                                 const float* __restrict__ b1, const float* __restrict__ bn_w,
-                                                 const float* __restrict__ bn_b, const float* __restrict__ bn_m,
-                                                 const float* __restrict__ bn_v, float bn_eps, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, const float* __restrict__ gamma,
-                                                 const float* __restrict__ resid, float* __restrict__ y, int H, int W, int C,
-                                                 int groups) {
+__global__ __launch_bounds__(256, 4) void lpi_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ bn_w,
+                                                    const float* __restrict__ bn_b, const float* __restrict__ bn_m,
+                                                    const float* __restrict__ bn_v, float bn_eps, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                    const float* __restrict__ resid, float* __restrict__ y, int H, int W, int C,
+                                                    int groups, const float* __restrict__ stats, const float* __restrict__ ln_w,
+                                                    const float* __restrict__ ln_b) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int N = H * W;
-    float* s_x = smem;                 // [N][32]
-    float* s_m = smem + N * LPI_CG;    // [N][32] intermediate
+    const int N = H * W, PW = W + 2;
+    float* s_x = smem;                 // [(H+2)][(W+2)][32]: input tile with a zero halo (the stencils carry no bounds logic), then the intermediate
     const int t = threadIdx.x, cq = t & 7, tl = t >> 3;              // channel quad, token lane
     const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * LPI_CG + cq * 4;
     const bool vec = ((C & 3) == 0) && (c + 3 < C);                  // whole quad in range and 16-byte aligned rows
     const float* xb = x + (long)b * N * C;
     auto ldc = [&](const float* p, int cc, float dflt) { return cc < C ? p[cc] : dflt; };
-    for (int n = tl; n < N; n += 32) {
-        f4 v;
-        if (vec) v = *reinterpret_cast<const f4*>(xb + (long)n * C + c);
-        else v = f4{ldc(xb + (long)n * C, c, 0.f), ldc(xb + (long)n * C, c + 1, 0.f), ldc(xb + (long)n * C, c + 2, 0.f),
-                    ldc(xb + (long)n * C, c + 3, 0.f)};
-        *reinterpret_cast<f4*>(s_x + n * LPI_CG + cq * 4) = v;
-    }
-    auto tap = [&](const float* p, int ch, int i) { return ch < C ? p[(long)ch * 9 + i] : 0.f; };     // dw weight (C,3,3)
-    f4 k1[9], k2[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        k1[i] = f4{tap(w1, c, i), tap(w1, c + 1, i), tap(w1, c + 2, i), tap(w1, c + 3, i)};
-        k2[i] = f4{tap(w2, c, i), tap(w2, c + 1, i), tap(w2, c + 2, i), tap(w2, c + 3, i)};
-    }
     auto ld4 = [&](const float* p, float dflt) { return f4{ldc(p, c, dflt), ldc(p, c + 1, dflt), ldc(p, c + 2, dflt), ldc(p, c + 3, dflt)}; };
-    const f4 bias1 = ld4(b1, 0.f), bias2 = ld4(b2, 0.f);
-    const f4 mean = ld4(bn_m, 0.f), var = ld4(bn_v, 1.f), bw = ld4(bn_w, 0.f), bb = ld4(bn_b, 0.f);
-    const f4 rstd = f4{1.0f / sqrtf(var.x + bn_eps), 1.0f / sqrtf(var.y + bn_eps), 1.0f / sqrtf(var.z + bn_eps),
-                       1.0f / sqrtf(var.w + bn_eps)};
+    const f4 lw = stats ? ld4(ln_w, 0.f) : f4{1.f, 1.f, 1.f, 1.f}, lb = stats ? ld4(ln_b, 0.f) : f4{0.f, 0.f, 0.f, 0.f};
+    // this thread's tokens n = tl + 32 j and their cells in the padded tile
+    int cell[LPI_TMAX];
+    f4 v0[LPI_TMAX];
+#pragma unroll
+    for (int j = 0; j < LPI_TMAX; ++j) {
+        const int n = tl + 32 * j;
+        const int yy = n / W, xx = n - yy * W;
+        cell[j] = ((yy + 1) * PW + xx + 1) * LPI_CG + cq * 4;
+        v0[j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < N) {
+            if (vec) v0[j] = *reinterpret_cast<const f4*>(xb + (long)n * C + c);
+            else v0[j] = f4{ldc(xb + (long)n * C, c, 0.f), ldc(xb + (long)n * C, c + 1, 0.f), ldc(xb + (long)n * C, c + 2, 0.f),
+                            ldc(xb + (long)n * C, c + 3, 0.f)};
+            if (stats) {                                              // the expression of layernorm_kernel: same bits as the unfused LayerNorm
+                const float mean = stats[((long)b * N + n) * 2], rstd = stats[((long)b * N + n) * 2 + 1];
+                v0[j] = (v0[j] - mean) * rstd * lw + lb;
+            }
+        }
+    }
+    for (int q = t; q < (H + 2) * PW * (LPI_CG / 4); q += 256) reinterpret_cast<f4*>(s_x)[q] = f4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    auto conv = [&](const float* src, const f4* k, f4 bias, int n) {
-        const int yy = n / W, xx = n % W;
+#pragma unroll
+    for (int j = 0; j < LPI_TMAX; ++j)
+        if (tl + 32 * j < N) *reinterpret_cast<f4*>(s_x + cell[j]) = v0[j];
+    auto tap = [&](const float* p, int ch, int i) { return ch < C ? p[(long)ch * 9 + i] : 0.f; };     // dw weight (C,3,3)
+    auto taps = [&](const float* p, f4* k) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k[i] = f4{tap(p, c, i), tap(p, c + 1, i), tap(p, c + 2, i), tap(p, c + 3, i)};
+    };
+    auto conv = [&](const f4* k, f4 bias, int at) {                  // 3x3 around tile cell `at`: nine 16-byte LDS reads, no bounds logic
         f4 acc = bias;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int y2 = yy + dy, x2 = xx + dx;
-                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W)
-                    acc = acc + k[(dy + 1) * 3 + dx + 1] * *reinterpret_cast<const f4*>(src + (y2 * W + x2) * LPI_CG + cq * 4);
-            }
+            for (int dx = -1; dx <= 1; ++dx)
+                acc = acc + k[(dy + 1) * 3 + dx + 1] * *reinterpret_cast<const f4*>(s_x + at + (dy * PW + dx) * LPI_CG);
         return acc;
     };
-    for (int n = tl; n < N; n += 32) {
-        const f4 u = conv(s_x, k1, bias1, n);
-        const f4 v = gelu_fast4(u);   // |erf error| <= 1.5e-7, ~3x fewer instructions than erff
-        *reinterpret_cast<f4*>(s_m + n * LPI_CG + cq * 4) = (v - mean) * rstd * bw + bb;
+    f4 k[9];
+    taps(w1, k);
+    const f4 bias1 = ld4(b1, 0.f);
+    const f4 mean = ld4(bn_m, 0.f), var = ld4(bn_v, 1.f), bw = ld4(bn_w, 0.f), bb = ld4(bn_b, 0.f);
+    const f4 rstd = f4{1.0f / sqrtf(var.x + bn_eps), 1.0f / sqrtf(var.y + bn_eps), 1.0f / sqrtf(var.z + bn_eps),
+                       1.0f / sqrtf(var.w + bn_eps)};
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LPI_TMAX; ++j) {
+        if (tl + 32 * j < N) {
+            const f4 u = conv(k, bias1, cell[j]);
+            const f4 v = gelu_fast4(u);   // |erf error| <= 1.5e-7, ~3x fewer instructions than erff
+            v0[j] = (v - mean) * rstd * bw + bb;
+        }
     }
+    taps(w2, k);                          // the first conv's taps are dead: same registers
+    const f4 bias2 = ld4(b2, 0.f);
+    __syncthreads();                      // every neighbourhood of the input tile has been read
+#pragma unroll
+    for (int j = 0; j < LPI_TMAX; ++j)
+        if (tl + 32 * j < N) *reinterpret_cast<f4*>(s_x + cell[j]) = v0[j];
     __syncthreads();
     const f4 gm = gamma ? ld4(gamma, 1.f) : f4{1.f, 1.f, 1.f, 1.f};
-    for (int n = tl; n < N; n += 32) {
-        f4 v = conv(s_m, k2, bias2, n);
+#pragma unroll
+    for (int j = 0; j < LPI_TMAX; ++j) {
+        const int n = tl + 32 * j;
+        if (n >= N) continue;
+        f4 v = conv(k, bias2, cell[j]);
         const long o = ((long)b * N + n) * C + c;
         if (gamma) v = v * gm;
         if (vec) {
@@ -241,6 +275,36 @@ __global__ __launch_bounds__(256) void lpi_kernel(const float* __restrict__ x, c
             const float vv[4] = {v.x, v.y, v.z, v.w};
             for (int q = 0; q < 4; ++q)
                 if (c + q < C) y[o + q] = vv[q] + (resid ? resid[o + q] : 0.f);
+        }
+    }
+}
+
+// (mean, rstd) of every token row: the statistics of layernorm_kernel (two-pass, biased variance, eps inside the sqrt), one wave per
+// row; what the LayerNorm-fused LPI above normalises with.  Reads x once, writes 8 bytes per row.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, long rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const float inv = 1.0f / (float)cols;
+    const bool vec = (cols & 3) == 0;
+    for (long row = wave0; row < rows; row += nwaves) {
+        const float* xr = x + row * cols;
+        float s = 0.f, q = 0.f;
+        if (vec) {
+            const int n4 = cols >> 2;
+            for (int i = lane; i < n4; i += 64) { const f4 v = reinterpret_cast<const f4*>(xr)[i]; s += (v.x + v.y) + (v.z + v.w); }
+            const float mean = wave_sum(s) * inv;
+            for (int i = lane; i < n4; i += 64) {
+                const f4 d = reinterpret_cast<const f4*>(xr)[i] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+            const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);     // every lane takes part in the reduction
+            if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = r; }
+        } else {
+            for (int i = lane; i < cols; i += 64) s += xr[i];          // the expressions of layernorm_generic_kernel (true divisions)
+            const float mean = wave_sum(s) / (float)cols;
+            for (int i = lane; i < cols; i += 64) { const float d = xr[i] - mean; q += d * d; }
+            const float r = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+            if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = r; }
         }
     }
 }
@@ -297,7 +361,22 @@ int mi355_xca16_fwd(const void* qkv, int qkv_is16, const float* temperature, voi
 }
 
 
-size_t mi355_lpi_workspace_bytes(int, int, int, int) { return 16; }   // fully fused: no scratch needed
+size_t mi355_lpi_workspace_bytes(int B, int H, int W, int) {      // (mean, rstd) per token of the LayerNorm-fused form
+    if (B <= 0 || H <= 0 || W <= 0) return 16;
+    return (size_t)B * H * W * 2 * sizeof(float) + 16;
+}
+
+static int lpi_launch(const float* x, const float* w1, const float* b1, const float* bn_w, const float* bn_b, const float* bn_mean,
+                      const float* bn_var, float bn_eps, const float* w2, const float* b2, const float* gamma, const float* resid,
+                      float* y, int B, int H, int W, int C, const float* stats, const float* ln_w, const float* ln_b, hipStream_t st) {
+    if (H * W > 32 * LPI_TMAX) return mi355::fail(MI355_EUNSUPPORTED, "mi355_lpi_fwd: %dx%d token grid exceeds the LDS tile (<= 256 tokens)", H, W);
+    const size_t smem = (size_t)(H + 2) * (W + 2) * LPI_CG * sizeof(float);
+    const int groups = cdiv(C, LPI_CG);
+    lpi_kernel<<<B * groups, 256, smem, st>>>(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, H, W, C, groups,
+                                              stats, ln_w, ln_b);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
 
 int mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const float* bn_w, const float* bn_b, const float* bn_mean,
                   const float* bn_var, float bn_eps, const float* w2, const float* b2, const float* gamma, const float* resid,
@@ -305,13 +384,23 @@ int mi355_lpi_fwd(const float* x, const float* w1, const float* b1, const float*
     MI355_CHECK_ARG(x && w1 && b1 && bn_w && bn_b && bn_mean && bn_var && w2 && b2 && y);
     MI355_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0);
     (void)ws; (void)ws_bytes;
-    const size_t smem = (size_t)2 * H * W * LPI_CG * sizeof(float);
-    if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "mi355_lpi_fwd: %dx%d token grid exceeds the LDS tile (<= 256 tokens)", H, W);
-    const int groups = cdiv(C, LPI_CG);
-    lpi_kernel<<<B * groups, 256, smem, static_cast<hipStream_t>(stream)>>>(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2,
-                                                                            gamma, resid, y, H, W, C, groups);
-    MI355_LAUNCH_CHECK();
-    return MI355_OK;
+    return lpi_launch(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, B, H, W, C, nullptr, nullptr, nullptr,
+                      static_cast<hipStream_t>(stream));
+}
+
+int mi355_ln_lpi_fwd(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const float* w1, const float* b1,
+                     const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, const float* w2,
+                     const float* b2, const float* gamma, const float* resid, float* y, int B, int H, int W, int C, void* ws,
+                     size_t ws_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && ln_w && ln_b && w1 && b1 && bn_w && bn_b && bn_mean && bn_var && w2 && b2 && y && ws);
+    MI355_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0);
+    MI355_CHECK_ARG(ws_bytes >= mi355_lpi_workspace_bytes(B, H, W, C) && aligned16(ws) && aligned16(x));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* stats = static_cast<float*>(ws);
+    const long rows = (long)B * H * W;
+    const int grid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
+    ln_stats_kernel<<<grid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
+    return lpi_launch(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, B, H, W, C, stats, ln_w, ln_b, st);
 }
 
 }  // extern "C"

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mi355_xca16_fwd": (c_int, [c_vp, c_int, c_vp, c_vp] + [c_int] * 5 + [c_vp]),
     "mi355_lpi_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_lpi_fwd": (c_int, [c_vp] * 7 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp, c_size, c_vp]),
+    "mi355_ln_lpi_fwd": (c_int, [c_vp] * 3 + [c_float] + [c_vp] * 6 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp, c_size, c_vp]),
     "mi355_patch_embed_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
     "mi355_patch_embed_workspace_bytes": (c_size, [c_int] * 7),
     "mi355_patch_embed_ws_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp, c_size, c_vp]),

@@ -812,8 +812,9 @@ def xca_core(qkv, temperature, num_heads, precision=None, out16=False):
     return out
 
 
-def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None, resid=None):
-    """XCiT LPI on tokens x (B,N,C) with eval-mode BatchNorm; optional fused `resid + gamma * LPI(x)`."""
+def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None, resid=None, ln=None):
+    """XCiT LPI on tokens x (B,N,C) with eval-mode BatchNorm; optional fused `resid + gamma * LPI(x)`.  `ln` (an nn.LayerNorm): the
+    block becomes resid + gamma * LPI(ln(x)) with the normalisation applied on the way into the stencil kernel (mi355_ln_lpi_fwd)."""
     x = require_device_f32(x, "x")
     B, N, C = x.shape
     if N != H * W:
@@ -826,6 +827,12 @@ def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None
     y = torch.empty_like(x)
     n = lib().mi355_lpi_workspace_bytes(B, H, W, C)
     ws = workspace(n, x.device)
+    if ln is not None:
+        lw, lb = require_device_f32(ln.weight, "ln.weight"), require_device_f32(ln.bias, "ln.bias")
+        check(lib().mi355_ln_lpi_fwd(dptr(x), dptr(lw), dptr(lb), float(ln.eps), *[dptr(a) for a in pre], float(bn_eps),
+                                     *[dptr(a) for a in post], dptr(gamma), dptr(resid), dptr(y), B, H, W, C, dptr(ws), ws.numel(),
+                                     stream_ptr(x.device)), "mi355_ln_lpi_fwd")
+        return y
     check(lib().mi355_lpi_fwd(dptr(x), *[dptr(a) for a in pre], float(bn_eps), *[dptr(a) for a in post], dptr(gamma),
                               dptr(resid), dptr(y), B, H, W, C, dptr(ws), ws.numel(), stream_ptr(x.device)),
           "mi355_lpi_fwd")

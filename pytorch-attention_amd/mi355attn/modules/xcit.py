@@ -46,10 +46,11 @@ class LPI(nn.Module):
         self.bn = nn.BatchNorm2d(in_features)
         self.conv2 = nn.Conv2d(in_features, out_features, kernel_size=3, padding=1, groups=out_features)
 
-    def forward(self, x, H, W, gamma=None, resid=None):
+    def forward(self, x, H, W, gamma=None, resid=None, ln=None):
+        """`ln`: the LayerNorm in front of the block (XCABlock passes norm3 with the un-normalised x): fused into the kernel."""
         bn = self.bn
         return F.lpi(x, self.conv1.weight, self.conv1.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                     self.conv2.weight, self.conv2.bias, H, W, gamma=gamma, resid=resid)
+                     self.conv2.weight, self.conv2.bias, H, W, gamma=gamma, resid=resid, ln=ln)
 
 
 class XCA(nn.Module):
@@ -110,7 +111,7 @@ class XCABlock(nn.Module):
             x = self.attn(x, gamma=self.gamma1, resid=x, ln=self.norm1)               # LayerNorm fused into the qkv GEMM
         else:
             x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
-        x = self.local_mp(norm(self.norm3, x, False), H, W, gamma=self.gamma3, resid=x)
+        x = self.local_mp(x, H, W, gamma=self.gamma3, resid=x, ln=self.norm3)          # norm3 fused into the LPI kernel
         if fast and F.mlp_fused_ok(x.shape[-1], self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
             return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, gamma=self.gamma2, precision=p)   # LN2 + MLP + LayerScale + residual
         return self.mlp(norm(self.norm2, x, fast), gamma=self.gamma2, resid=x)

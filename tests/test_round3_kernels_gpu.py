@@ -506,3 +506,33 @@ def test_non_default_init_weights_vit_and_cswin():
         with torch.no_grad():
             y = m.cuda()(x.cuda())
         assert_parity(y.cpu(), ref, 1e-3, f"perturbed CSWinBlock{args}")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 14, 14, 384), (1, 7, 7, 40), (3, 4, 9, 100), (2, 16, 16, 128), (1, 1, 1, 32), (2, 5, 3, 30)])
+def test_ln_lpi_fused_is_bit_identical_to_layernorm_then_lpi(B, H, W, C):
+    """mi355_ln_lpi_fwd (row statistics + normalisation on the way into the stencil kernel) against mi355_layernorm_fwd followed by
+    mi355_lpi_fwd: the same expression per element, so the same bits; and against the oracle."""
+    import oracle as O
+    from mi355attn import functional as F
+    from mi355attn.modules import LPI
+    torch.manual_seed(C + H)
+    m = LPI(C).eval()
+    _bn_randomise(m)
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.2)
+    x = torch.randn(B, H * W, C) * 2 + 0.5
+    gamma = torch.rand(C) + 0.5
+    m, ln = m.cuda(), ln.cuda()
+    xd, gd = x.cuda(), gamma.cuda()
+    with torch.no_grad():
+        fused = m(xd, H, W, gamma=gd, resid=xd, ln=ln)
+        unfused = m(F.layernorm(xd, ln.weight, ln.bias, ln.eps), H, W, gamma=gd, resid=xd)
+        fused2 = m(xd, H, W, gamma=gd, resid=xd, ln=ln)
+    assert torch.equal(fused, fused2)
+    assert torch.equal(fused, unfused), "fused LayerNorm differs from layernorm -> lpi"
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    u = torch.nn.functional.layer_norm(x, (C,), ln.weight.cpu(), ln.bias.cpu(), ln.eps)
+    ref = x + gamma * O.lpi_forward(u, sd, H, W)
+    assert_parity(fused.cpu(), ref, 2e-5, "ln + lpi vs oracle")

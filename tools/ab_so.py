@@ -72,6 +72,22 @@ elif op in ("se", "cbam", "eca"):
             n = lib.mi355_eca_workspace_bytes(256, 256, 56, 56)
             wss[k] = torch.zeros(max(n, 256), dtype=torch.uint8, device=dev)
             fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_eca_fwd(x.data_ptr(), taps.data_ptr(), outs[k].data_ptr(), 256, 256, 5, 56, 56, wss[k].data_ptr(), n, st))
+elif op == "lpi":
+    B, H, W, C = 256, 14, 14, 384
+    x = torch.randn(B, H * W, C, device=dev)
+    w1, w2 = torch.randn(C, 1, 3, 3, device=dev) / 3, torch.randn(C, 1, 3, 3, device=dev) / 3
+    b1, b2, bw, bb, bm = (torch.randn(C, device=dev) * 0.1 for _ in range(5))
+    bv = torch.rand(C, device=dev) + 0.5
+    gm = torch.rand(C, device=dev)
+    outs, fns, wss = {}, {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty_like(x)
+        lib.mi355_lpi_fwd.restype = ci
+        lib.mi355_lpi_fwd.argtypes = [vp] * 7 + [cf] + [vp] * 5 + [ci] * 4 + [vp, sz, vp]
+        wss[k] = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_lpi_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), bw.data_ptr(), bb.data_ptr(), bm.data_ptr(), bv.data_ptr(),
+                                                          1e-5, w2.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), outs[k].data_ptr(), B, H, W, C,
+                                                          wss[k].data_ptr(), 1 << 20, st))
 else:
     raise SystemExit("unknown op " + op)
 
