@@ -76,6 +76,10 @@ bool   double_attn_fused_ok(int B, int C, int cm, int cn, int HW, int precision)
 size_t double_attn_fused_workspace(int B, int C, int HW);
 int    double_attn_fused(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV, const float* bV,
                          const float* wP, const float* bP, float* y, int B, int C, int HW, int precision, void* ws, hipStream_t st);
+// DoubleAttention in one kernel for c_m = c_n = 32, C = 64, H*W <= 1024 (double_attn_small.hip): the README / smoke-test shape class
+bool   double_attn_small_ok(int B, int C, int cm, int cn, int HW, int precision);
+int    double_attn_small(const float* x, const float* wA, const float* bA, const float* wB, const float* bB, const float* wV, const float* bV,
+                         const float* wP, const float* bP, float* y, int B, int C, int HW, int precision, hipStream_t st);
 // GEMM engine (gemm.hip), shared by the other translation units.  NT: B is (N,K) K-contiguous; KN: B is (K,N) N-contiguous.
 int gemm_nt(const float* A, const float* B, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
             int K, int lda, int ldb, int ldc, int act, int precision, hipStream_t st);

@@ -170,6 +170,9 @@ int mi355_double_attn_fwd(const float* x, const float* wA, const float* bA, cons
     MI355_CHECK_ARG(B > 0 && C > 0 && cm > 0 && cn > 0 && H > 0 && W > 0);
     MI355_CHECK_ARG(ws_bytes >= mi355_double_attn_ws_bytes(B, C, cm, cn, H, W, precision));
     const int HW = H * W, M3 = cm + 2 * cn;
+    if (mi355::opt_da_fused() != 0 && mi355::double_attn_small_ok(B, C, cm, cn, HW, precision) && aligned16(x) && aligned16(y) && aligned16(wA) &&
+        aligned16(wB) && aligned16(wV) && aligned16(bV))
+        return mi355::double_attn_small(x, wA, bA, wB, bB, wV, bV, wP, bP, y, B, C, HW, precision, static_cast<hipStream_t>(stream));
     if (mi355::double_attn_fused_ok(B, C, cm, cn, HW, precision) && aligned16(x) && aligned16(y) && aligned16(ws) && mi355::opt_da_fused() != 0)
         return mi355::double_attn_fused(x, wA, bA, wB, bB, wV, bV, wP, bP, y, B, C, HW, precision, ws, static_cast<hipStream_t>(stream));
     if ((HW & 3) || (C & 3) || (cm & 3) || (cn & 3) || !aligned16(x) || !aligned16(y) || !aligned16(ws))

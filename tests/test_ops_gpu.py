@@ -493,7 +493,8 @@ def test_lpi(B, H, W, C):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("B,C,cm,cn,H,W", [(2, 64, 32, 32, 32, 32), (2, 32, 16, 8, 8, 8), (1, 256, 128, 128, 14, 14), (3, 16, 4, 12, 6, 6)])
+@pytest.mark.parametrize("B,C,cm,cn,H,W", [(2, 64, 32, 32, 32, 32), (2, 32, 16, 8, 8, 8), (1, 256, 128, 128, 14, 14), (3, 16, 4, 12, 6, 6),
+                                          (3, 64, 32, 32, 8, 8), (1, 64, 32, 32, 16, 24), (5, 64, 32, 32, 4, 8), (2, 64, 32, 32, 8, 12)])   # one-kernel path (double_attn_small.hip): 2 .. 12 pixel groups, fewer groups than waves
 def test_double_attention(B, C, cm, cn, H, W, prec):
     from mi355attn.modules import DoubleAttention
     torch.manual_seed(C + cm)

@@ -536,3 +536,26 @@ def test_ln_lpi_fused_is_bit_identical_to_layernorm_then_lpi(B, H, W, C):
     u = torch.nn.functional.layer_norm(x, (C,), ln.weight.cpu(), ln.bias.cpu(), ln.eps)
     ref = x + gamma * O.lpi_forward(u, sd, H, W)
     assert_parity(fused.cpu(), ref, 2e-5, "ln + lpi vs oracle")
+
+
+@pytest.mark.parametrize("prec,tol", [(1, 1e-3), (2, 8e-3)])
+def test_double_attention_one_kernel_path_properties(prec, tol):
+    """double_attn_small.hip (c_m = c_n = 32, C = 64, H*W <= 1024): parity at the README shape in both operand types, run-to-run bit
+    identity, and batch independence (an image is one workgroup: its bits cannot depend on its neighbours)."""
+    import oracle as O
+    from mi355attn.modules import DoubleAttention
+    torch.manual_seed(1234)
+    m = DoubleAttention(64, 32, 32, precision=prec).eval()
+    sd = m.state_dict()
+    torch.manual_seed(4321)
+    x = torch.randn(6, 64, 32, 32)
+    ref = O.double_attention_forward(x, sd["convA.weight"], sd["convA.bias"], sd["convB.weight"], sd["convB.bias"],
+                                     sd["convV.weight"], sd["convV.bias"], sd["proj.weight"], sd["proj.bias"], torch.float64)
+    m = m.cuda()
+    with torch.no_grad():
+        y = m(x.cuda())
+        y2 = m(x.cuda())
+        y1 = m(x[3:4].cuda())
+    assert torch.equal(y, y2)
+    assert torch.equal(y[3:4], y1), "an image's result depends on the batch around it"
+    assert_parity(y.cpu(), ref.float(), tol, f"DoubleAttention(64,32,32) p{prec}")
