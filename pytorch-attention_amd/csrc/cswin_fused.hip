@@ -34,8 +34,31 @@ struct StripeArgs {
     int win_per_img;           // windows per image and branch (reso / split)
 };
 
-template <int PREC, int C, int TFULL = 0, int ABL = 0>
-__global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(const StripeArgs a) {
+
+// One LePE tap on eight channels: r += w * (float)nb.  fp16: v_fma_mix_f32 reads the packed 16-bit neighbour values as they are
+// (hipcc otherwise converts all eight and pairs the products into half-rate v_pk_fma_f32: 2 x the issue slots); same arithmetic.
+template <int PREC, typename V8>
+__device__ __forceinline__ void lepe_tap(f4& r0, f4& r1, const V8 nb, const f4 w0, const f4 w1) {
+    if constexpr (PREC == 1) {
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t p = __builtin_bit_cast(u32x4_t, nb);
+#define MI355_MIX(acc, pk, wt)                                                                                             \
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.x) : "v"(pk.x), "v"(wt.x));           \
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.y) : "v"(pk.x), "v"(wt.y));           \
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.z) : "v"(pk.y), "v"(wt.z));           \
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.w) : "v"(pk.y), "v"(wt.w));
+        struct { unsigned x, y; } lo{p.x, p.y}, hi{p.z, p.w};
+        MI355_MIX(r0, lo, w0)
+        MI355_MIX(r1, hi, w1)
+#undef MI355_MIX
+    } else {
+        r0 = __builtin_elementwise_fma(w0, f4{(float)nb[0], (float)nb[1], (float)nb[2], (float)nb[3]}, r0);
+        r1 = __builtin_elementwise_fma(w1, f4{(float)nb[4], (float)nb[5], (float)nb[6], (float)nb[7]}, r1);
+    }
+}
+
+template <int PREC, int C, int TFULL = 0, bool L1D = false, int OCC = (C == 64 ? 3 : 2), bool LWREG = true, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
     using v4 = typename M_::v4;
@@ -85,8 +108,27 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
     // LePE constants of this lane: it stores query row wave*16 + lane/4, channels (lane & 3)*8 + [0,8) of every window
     const int sr = lane >> 2, sc8 = (lane & 3) * 8;
     const int myslot = wave * 16 + sr;
-    int tapoff[9];                                                 // element offset of the neighbour's row in s_vt (zero row outside the window)
-    {
+    // L1D (split == 1: the stripes are one token wide, CSWin stage 1): six of the nine taps fall outside the window for EVERY token,
+    // the other three are the slots before / at / after the token in both branches (branch 0: taps (dy, 0) = 1, 4, 7; branch 1:
+    // taps (0, dx) = 3, 4, 5).  Three LDS rows instead of nine and the 24 tap weights of a lane live in registers.
+    constexpr int NTAP = L1D ? 3 : 9;
+    int tapoff[NTAP];                                              // element offset of the neighbour's row in s_vt (zero row outside the window)
+    f4 lw0[L1D && LWREG ? 3 : 1], lw1[L1D && LWREG ? 3 : 1];       // L1D: tap weights of channels sc8 + [0,4) / + [4,8)
+    int tap0 = 0, tapstep = 1;
+    if constexpr (L1D) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sl = myslot + j - 1;
+            tapoff[j] = ((myslot < T && sl >= 0 && sl < T) ? sl : TK) * QP + sc8;
+            const int tap = br == 0 ? 1 + 3 * j : 3 + j;
+            if constexpr (LWREG) {
+                const float* wsrc = a.lw[br] + (long)(head * D + sc8) * 9 + tap;
+                lw0[j] = f4{wsrc[0], wsrc[9], wsrc[18], wsrc[27]};
+                lw1[j] = f4{wsrc[36], wsrc[45], wsrc[54], wsrc[63]};
+            }
+        }
+        tap0 = br == 0 ? 1 : 3; tapstep = br == 0 ? 3 : 1;
+    } else {
         const int ty = myslot / Wsp, tx = myslot - ty * Wsp;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -166,7 +208,11 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
             for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const v8*>(s_xn + (wave * 16 + l15) * WP + ks * 32 + g * 8);
 #pragma unroll
             for (int ft = 0; ft < 6; ++ft) {
-                f4 acc = zero4;
+                // the bias is the initial value of the accumulator (no separate add): q / k tiles hold features g*4 + r of token l15,
+                // v tiles feature l15 of tokens g*4 + r
+                const f4 brow = *reinterpret_cast<const f4*>(s_bias + ft * 16 + g * 4);
+                const float bcol = s_bias[ft * 16 + l15];
+                f4 acc = ft < 4 ? brow : f4{bcol, bcol, bcol, bcol};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const v8 wf = wfr[ft][ks];
@@ -174,22 +220,20 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
                     else        acc = M_::mma(xf[ks], wf, acc);    // v:    rows = tokens,   columns = features
                 }
                 if (ft < 4) {
-                    const f4 bb = *reinterpret_cast<const f4*>(s_bias + ft * 16 + g * 4);
-                    f4 v = acc + bb;
+                    f4 v = acc;
                     if (ft < 2) v = v * a.scale;                   // cswin.py:116: q * scale before the product
                     const v4 h = M_::cvt(v);
                     unsigned short* dst = (ft < 2 ? s_q : s_k) + (wave * 16 + l15) * QP + (ft & 1) * 16 + g * 4;
                     *reinterpret_cast<v4*>(dst) = h;
                 } else {
-                    const float bb = s_bias[ft * 16 + l15];
-                    const v4 h = M_::cvt(acc + bb);
+                    const v4 h = M_::cvt(acc);
                     *reinterpret_cast<v4*>(s_v + ((ft - 4) * 16 + l15) * VP + wave * 16 + g * 4) = h;
                     // the same tile token-major for LePE (second orientation of the product: the matrix pipe has room)
-                    f4 acc2 = zero4;
+                    f4 acc2 = brow;
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc2 = M_::mma(wfr[ft][ks], xf[ks], acc2);
-                    const v4 h2 = M_::cvt(acc2 + *reinterpret_cast<const f4*>(s_bias + ft * 16 + g * 4));
+                    const v4 h2 = M_::cvt(acc2);
                     *reinterpret_cast<v4*>(s_vt + (wave * 16 + l15) * QP + (ft - 4) * 16 + g * 4) = h2;
                 }
             }
@@ -209,29 +253,34 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
                     s[kt] = M_::mma(kf, qf, s[kt]);
                 }
             }
+            // softmax over the keys of query l15 (rows g*4 + r of the four key tiles): the maximum is taken over the raw scores and
+            // log2(e) rides in the FMA that forms the exponent (attn.hip)
             float m = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + g * 4 + r;
-                    const float v = (kt < TFULL || key < T) ? s[kt][r] * L2E : -INFINITY;      // kt < TFULL folds at compile time
+                    const float v = (kt < TFULL || key < T) ? s[kt][r] : -INFINITY;            // kt < TFULL folds at compile time
                     s[kt][r] = v;
                     m = fmaxf(m, v);
                 }
             m = fmaxf(m, __shfl_xor(m, 16, WAVE));
             m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+            const float nm = -(m * L2E);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], L2E, nm));
                     s[kt][r] = p;
                     sum += p;
                 }
             sum += __shfl_xor(sum, 16, WAVE);
             sum += __shfl_xor(sum, 32, WAVE);
+            // O^T = V^T P^T: the accumulator of a lane holds features nt*16 + g*4 + r of query l15 -- the query its softmax
+            // statistics belong to, so the normaliser needs no exchange and a lane's four features leave as one 16-byte write
             f4 o[2] = {zero4, zero4};
 #pragma unroll
             for (int kb = 0; kb < KT / 2; ++kb) {
@@ -242,17 +291,13 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
                     for (int nt = 0; nt < 2; ++nt) {
                         const unsigned short* vr = s_v + (nt * 16 + l15) * VP + kb * 32 + g * 4;
                         const v4 a0 = *reinterpret_cast<const v4*>(vr), a1 = *reinterpret_cast<const v4*>(vr + 16);
-                        o[nt] = M_::mma(pf, v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, o[nt]);
+                        o[nt] = M_::mma(v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pf, o[nt]);
                     }
                 }
             }
-            float inv[4];
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) inv[r] = __builtin_amdgcn_rcpf(__shfl(sum, g * 4 + r, WAVE));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(g * 4 + r) * OP + nt * 16 + l15] = o[nt][r] * inv[r];
+            for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f4*>(slab + l15 * OP + nt * 16 + g * 4) = o[nt] * inv;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (myslot < T) {                                       // 64-byte head rows: 4 lanes per row, 16 rows per instruction
@@ -264,11 +309,15 @@ __global__ __launch_bounds__(256, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(co
                     r0 = r0 + bz0;
                     r1 = r1 + bz1;
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
+                    for (int tap = 0; tap < NTAP; ++tap) {
                         const v8 nb = *reinterpret_cast<const v8*>(s_vt + tapoff[tap]);
-                        const f4 w0 = *reinterpret_cast<const f4*>(s_lwt + tap * D + sc8), w1 = *reinterpret_cast<const f4*>(s_lwt + tap * D + sc8 + 4);
-                        r0 = __builtin_elementwise_fma(w0, f4{(float)nb[0], (float)nb[1], (float)nb[2], (float)nb[3]}, r0);
-                        r1 = __builtin_elementwise_fma(w1, f4{(float)nb[4], (float)nb[5], (float)nb[6], (float)nb[7]}, r1);
+                        f4 w0, w1;
+                        if constexpr (L1D && LWREG) { w0 = lw0[tap]; w1 = lw1[tap]; }
+                        else if constexpr (L1D) {
+                            const float* wr = s_lwt + (tap0 + tap * tapstep) * D + sc8;
+                            w0 = *reinterpret_cast<const f4*>(wr); w1 = *reinterpret_cast<const f4*>(wr + 4);
+                        } else { w0 = *reinterpret_cast<const f4*>(s_lwt + tap * D + sc8); w1 = *reinterpret_cast<const f4*>(s_lwt + tap * D + sc8 + 4); }
+                        lepe_tap<PREC>(r0, r1, nb, w0, w1);
                     }
                 }
                 const v4 h0 = M_::cvt(r0), h1 = M_::cvt(r1);
@@ -308,8 +357,10 @@ extern "C" int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, c
     const bool t3 = reso * split >= 48;                           // the model shapes (56 tokens): three key tiles need no validity mask
 #define GO(P_, C_)                                                                       \
     do {                                                                                 \
-        if (t3) cswin_stripe_kernel<P_, C_, 3><<<grid, 256, 0, st>>>(a);                 \
-        else    cswin_stripe_kernel<P_, C_, 0><<<grid, 256, 0, st>>>(a);                 \
+        if (split == 1 && t3) cswin_stripe_kernel<P_, C_, 3, true><<<grid, 256, 0, st>>>(a);    \
+        else if (split == 1)  cswin_stripe_kernel<P_, C_, 0, true><<<grid, 256, 0, st>>>(a);    \
+        else if (t3)          cswin_stripe_kernel<P_, C_, 3, false><<<grid, 256, 0, st>>>(a);   \
+        else                  cswin_stripe_kernel<P_, C_, 0, false><<<grid, 256, 0, st>>>(a);   \
     } while (0)
     if (C == 64) { if (precision == MI355_PREC_FP16) GO(1, 64); else GO(2, 64); }
     else         { if (precision == MI355_PREC_FP16) GO(1, 128); else GO(2, 128); }

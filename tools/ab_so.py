@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Same-process A/B of two builds of libmi355attn.so on one op (box-to-box variance on the pool is 10-20 %, so cross-run comparisons of
-small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|xca16 [baseline.so]`.
+small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|stripe1|stripe2|pmlp1|pmlp2 [baseline.so]`.
 The baseline library defaults to tools/bin/libmi355attn_r2.so (built from the round-2 head in a scratch worktree)."""
 import ctypes
 import os
@@ -88,6 +88,43 @@ elif op == "lpi":
         fns[k] = (lambda lib=lib, k=k: lib.mi355_lpi_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), bw.data_ptr(), bb.data_ptr(), bm.data_ptr(), bv.data_ptr(),
                                                           1e-5, w2.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), outs[k].data_ptr(), B, H, W, C,
                                                           wss[k].data_ptr(), 1 << 20, st))
+elif op in ("stripe1", "stripe2"):
+    # first half of a CSWinBlock (mi355_cswin_stripe_attn_fwd) at the stage-1 / stage-2 shapes of the bench step
+    C, reso, hb, split = (64, 56, 1, 1) if op == "stripe1" else (128, 28, 2, 2)
+    B = 256
+    x = torch.randn(B, reso * reso, C, device=dev)
+    w = (torch.randn(3 * C, C, device=dev) / C ** 0.5).half()
+    bq = torch.randn(3 * C, device=dev) * 0.1
+    gw = [torch.randn(C // 2, 1, 3, 3, device=dev) / 3 for _ in range(2)]
+    gb = [torch.randn(C // 2, device=dev) * 0.1 for _ in range(2)]
+    outs, fns = {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty(B, reso * reso, C, device=dev, dtype=torch.float16)
+        lib.mi355_cswin_stripe_attn_fwd.restype = ci
+        lib.mi355_cswin_stripe_attn_fwd.argtypes = [vp] * 8 + [ci] * 5 + [cf, cf, ci, vp]
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_cswin_stripe_attn_fwd(x.data_ptr(), w.data_ptr(), bq.data_ptr(), gw[0].data_ptr(), gb[0].data_ptr(),
+                                                                       gw[1].data_ptr(), gb[1].data_ptr(), outs[k].data_ptr(), B, reso, C, hb, split,
+                                                                       32 ** -0.5, 1e-5, 1, st))
+elif op in ("pmlp1", "pmlp2"):
+    # second half of a CSWinBlock (mi355_proj_mlp_fused_fwd)
+    C = 64 if op == "pmlp1" else 128
+    HD = 4 * C
+    M = 256 * (3136 if C == 64 else 784)
+    x = torch.randn(M, C, device=dev)
+    ctx = torch.randn(M, C, device=dev).half()
+    wp = (torch.randn(C, C, device=dev) / C ** 0.5).half()
+    w1 = (torch.randn(HD, C, device=dev) / C ** 0.5).half()
+    w2 = (torch.randn(C, HD, device=dev) / HD ** 0.5).half()
+    if C == 128:
+        w2 = w2.reshape(C, HD // 32, 32).permute(1, 0, 2).contiguous()
+    bp, b1, b2 = torch.randn(C, device=dev) * 0.1, torch.randn(HD, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1
+    outs, fns = {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty(M, C, device=dev)
+        lib.mi355_proj_mlp_fused_fwd.restype = ci
+        lib.mi355_proj_mlp_fused_fwd.argtypes = [vp] * 10 + [ctypes.c_long, ci, ci, ci, cf, ci, vp]
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_proj_mlp_fused_fwd(x.data_ptr(), ctx.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                                                    w2.data_ptr(), b2.data_ptr(), None, outs[k].data_ptr(), M, C, HD, 1, 1e-5, 1, st))
 else:
     raise SystemExit("unknown op " + op)
 
