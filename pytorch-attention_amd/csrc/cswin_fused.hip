@@ -57,35 +57,44 @@ __device__ __forceinline__ void lepe_tap(f4& r0, f4& r1, const V8 nb, const f4 w
     }
 }
 
-template <int PREC, int C, int TFULL = 0, bool L1D = false, int OCC = (C == 64 ? 3 : 2), bool LWREG = true, int ABL = 0>
-__global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs a) {
+template <int PREC, int C, int TFULL = 0, bool L1D = false, int ABL = 0>
+__global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(const StripeArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
     using v4 = typename M_::v4;
     using el = typename M_::e;
     static_assert(Mma<PREC>::NSPLIT == 1, "16-bit operand modes only");
-    constexpr int D = 32, TK = 64, KT = 4, NW = 4;
+    constexpr int D = 32, TK = 64, KT = 4;
+    constexpr int NH = C / 64;                 // heads per branch = head groups of four waves in this workgroup
+    constexpr int NW = 4 * NH, NTHR = 64 * NW;
+    constexpr bool LWREG = true;
     constexpr int KS = C / 32;                 // k-steps of the projection
     constexpr int WP = C + 8;                  // pitch of s_w / s_xn rows (elements)
     constexpr int QP = D + 8;                  // pitch of s_q / s_k rows
     constexpr int VP = TK + 4;                 // pitch of s_v rows (V^T: [d][key]); column TK is the zero column of the LePE taps
     constexpr int OP = D + 4;                  // slab pitch (floats)
-    constexpr int PT = C / 4;                  // floats of a token row per staging thread (4 threads per token)
+    constexpr int PT = C / (4 * NH);           // floats of a token row per staging thread (4 NH threads per token): 16
     __shared__ __attribute__((aligned(16))) unsigned short s_xn[TK * WP];
-    __shared__ __attribute__((aligned(16))) unsigned short s_q[TK * QP];
-    __shared__ __attribute__((aligned(16))) unsigned short s_k[TK * QP];
-    __shared__ __attribute__((aligned(16))) unsigned short s_v[D * VP];
-    __shared__ __attribute__((aligned(16))) unsigned short s_vt[(TK + 1) * QP];   // v token-major ([key][d]); row TK is the zero row of the LePE taps
+    __shared__ __attribute__((aligned(16))) unsigned short s_q_[NH][TK * QP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_k_[NH][TK * QP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_v_[NH][D * VP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_vt_[NH][(TK + 1) * QP];   // v token-major ([key][d]); row TK is the zero row of the LePE taps
     __shared__ __attribute__((aligned(16))) float s_o[NW * 16 * OP];
-    __shared__ float s_bias[96];
-    __shared__ __attribute__((aligned(16))) float s_lwt[10 * D];   // LePE taps, tap-major: [tap][channel]; row 9 = bias
+    __shared__ __attribute__((aligned(16))) float s_bias_[NH][96];
+    __shared__ __attribute__((aligned(16))) float s_lwt_[NH][10 * D];   // LePE taps, tap-major: [tap][channel]; row 9 = bias
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
-    // ---- unit of this workgroup: (branch, head); the grid is cut into `units` contiguous groups of workgroups ---------------------
-    const int units = 2 * a.hb;
-    const int per_unit = gridDim.x / units;                        // launcher: gridDim.x is a multiple of units
-    const int unit = blockIdx.x / per_unit, slot = blockIdx.x % per_unit;
-    const int br = unit / a.hb, head = unit % a.hb;
+    // ---- unit of this workgroup: a BRANCH; the first half of the grid walks the windows of branch 0, the second half those of
+    //      branch 1.  The NH heads of the branch are groups of four waves that share the LayerNorm'd window in s_xn ------------------
+    const int per_unit = gridDim.x / 2;                            // launcher: gridDim.x is even
+    const int br = blockIdx.x / per_unit, slot = blockIdx.x % per_unit;
+    const int head = __builtin_amdgcn_readfirstlane(wave >> 2), wq = wave & 3;   // head of this wave, its token tile inside the window
+    unsigned short* const s_q = s_q_[head];
+    unsigned short* const s_k = s_k_[head];
+    unsigned short* const s_v = s_v_[head];
+    unsigned short* const s_vt = s_vt_[head];
+    float* const s_bias = s_bias_[head];
+    float* const s_lwt = s_lwt_[head];
     const int Hsp = br == 0 ? a.reso : a.split, Wsp = br == 0 ? a.split : a.reso, nWx = a.reso / Wsp;
     const int T = a.reso * a.split;                                // tokens per window (<= 64)
     const int L = a.reso * a.reso;
@@ -103,11 +112,14 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wfr[ft][ks] = *reinterpret_cast<const v8*>(wg + (long)grow * C + ks * 32 + g * 8);
     }
-    if (t < 96) s_bias[t] = a.b[(t >> 5) * C + ch0 + (t & 31)];
-    for (int q = t; q < QP; q += 256) s_vt[TK * QP + q] = 0;
-    // LePE constants of this lane: it stores query row wave*16 + lane/4, channels (lane & 3)*8 + [0,8) of every window
+    if (t < 96 * NH) {
+        const int hh = t / 96, tt = t - hh * 96;
+        s_bias_[hh][tt] = a.b[(tt >> 5) * C + br * (C / 2) + hh * D + (tt & 31)];
+    }
+    for (int q = t; q < NH * QP; q += NTHR) s_vt_[q / QP][TK * QP + q % QP] = 0;
+    // LePE constants of this lane: it stores query row wq*16 + lane/4, channels (lane & 3)*8 + [0,8) of every window
     const int sr = lane >> 2, sc8 = (lane & 3) * 8;
-    const int myslot = wave * 16 + sr;
+    const int myslot = wq * 16 + sr;
     // L1D (split == 1: the stripes are one token wide, CSWin stage 1): six of the nine taps fall outside the window for EVERY token,
     // the other three are the slots before / at / after the token in both branches (branch 0: taps (dy, 0) = 1, 4, 7; branch 1:
     // taps (0, dx) = 3, 4, 5).  Three LDS rows instead of nine and the 24 tap weights of a lane live in registers.
@@ -136,12 +148,12 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
             tapoff[tap] = ((myslot < T && yy >= 0 && yy < Hsp && xx >= 0 && xx < Wsp) ? yy * Wsp + xx : TK) * QP + sc8;
         }
     }
-    for (int q = t; q < 10 * D; q += 256) {
-        const int tap = q / D, c = q - tap * D;
-        s_lwt[q] = tap < 9 ? a.lw[br][(long)(head * D + c) * 9 + tap] : a.lb[br][head * D + c];
+    for (int q = t; q < NH * 10 * D; q += NTHR) {
+        const int hh = q / (10 * D), qq = q - hh * 10 * D, tap = qq / D, c = qq - tap * D;
+        s_lwt_[hh][qq] = tap < 9 ? a.lw[br][(long)(hh * D + c) * 9 + tap] : a.lb[br][hh * D + c];
     }
     // rows of s_xn beyond T stay zero for the whole kernel (their q / k / v are bias-only and masked / never stored)
-    for (int i = t; i < TK * WP / 2; i += 256) reinterpret_cast<unsigned int*>(s_xn)[i] = 0u;
+    for (int i = t; i < TK * WP / 2; i += NTHR) reinterpret_cast<unsigned int*>(s_xn)[i] = 0u;
 
     // window slot -> token: token = origin(window) + offset(slot); branch 0 windows are columns of width `split` (origin = win * split),
     // branch 1 windows are rows of height `split` (origin = win * split * reso).  No divisions inside the window loop.
@@ -149,8 +161,8 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
     const int org_step = br == 0 ? a.split : a.split * a.reso;
     (void)nWx;
 
-    // ---- x staging: thread -> (token slot = t / 4, quarter of the row) --------------------------------------------------------------
-    const int xs = t >> 2, xq = t & 3;
+    // ---- x staging: thread -> (token slot, 16-float piece of the row): 4 NH threads per token -------------------------------------------
+    const int xs = t / (4 * NH), xq = t % (4 * NH);
     f4 xr[PT / 4];
     const int nwin_total = a.B * a.win_per_img;                    // launcher: < 2^31
     const int xoff = slot_off(xs < T ? xs : 0), soff = slot_off(myslot < T ? myslot : 0);
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
         for (int i = 0; i < PT / 4; ++i) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
         s += __shfl_xor(s, 1, WAVE);
         s += __shfl_xor(s, 2, WAVE);
+        if (NH == 2) s += __shfl_xor(s, 4, WAVE);
         const float mean = s * (1.0f / (float)C);
         float q = 0.f;
 #pragma unroll
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
         }
         q += __shfl_xor(q, 1, WAVE);
         q += __shfl_xor(q, 2, WAVE);
+        if (NH == 2) q += __shfl_xor(q, 4, WAVE);
         const float rstd = 1.0f / sqrtf(q * (1.0f / (float)C) + a.eps);
         if (xs < T) {
 #pragma unroll
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
         if (!(ABL & 4)) {
             v8 xf[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const v8*>(s_xn + (wave * 16 + l15) * WP + ks * 32 + g * 8);
+            for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const v8*>(s_xn + (wq * 16 + l15) * WP + ks * 32 + g * 8);
 #pragma unroll
             for (int ft = 0; ft < 6; ++ft) {
                 // the bias is the initial value of the accumulator (no separate add): q / k tiles hold features g*4 + r of token l15,
@@ -223,25 +237,25 @@ __global__ __launch_bounds__(256, OCC) void cswin_stripe_kernel(const StripeArgs
                     f4 v = acc;
                     if (ft < 2) v = v * a.scale;                   // cswin.py:116: q * scale before the product
                     const v4 h = M_::cvt(v);
-                    unsigned short* dst = (ft < 2 ? s_q : s_k) + (wave * 16 + l15) * QP + (ft & 1) * 16 + g * 4;
+                    unsigned short* dst = (ft < 2 ? s_q : s_k) + (wq * 16 + l15) * QP + (ft & 1) * 16 + g * 4;
                     *reinterpret_cast<v4*>(dst) = h;
                 } else {
                     const v4 h = M_::cvt(acc);
-                    *reinterpret_cast<v4*>(s_v + ((ft - 4) * 16 + l15) * VP + wave * 16 + g * 4) = h;
+                    *reinterpret_cast<v4*>(s_v + ((ft - 4) * 16 + l15) * VP + wq * 16 + g * 4) = h;
                     // the same tile token-major for LePE (second orientation of the product: the matrix pipe has room)
                     f4 acc2 = brow;
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         acc2 = M_::mma(wfr[ft][ks], xf[ks], acc2);
                     const v4 h2 = M_::cvt(acc2);
-                    *reinterpret_cast<v4*>(s_vt + (wave * 16 + l15) * QP + (ft - 4) * 16 + g * 4) = h2;
+                    *reinterpret_cast<v4*>(s_vt + (wq * 16 + l15) * QP + (ft - 4) * 16 + g * 4) = h2;
                 }
             }
         }
         __syncthreads();                                           // (2) q / k / v of all 64 slots in LDS
 
         // ---- attention of this wave's query tile (attn.hip phase B, D = 32, KT = 4) --------------------------------------------------
-        const int qt = wave;
+        const int qt = wq;
         if (qt * 16 < T && !(ABL & 2)) {
             const v8 qf = *reinterpret_cast<const v8*>(s_q + (qt * 16 + l15) * QP + g * 8);
             f4 s[KT];
@@ -346,21 +360,21 @@ extern "C" int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, c
     StripeArgs a{};
     a.x = x; a.w = wqkv16; a.b = bqkv; a.lw[0] = getv_w0; a.lb[0] = getv_b0; a.lw[1] = getv_w1; a.lb[1] = getv_b1; a.ctx = ctx16;
     a.B = B; a.reso = reso; a.split = split; a.hb = heads_per_branch; a.scale = scale; a.eps = eps; a.win_per_img = reso / split;
-    const int units = 2 * heads_per_branch;
-    const long nwin = (long)B * a.win_per_img;
+    const long nwin = (long)B * a.win_per_img;                    // windows per branch
     if (nwin >= (1L << 30)) return mi355::fail(MI355_EUNSUPPORTED, "mi355_cswin_stripe_attn_fwd: too many windows");
-    long per_unit = (long)mi355::resident_slots(C == 64 ? 3 : 2) / units;
+    // C = 64: 4-wave workgroups, three per CU; C = 128: 8-wave workgroups (two heads share the LayerNorm'd window), one per CU
+    long per_unit = (long)mi355::resident_slots(C == 64 ? 3 : 1) / 2;
     if (per_unit > nwin) per_unit = nwin;
     if (per_unit < 1) per_unit = 1;
-    const int grid = (int)(per_unit * units);
+    const int grid = (int)(per_unit * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool t3 = reso * split >= 48;                           // the model shapes (56 tokens): three key tiles need no validity mask
 #define GO(P_, C_)                                                                       \
     do {                                                                                 \
-        if (split == 1 && t3) cswin_stripe_kernel<P_, C_, 3, true><<<grid, 256, 0, st>>>(a);    \
-        else if (split == 1)  cswin_stripe_kernel<P_, C_, 0, true><<<grid, 256, 0, st>>>(a);    \
-        else if (t3)          cswin_stripe_kernel<P_, C_, 3, false><<<grid, 256, 0, st>>>(a);   \
-        else                  cswin_stripe_kernel<P_, C_, 0, false><<<grid, 256, 0, st>>>(a);   \
+        if (split == 1 && t3) cswin_stripe_kernel<P_, C_, 3, true><<<grid, C_ * 4, 0, st>>>(a);    \
+        else if (split == 1)  cswin_stripe_kernel<P_, C_, 0, true><<<grid, C_ * 4, 0, st>>>(a);    \
+        else if (t3)          cswin_stripe_kernel<P_, C_, 3, false><<<grid, C_ * 4, 0, st>>>(a);   \
+        else                  cswin_stripe_kernel<P_, C_, 0, false><<<grid, C_ * 4, 0, st>>>(a);   \
     } while (0)
     if (C == 64) { if (precision == MI355_PREC_FP16) GO(1, 64); else GO(2, 64); }
     else         { if (precision == MI355_PREC_FP16) GO(1, 128); else GO(2, 128); }
