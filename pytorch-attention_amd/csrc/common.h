@@ -209,4 +209,38 @@ typedef float gelu_f4 __attribute__((ext_vector_type(4)));      // the same type
 __device__ __forceinline__ gelu_f4 gelu_fast4(gelu_f4 v) {
     return gelu_f4{gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)};
 }
+// The same GELU for results that are rounded to 16 bits right away (hidden units of the fused MLPs, 16-bit fc1 outputs): the
+// exponent polynomial has degree 5 and carries the factor 1/2 in its constant term (erfc(a / sqrt 2) / 2 = 2^{h(a)}), so
+//     gelu(x) = (x + |x|) / 2 - a 2^{h(a)}:   min, 5 FMAs, v_exp_f32, one multiply and two FMAs (|x| and -a are source modifiers)
+// = 10 issue slots + the transcendental against 15 for gelu_fast.  Absolute error <= 9e-7 over [-12, 12] (the fp32 rounding of the
+// result on the positive side, 5e-7 of approximation error on the negative side): less than half an fp16 ulp wherever
+// |gelu| >= 2e-3 and far below a bf16 ulp everywhere.  A NaN in x survives through the (x + |x|) / 2 term.  tools/fit_gelu.py.
+#define MI355_GELU16_H0 -1.000037670135498f
+#define MI355_GELU16_H1 -1.1507878303527832f
+#define MI355_GELU16_H2 -0.4599926173686981f
+#define MI355_GELU16_H3 -0.05182718485593796f
+#define MI355_GELU16_H4 0.007084468379616737f
+#define MI355_GELU16_H5 -0.0004732950183097273f
+__device__ __forceinline__ float gelu16_fast(float x) {
+    const float ax = fabsf(x);
+    const float a = fminf(ax, MI355_GELU_CLAMP);
+    float p = MI355_GELU16_H5;
+    p = __builtin_fmaf(p, a, MI355_GELU16_H4);
+    p = __builtin_fmaf(p, a, MI355_GELU16_H3);
+    p = __builtin_fmaf(p, a, MI355_GELU16_H2);
+    p = __builtin_fmaf(p, a, MI355_GELU16_H1);
+    p = __builtin_fmaf(p, a, MI355_GELU16_H0);
+    const float e = __builtin_amdgcn_exp2f(p);
+    const float t = __builtin_fmaf(0.5f, ax, 0.5f * x);
+    return __builtin_fmaf(-a, e, t);
+}
+__device__ __forceinline__ gelu_f4 gelu16_fast4(gelu_f4 v) {
+    return gelu_f4{gelu16_fast(v.x), gelu16_fast(v.y), gelu16_fast(v.z), gelu16_fast(v.w)};
+}
+// 16-bit destination -> gelu16_fast, fp32 destination -> gelu_fast
+template <bool OUT16>
+__device__ __forceinline__ gelu_f4 gelu_out4(gelu_f4 v) {
+    if constexpr (OUT16) return gelu16_fast4(v);
+    else return gelu_fast4(v);
+}
 #endif

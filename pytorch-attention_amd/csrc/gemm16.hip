@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
                 const int n = n0 + wc * TN + j * 16 + g4;
                 if (n >= g.N) continue;                         // N % 4 == 0 is a launch precondition
                 f4 v = acc[i][j] + bias4[j];
-                if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
+                if (g.act == MI355_ACT_GELU) v = gelu_out4<OUT16>(v);
                 if (g.gamma) v = v * gam4[j];
                 if (g.resid) v = v + *reinterpret_cast<const f4*>(g.resid + (long)mr * g.ldc + n);
                 if constexpr (OUT16) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, (LNA ? 2 : (KK == 64 ? 4 : 2))) void gemm16_ws
                     f4 v = acc[i][j];
                     if (n < g.N) {
                         if (g.bias) v = v + *reinterpret_cast<const f4*>(g.bias + n);
-                        if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
+                        if (g.act == MI355_ACT_GELU) v = gelu_out4<OUT16>(v);
                         if (g.gamma) v = v * *reinterpret_cast<const f4*>(g.gamma + n);
                         const int m = m0 + wr * TM + i * 16 + l15;
                         if (g.resid && m < g.M) v = v + *reinterpret_cast<const f4*>(g.resid + (long)m * g.ldc + n);

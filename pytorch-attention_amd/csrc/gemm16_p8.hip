@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f4 v = acc[i][j] + bias4[j];
-                        if (g.act == MI355_ACT_GELU) v = gelu_fast4(v);
+                        if (g.act == MI355_ACT_GELU) v = gelu16_fast4(v);
                         if (g.gamma) v = v * gam4[j];
                         if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);
                         *reinterpret_cast<v4*>(slab + l15 * 128 + (((j * 2 + (fq4 >> 1)) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8) =

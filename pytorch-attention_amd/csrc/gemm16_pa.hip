@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
                      : "memory");
     };
     auto act4 = [&](f4 v) {
-        if constexpr (GELU) v = gelu_fast4(v);
+        if constexpr (GELU) v = gelu_out4<OUT16>(v);
         return v;
     };
     // C (16-bit): one accumulator tile (row tile i, column tile j) -> slab, accumulator layout (lane = row l15, 4 columns fq4*4..)

@@ -161,8 +161,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 f4 p0 = s[tt][0], p1 = s[tt][1];
-                p0 = gelu_fast4(p0);
-                p1 = gelu_fast4(p1);
+                p0 = gelu16_fast4(p0);
+                p1 = gelu16_fast4(p1);
                 const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
                 pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             }
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
                 for (int ks = 0; ks < KS; ++ks)
                     s[h2] = M_::mma(*reinterpret_cast<const v8*>(sw1 + (h2 * 16 + l15) * P1 + ks * 32 + g * 8), xb[ks], s[h2]);
             }
-            const f4 p0 = gelu_fast4(s[0]);
-            const f4 p1 = gelu_fast4(s[1]);
+            const f4 p0 = gelu16_fast4(s[0]);
+            const f4 p1 = gelu16_fast4(s[1]);
             const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
             const v8 pf = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll

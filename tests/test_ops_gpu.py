@@ -533,8 +533,15 @@ def test_linear16_bit_identical_to_fp32_entry(M, N, K, prec):
     assert torch.equal(f.linear16(x16, w16, b, precision=prec), ref)
     ref2 = f.linear(x, w, b, act=f.ACT_GELU, gamma=gamma, resid=resid, precision=prec)
     assert torch.equal(f.linear16(x16, w16, b, act=f.ACT_GELU, gamma=gamma, resid=resid, precision=prec), ref2)
+    # 16-bit outputs without an activation round the same fp32 number; with GELU the 16-bit epilogues use the short form of the
+    # function (csrc/common.h gelu16_fast: |error| <= 9e-7 before the rounding), so at most a rounding boundary may be crossed
+    out16 = f.linear16(x16, w16, b, out16=True, precision=prec)
+    assert torch.equal(out16, f.linear(x, w, b, precision=prec).to(out16.dtype))
     out16 = f.linear16(x16, w16, b, act=f.ACT_GELU, out16=True, precision=prec)
-    assert torch.equal(out16, f.linear(x, w, b, act=f.ACT_GELU, precision=prec).to(out16.dtype))
+    ref3 = f.linear(x, w, b, act=f.ACT_GELU, precision=prec)
+    ulp = 2.0 ** -10 if prec == 1 else 2.0 ** -7
+    assert torch.all((out16.float() - ref3).abs() <= ulp * ref3.abs() + 2e-6)
+    assert (out16 != ref3.to(out16.dtype)).float().mean() < 0.02
 
 
 def test_linear16_rejects_shapes_outside_the_envelope():

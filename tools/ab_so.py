@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Same-process A/B of two builds of libmi355attn.so on one op (box-to-box variance on the pool is 10-20 %, so cross-run comparisons of
-small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|stripe1|stripe2|pmlp1|pmlp2 [baseline.so]`.
+small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|stripe1|stripe2|pmlp1|pmlp2|fc1|qkv|proj|fc2 [baseline.so]`.
 The baseline library defaults to tools/bin/libmi355attn_r2.so (built from the round-2 head in a scratch worktree)."""
 import ctypes
 import os
@@ -125,6 +125,24 @@ elif op in ("pmlp1", "pmlp2"):
         lib.mi355_proj_mlp_fused_fwd.argtypes = [vp] * 10 + [ctypes.c_long, ci, ci, ci, cf, ci, vp]
         fns[k] = (lambda lib=lib, k=k: lib.mi355_proj_mlp_fused_fwd(x.data_ptr(), ctx.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                                                     w2.data_ptr(), b2.data_ptr(), None, outs[k].data_ptr(), M, C, HD, 1, 1e-5, 1, st))
+elif op in ("fc1", "qkv", "proj", "fc2"):
+    # the four GEMMs of a ViT-Base layer at B = 256 (mi355_linear16_ws_fwd): fc1 = bias + GELU, 16-bit out; fc2 / proj = fp32 + residual
+    M = 256 * 197
+    N, K, act, o16, res = {"fc1": (3072, 768, 1, 1, 0), "qkv": (2304, 768, 0, 1, 0), "proj": (768, 768, 0, 0, 1), "fc2": (768, 3072, 0, 0, 1)}[op]
+    x16 = torch.randn(M, K, device=dev).half()
+    w16 = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+    b = torch.randn(N, device=dev) * 0.1
+    r = torch.randn(M, N, device=dev) if res else None
+    outs, fns, wss = {}, {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty(M, N, device=dev, dtype=torch.float16 if o16 else torch.float32)
+        lib.mi355_linear16_workspace_bytes.restype = sz; lib.mi355_linear16_workspace_bytes.argtypes = [ci] * 3
+        n = lib.mi355_linear16_workspace_bytes(M, N, K)
+        wss[k] = torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
+        lib.mi355_linear16_ws_fwd.restype = ci
+        lib.mi355_linear16_ws_fwd.argtypes = [vp] * 6 + [ci] * 8 + [vp, sz, vp]
+        fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_linear16_ws_fwd(x16.data_ptr(), w16.data_ptr(), b.data_ptr(), None, r.data_ptr() if res else None,
+                                                                       outs[k].data_ptr(), M, N, K, K, N, act, o16, 1, wss[k].data_ptr(), n, st))
 else:
     raise SystemExit("unknown op " + op)
 

@@ -64,3 +64,33 @@ def old(x):
     ea=(np.float32(1)-p*e).astype(np.float32)
     return (np.float32(0.5)*x*(np.float32(1)+np.copysign(ea,z))).astype(np.float32)
 eo=np.abs(old(x).astype(np.float64)-ref); print("old max abs err",eo.max())
+
+# ---- gelu16_fast (csrc/common.h): the form for results that are rounded to 16 bits right away (MLP hidden units, fc1 outputs) ----
+# erfc(t)/2 = 2^q5(t) with q5 of degree 5, fitted for the absolute error of |x| erfc(|x| / sqrt 2) / 2 (the only inexact term of
+# gelu(x) = (x + |x|) / 2 - |x| erfc(|x| / sqrt 2) / 2); the 1/2 is the constant term.  Absolute error <= 5e-7 = fp32 rounding level of
+# the positive side and below half an fp16 ulp wherever |gelu| >= 1e-3.
+def fit16(deg, iters=80):
+    n=4000
+    t=0.5*T*(1-np.cos(np.pi*(np.arange(n)+0.5)/n))
+    y=np.log2(erfc(t)); w=erfc(t)*np.log(2)*np.maximum(t,1e-3)
+    xx=2*t/T-1
+    V=np.polynomial.chebyshev.chebvander(xx,deg)
+    wt=np.ones(n)
+    for it in range(iters):
+        A=V*(w*wt)[:,None]; b=y*w*wt
+        c,*_=np.linalg.lstsq(A,b,rcond=None)
+        e=np.abs((V@c-y)*w); wt=wt*(0.5+e/e.mean()*0.5); wt/=wt.mean()
+    p=np.polynomial.chebyshev.cheb2poly(c); P=np.polynomial.Polynomial(p)
+    return P(np.polynomial.Polynomial([-1,2/T])).coef
+c5=fit16(5); h5=np.array([c5[k]*s**k for k in range(6)]); h5[0]-=1.0
+h5f=h5.astype(np.float32)
+print("gelu16 coefficients", [float(v) for v in h5f])
+def gelu16(x):
+    x=x.astype(np.float32); ax=np.abs(x); a=np.minimum(ax,CL)
+    p=np.full_like(a,h5f[-1])
+    for k in range(4,-1,-1): p=(p*a+h5f[k]).astype(np.float32)
+    e=np.exp2(p).astype(np.float32)
+    t=(np.float32(0.5)*x).astype(np.float32); t=(np.float32(0.5)*ax+t).astype(np.float32)
+    return (t-a*e).astype(np.float32)
+g16=gelu16(x).astype(np.float64); e16=np.abs(g16-ref)
+print("gelu16 max abs err", e16.max(), "at", x[e16.argmax()])
