@@ -92,6 +92,33 @@ WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hip
     else if (it != g_ws.end()) g_ws.erase(it);             // zeroed on every call from now on: what was remembered is void
     return r;
 }
+// Workspaces of the kernels that keep their launch tag in device memory (se_single_kernel, cbam_single_kernel): the host only has to know whether the
+// region was zeroed for this shape.  Under stream capture an unknown region stays unknown (the memset the caller records runs at
+// replay time, not now); a known one needs nothing.
+bool ws_known(const void* region, unsigned long long key, hipStream_t st) {
+    if (!opt_ws_persistent()) return false;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(region);
+    if (it != g_ws.end() && it->second.key == key) return true;
+    if (!stream_is_capturing(st)) g_ws[region] = WsEntry{key, 0u};
+    return false;
+}
+// Zero an exchange area with a KERNEL.  Under stream capture a recorded hipMemsetAsync did not reliably take effect before the kernel
+// node behind it on this runtime (ROCm 7.2: the second of two back-to-back memset nodes -- a replayed SE launch saw the granules of
+// the previous replay); a kernel node is ordered like any other launch, so the exchange kernels zero their areas this way everywhere.
+namespace {
+__global__ __launch_bounds__(256) void ws_zero_kernel(unsigned* p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+hipError_t ws_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t words = bytes / 4;                                    // callers pass multiples of 4 bytes, 4-byte aligned
+    if (!words) return hipSuccess;
+    size_t blocks = (words + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    ws_zero_kernel<<<(int)blocks, 256, 0, st>>>(static_cast<unsigned*>(p), words);
+    return hipGetLastError();
+}
 void ws_forget(const void* region) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     g_ws.erase(region);
@@ -122,6 +149,10 @@ unsigned* sync_err_word() {
         }
     });
     return g_sync_word;
+}
+unsigned* sync_err_word_on(hipStream_t st) {
+    if (!g_sync_word && stream_is_capturing(st)) return nullptr;          // never allocate pinned memory inside a capture
+    return sync_err_word();
 }
 unsigned* range_word(hipStream_t st) {
     if (!g_sync_word && stream_is_capturing(st)) return nullptr;          // never allocate pinned memory inside a capture

@@ -14,9 +14,11 @@
 // Every sum is accumulated in a fixed order (butterfly inside the segment, bands in band order, channel groups in group
 // order), so results are run-to-run identical and independent of placement.  Slices (image, band) are handed out in image
 // order by a ticket; a workgroup only takes its next ticket once it no longer waits for anybody, so progress needs only
-// NB (bands per image) running workgroups, never a particular placement.  The tag is unique per launch (api.hip ws_epoch), so
-// slots written by earlier launches never look valid and the region is only zeroed when its history is unknown; polls are
-// bounded and raise the workspace error word instead of hanging.
+// NB (bands per image) running workgroups, never a particular placement.  The tag of a launch is `epoch + 1`, read from the
+// workspace; the workgroup that draws the last ticket of a launch (total + gridDim.x draws: one per slice, one stop ticket per
+// workgroup) zeroes the ticket word and advances the epoch.  Slots written by earlier launches never look valid, the region is
+// only zeroed when its history is unknown, and because nothing about a launch lives on the host, eager launches and hipGraph
+// replays can share a workspace.  Polls are bounded and raise the workspace error word instead of hanging.
 #include "common.h"
 #include "bufops.h"
 
@@ -66,10 +68,9 @@ __device__ __forceinline__ void seg_reduce(float& s, float& m, int lane) {
 
 struct CbamSingleArgs {
     const float* x; float* y; const float* w1; const float* w2; const float* wconv;
-    u32x4* g1; u32x4* g2; u32x4* g3; u32* ticket; u32* err; u32* herr;   // herr: pinned host word every later call checks (api.hip)
+    u32x4* g1; u32x4* g2; u32x4* g3; u32* ticket; u32* epoch; u32* err; u32* herr;   // herr: pinned host word every later call checks (api.hip)
     u32 spin;
     int C, Cr, H, W, ks, R, Q, NB, cpb, total, nts, wlds;
-    u32 tag, tbase;                                                   // granule tag and ticket base of this launch (ws_epoch)
 #ifdef CBAM_TIMING
     unsigned long long* dbg;                                          // [gridDim][16 slices][10 stamps] of wall_clock64 (tools/cbam_timing.hip)
 #endif
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
     constexpr int CL = NT / SEG;                                     // channel groups (segments) per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ u32 s_tk[2];
+    __shared__ u32 s_ep;
     const int C = a.C, Cr = a.Cr, W = a.W, H = a.H, ks = a.ks, pad = (ks - 1) >> 1;
     const int HW = H * W, npx = a.R * W, TW = W + 2 * pad, TH = a.R + 2 * pad;
     const int Cp = (CL * NV > C ? CL * NV : ((C + 3) & ~3)), Crp = (Cr + 3) & ~3, L2p = (a.NB * a.cpb + 3) & ~3;   // every sub-array starts 16-byte aligned
@@ -108,12 +110,29 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
 
     const int t = threadIdx.x, q = t & (SEG - 1), cl = t / SEG;
     const bool qa = q < a.Q;
-    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
+    // one ticket; the last draw of the launch (number total + gridDim.x - 1) resets the ticket word and advances the epoch
+    const u32 last_draw = (u32)a.total + gridDim.x - 1u;
+    auto draw = [&](u32 ep) -> u32 {
+        const u32 v = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+        if (v == last_draw) {
+            __hip_atomic_store(a.ticket, 0u, AGENT_RLX);
+            __hip_atomic_store(a.epoch, ep + 1u, AGENT_RLX);
+        }
+        return v;
+    };
+    if (t == 0) {
+        const u32 ep = __hip_atomic_load(a.epoch, AGENT_RLX);         // before the first draw: the epoch cannot move until this
+        s_ep = ep;                                                    // workgroup has drawn its stop ticket
+        s_tk[0] = draw(ep);
+    }
     for (int i = t; i < 2 * ks * ks; i += NT) s_wc[i] = a.wconv[i];
     if (a.wlds)
         for (int i = t; i < Cr * C; i += NT) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
     const float* w1 = a.wlds ? s_w1 : a.w1;
     const float* w2 = a.wlds ? s_w2 : a.w2;
+    __syncthreads();
+    const u32 EP = s_ep;
+    const u32 TAG = (EP + 1u) ? EP + 1u : 1u;                         // 0 is what a zeroed granule holds
     int par = 0;
 #ifdef CBAM_TIMING
     int nslice = -1;
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
             float s = (r[j].x + r[j].y) + (r[j].z + r[j].w);
             float m = qa ? fmaxf(fmaxf(r[j].x, r[j].y), fmaxf(r[j].z, r[j].w)) : -INFINITY;
             seg_reduce<SEG>(s, m, t & 63);
-            if (q == 0 && c < C) gran_put(rg1, (u32)(band * C + c), s, m, a.tag);
+            if (q == 0 && c < C) gran_put(rg1, (u32)(band * C + c), s, m, TAG);
         }
         STAMP(1);                                                                    // loads landed, band partials published
         // ---- hop 1, consume: this band adds up channels ck0 .. ck0+nch-1 over all bands, publishes (avg, max) as hop 2 ------
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
             for (int i = t; i < n1; i += NT) {
                 const int bb = i / nch, cc = i - bb * nch;
                 float v0, v1;
-                if (gran_get(rg1, (u32)(bb * C + ck0 + cc), v0, v1, a.tag)) { s_l2s[bb * a.cpb + cc] = v0; s_l2m[bb * a.cpb + cc] = v1; }
+                if (gran_get(rg1, (u32)(bb * C + ck0 + cc), v0, v1, TAG)) { s_l2s[bb * a.cpb + cc] = v0; s_l2m[bb * a.cpb + cc] = v1; }
                 else ok = false;
             }
             if (__syncthreads_and(ok)) break;
@@ -180,14 +199,14 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
         if (t < nch) {
             float s = 0.f, m = -INFINITY;
             for (int bb = 0; bb < a.NB; ++bb) { s += s_l2s[bb * a.cpb + t]; m = fmaxf(m, s_l2m[bb * a.cpb + t]); }
-            gran_put(rg2, (u32)(ck0 + t), s / (float)HW, m, a.tag);
+            gran_put(rg2, (u32)(ck0 + t), s / (float)HW, m, TAG);
         }
         // ---- hop 2, consume: (avg, max) of every channel of the image ---------------------------------------------------------
         for (;;) {
             bool ok = true;
             for (int c = t; c < C; c += NT) {
                 float v0, v1;
-                if (gran_get(rg2, (u32)c, v0, v1, a.tag)) { s_a[c] = v0; s_m[c] = v1; }
+                if (gran_get(rg2, (u32)c, v0, v1, TAG)) { s_a[c] = v0; s_m[c] = v1; }
                 else ok = false;
             }
             if (__syncthreads_and(ok)) break;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
             const int ty = t / W, tx = t - ty * W;
             s_t[(0 * TH + ty + pad) * TW + tx + pad] = s;
             s_t[(1 * TH + ty + pad) * TW + tx + pad] = m;
-            gran_put(rg3, (u32)(r0 * W + t), s, m, a.tag);                                  // hop 3, publish
+            gran_put(rg3, (u32)(r0 * W + t), s, m, TAG);                                  // hop 3, publish
         }
         STAMP(5);                                                                    // statistics published
         // ---- hop 3, consume: halo rows of the neighbouring bands ------------------------------------------------------------------
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
                     const int hr = i / W, tx = i - hr * W;
                     const int gy = (hr < up) ? r0 - up + hr : r0 + a.R + (hr - up);
                     float v0, v1;
-                    if (gran_get(rg3, (u32)(gy * W + tx), v0, v1, a.tag)) {
+                    if (gran_get(rg3, (u32)(gy * W + tx), v0, v1, TAG)) {
                         const int ty = gy - r0 + pad;
                         s_t[(0 * TH + ty) * TW + tx + pad] = v0;
                         s_t[(1 * TH + ty) * TW + tx + pad] = v1;
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
         // nobody is waited for any more: take the next ticket (hidden behind the conv and the stores)
         u32 next_tk = 0;
         if (t == 0) {
-            next_tk = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;     // consumed after the stores below
+            next_tk = draw(EP);                                                      // consumed after the stores below
             if (timeout) {
                 __hip_atomic_store(a.err, 1u, AGENT_RLX);
                 if (a.herr) __hip_atomic_store(a.herr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -418,7 +437,8 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
     a.g3 = a.g2 + (size_t)B * C;
     a.ticket = reinterpret_cast<u32*>(a.g3 + (size_t)B * H * W);
     a.err = a.ticket + 1;
-    a.herr = sync_err_word(); a.spin = spin_limit();
+    a.epoch = a.ticket + 2;
+    a.herr = sync_err_word_on(st); a.spin = spin_limit();
     if (int rc = sync_pending("cbam_single")) return rc;
     a.C = C; a.Cr = Cr; a.H = H; a.W = W; a.ks = ks; a.R = g.R; a.Q = g.Q; a.NB = g.NB; a.cpb = g.cpb;
     const long total_l = (long)B * g.NB;
@@ -435,13 +455,10 @@ int cbam_single(const float* x, const float* w1, const float* w2, const float* w
 #endif
     if (g.NB > grid) return fail(MI355_EUNSUPPORTED, "cbam_single: an image needs %d resident workgroups, the device holds %ld", g.NB, grid);
     if (grid > a.total) grid = a.total;
-    // every workgroup draws one ticket per slice plus one that tells it to stop: total + grid draws per launch
     const unsigned long long key = ((unsigned long long)B << 48) ^ ((unsigned long long)C << 32) ^ ((unsigned long long)H << 16) ^ (unsigned long long)W ^ ((unsigned long long)g.NT << 40) ^ 0xCBA0000000000000ull;
-    const WsEpoch ep = ws_epoch(extra, key, (unsigned)(a.total + grid), st);
-    a.tag = ep.tag; a.tbase = ep.ticket_base;
-    if (ep.fresh) {
-        hipError_t e = hipMemsetAsync(extra, 0, cbam_single_extra_bytes(B, C, H, W), st);
-        if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: memset -> %s", hipGetErrorString(e)); }
+    if (!ws_known(extra, key, st)) {                                            // unknown history: granules, ticket, epoch
+        hipError_t e = ws_zero_async(extra, cbam_single_extra_bytes(B, C, H, W), st);
+        if (e != hipSuccess) { ws_forget(extra); return fail(MI355_EHIP, "cbam_single: zeroing -> %s", hipGetErrorString(e)); }
     }
 #define GO(SEG_, NV_)                                                                              \
     do {                                                                                           \

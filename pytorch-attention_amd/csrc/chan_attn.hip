@@ -461,7 +461,7 @@ static int se_eca_common(int mode, const float* x, const float* wa, const float*
     const int groups = cdiv(C, RPB);
     const size_t smem = (size_t)(C + (mode == 0 ? Cr : 0) + RPB) * sizeof(float);
     if (smem > 64 * 1024) return mi355::fail(MI355_EUNSUPPORTED, "channel count %d too large for the gate stage", C);
-    if (mode == 0 && vec && mi355::se_single_applicable(C, Cr, H, W) && !mi355::stream_is_capturing(st)) {       // SE: x read once, means exchanged as tagged granules
+    if (mode == 0 && vec && mi355::se_single_applicable(C, Cr, H, W)) {       // SE: x read once, means exchanged as tagged granules
         char* state = static_cast<char*>(ws) + pooled_bytes(B, C);
         return mi355::se_single(x, wa, wb, y, B, C, Cr, H, W, state, state + mi355::fused_state_bytes(B), ex, st);
     }
@@ -537,8 +537,7 @@ int mi355_cbam_fwd(const float* x, const float* w1, const float* w2, const float
     if (do_s) MI355_CHECK_ARG(wconv && ks > 0 && (ks & 1));
     MI355_CHECK_ARG(ws_bytes >= mi355_cbam_workspace_bytes(B, C, H, W));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (stage == 0 && aligned16(x) && aligned16(y) && mi355::cbam_single_applicable(C, Cr, H, W, ks) &&
-        !mi355::stream_is_capturing(st))                                                                  // x read once
+    if (stage == 0 && aligned16(x) && aligned16(y) && mi355::cbam_single_applicable(C, Cr, H, W, ks))                                                   // x read once
         return mi355::cbam_single(x, w1, w2, wconv, y, B, C, Cr, H, W, ks, static_cast<char*>(ws) + cbam_multipass_bytes(B, C, H, W), st);
     if (!do_c) Cr = 0;
     if (!do_s) ks = 1;

@@ -98,35 +98,54 @@ __global__ __launch_bounds__(512, 6) void eca_halo_kernel(const float* __restric
 // arrival counter (MI355X_MICROARCH.md price list: handoff-1to1 / allgather rows).  Every workgroup of the image then sweeps
 // the image's C granules with sc1 loads (one per thread) until all tags match, computes the excitation MLP redundantly
 // (C*Cr MACs) and scales its rows from registers.  Slices are handed out in image order by a ticket that is prefetched one
-// slice ahead, so progress needs only C/8 running workgroups and never a particular placement.  The tag is unique per launch
-// (api.hip ws_epoch): the granule array is only zeroed when the history of the workspace is unknown.  Polls are bounded.
+// slice ahead, so progress needs only C/8 running workgroups and never a particular placement.  The tag of a launch is `epoch + 1`,
+// read from the workspace; the workgroup that draws the LAST ticket of a launch (every workgroup draws one ticket per slice plus one
+// that tells it to stop: total + gridDim.x draws) sets the ticket word back to zero and advances the epoch.  Nothing about a launch
+// lives on the host, so eager launches and hipGraph replays can be mixed freely on one workspace, and the granule array is only
+// zeroed when the history of the workspace is unknown.  Polls are bounded.
 typedef unsigned long long u64;
 
 struct SeSingleArgs {
     const float* x; float* y; const float* w1; const float* w2; const float* b1; const float* b2;
-    u64* gran; u32* ticket; u32* err; u32* herr;   // err: workspace word (debug), herr: pinned host word every later call checks
+    u64* gran; u32* ticket; u32* epoch; u32* err; u32* herr;   // err: workspace word (debug), herr: pinned host word every later call checks
     u32 spin;
     int gate;
     int C, Cr, HW, n4, gpi, total;
-    u32 tag, tbase;                    // granule tag and ticket base of this launch (api.hip ws_epoch)
 };
 
 template <int NV, bool NTS, bool WLDS, int OCC>
 __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // p[C] | h[Cr] | (WLDS: W1[Cr*C] | W2[C*Cr])
     __shared__ u32 s_tk[2];
+    __shared__ u32 s_ep;
     float* s_p = smem;
     float* s_h = smem + a.C;
     float* s_w1 = s_h + a.Cr;
     float* s_w2 = s_w1 + a.Cr * a.C;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float inv = 1.0f / (float)a.HW;
-    const u32 GRAN_TAG = a.tag;
-    if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
+    // one ticket; the last draw of the launch (number total + gridDim.x - 1) resets the ticket word and advances the epoch
+    const u32 last_draw = (u32)a.total + gridDim.x - 1u;
+    auto draw = [&](u32 ep) -> u32 {
+        const u32 v = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+        if (v == last_draw) {
+            __hip_atomic_store(a.ticket, 0u, AGENT_RLX);
+            __hip_atomic_store(a.epoch, ep + 1u, AGENT_RLX);
+        }
+        return v;
+    };
+    if (t == 0) {
+        const u32 ep = __hip_atomic_load(a.epoch, AGENT_RLX);         // read BEFORE the first draw: the epoch cannot move until this
+        s_ep = ep;                                                    // workgroup has drawn its stop ticket
+        s_tk[0] = draw(ep);
+    }
     if (WLDS) {                                                       // both weight matrices stay in LDS for every slice
         const int nw = a.Cr * a.C;
         for (int i = t; i < nw; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
     }
+    __syncthreads();
+    const u32 EP = s_ep;
+    const u32 GRAN_TAG = (EP + 1u) ? EP + 1u : 1u;                    // 0 is what a zeroed granule holds
     int par = 0;
     for (;;) {
         __syncthreads();
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
         }
         // Next slice's ticket: only now, when this workgroup no longer waits for anybody -- a workgroup that held an unprocessed
         // ticket of the image it is still waiting for would deadlock.  Its latency hides behind the MLP and the stores.
-        if (t == 0) s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
+        if (t == 0) s_tk[par ^ 1] = draw(EP);
         // excitation: h = relu(W1 p) (16 lanes per hidden unit), g = sigmoid(W2[c,:] h) (one wave per channel)
         const float* w1 = WLDS ? s_w1 : a.w1;
         const float* w2 = WLDS ? s_w2 : a.w2;
@@ -262,15 +281,16 @@ bool se_single_applicable(int C, int Cr, int H, int W) {
            C / ECW <= resident_slots(2);
 }
 
-// `state` = arrive[B] | ticket | err (fused_state_bytes), `gran` = B*C granules (se_single_extra_bytes)
+// `state` = epoch | (B - 1 unused words) | ticket | err (fused_state_bytes), `gran` = B*C granules (se_single_extra_bytes)
 int se_single(const float* x, const float* w1, const float* w2, float* y, int B, int C, int Cr, int H, int W, void* state,
               void* gran, SeExtra ex, hipStream_t st) {
     SeSingleArgs a{};
     a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.b1 = ex.b1; a.b2 = ex.b2; a.gate = ex.gate;
     a.gran = static_cast<u64*>(gran);
     a.ticket = static_cast<u32*>(state) + B;
+    a.epoch = static_cast<u32*>(state);
     a.err = a.ticket + 1;
-    a.herr = sync_err_word(); a.spin = spin_limit();
+    a.herr = sync_err_word_on(st); a.spin = spin_limit();
     if (int rc = sync_pending("se_single")) return rc;
     a.C = C; a.Cr = Cr; a.HW = H * W; a.n4 = a.HW / 4; a.gpi = C / ECW;
     const long total_l = (long)B * a.gpi;
@@ -281,14 +301,11 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     long grid = (long)resident_slots(occ);                // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
     if (a.gpi > grid) return fail(MI355_EUNSUPPORTED, "se_single: an image needs %d resident workgroups, the device holds %ld", a.gpi, grid);
     if (grid > a.total) grid = a.total;
-    const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ 0x5E00000000000000ull;
-    const WsEpoch ep = ws_epoch(state, key, (unsigned)(a.total + grid), st);     // one draw per slice + one stop draw per workgroup
-    a.tag = ep.tag; a.tbase = ep.ticket_base;
+    const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ ((unsigned long long)grid << 44) ^ 0x5E00000000000000ull;
     hipError_t e = hipSuccess;
-    if (ep.fresh) {
-        e = hipMemsetAsync(a.ticket, 0, 2 * sizeof(u32), st);
-        if (e == hipSuccess) e = hipMemsetAsync(gran, 0, se_single_extra_bytes(B, C), st);
-        if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: memset -> %s", hipGetErrorString(e)); }
+    if (!ws_known(state, key, st)) {                      // unknown history (first use, other shape, "ws_persistent" off): epoch, ticket, granules
+        e = ws_zero_async(state, fused_state_bytes(B) + se_single_extra_bytes(B, C), st);     // state | granules are contiguous (chan_attn.hip)
+        if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: zeroing -> %s", hipGetErrorString(e)); }
     }
     const size_t smem = (size_t)(C + Cr + (wlds ? 2 * C * Cr : 0)) * sizeof(float);
     const int nv = (a.n4 + 63) / 64;

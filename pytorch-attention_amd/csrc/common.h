@@ -28,6 +28,9 @@ long  opt_ws_persistent();
 struct WsEpoch { unsigned tag; unsigned ticket_base; bool fresh; };
 WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hipStream_t st);   // api.hip: tag + ticket base of this launch
 void  ws_forget(const void* region);
+bool  ws_known(const void* region, unsigned long long key, hipStream_t st);   // api.hip: was this workspace zeroed for this shape? (device-resident launch tags)
+hipError_t ws_zero_async(void* p, size_t bytes, hipStream_t st);   // zero an exchange area with a kernel (capture-safe ordering)
+unsigned* sync_err_word_on(hipStream_t st);     // sync_err_word(), but never allocates inside a stream capture (may return null there)
 bool  stream_is_capturing(hipStream_t st);      // hipGraph capture in progress on this stream
 void  ws_forget_range(const void* base, size_t bytes);
 long  opt_cbam_single();

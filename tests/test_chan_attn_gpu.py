@@ -360,9 +360,11 @@ def test_zoo_single_and_two_pass_agree_and_repeat():
 
 
 def test_exchange_kernels_under_graph_capture():
-    """A captured launch replays with the same kernel arguments, so the granule-exchange kernels (per-launch tags, host-side ticket
-    bases) step aside under hipGraph capture and the multi-pass paths are recorded instead.  Capture SE + CBAM + GCT + ECA, replay with
-    new inputs, interleave eager calls of the same modules (which do use the exchange kernels)."""
+    """hipGraph capture of the channel-attention modules.  SE and CBAM record their single-read exchange kernels: the granule tag of a
+    launch and the ticket word live in the workspace (epoch + 1; the last ticket draw of a launch resets the ticket and advances the
+    epoch), so a replay is just another launch and eager calls may be interleaved with replays on the same workspace -- the results
+    are the same bits either way.  GCT (host-side launch tags) still steps aside to its multi-pass kernels under capture; ECA has no
+    exchange."""
     from mi355attn.modules import GCT
     se, _, cbam = _mods(64)
     gct = GCT(64)
@@ -381,16 +383,52 @@ def test_exchange_kernels_under_graph_capture():
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g), torch.no_grad():
         outs = [m(static_x) for m in mods]
-    for rep in range(3):
+    for rep in range(4):
         x = torch.randn(6, 64, 28, 28, device="cuda")
+        static_x.copy_(x)
+        g.replay()
+        if rep == 2:
+            g.replay()                                    # two replays back to back: the epoch advances inside the graph
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        with torch.no_grad():
+            want = [m(x) for m in mods]                   # eager calls in between, same workspaces
+        for a, b, m in zip(got, want, mods):
+            assert_parity(a.cpu(), b.cpu(), 2e-6, f"replay {rep} {type(m).__name__}")
+        assert torch.equal(got[0], want[0]), "SE: replay and eager launch differ"
+        assert torch.equal(got[1], want[1]), "CBAM: replay and eager launch differ"
+    import mi355attn
+    mi355attn.sync_status(wait=True)
+
+
+def test_exchange_kernels_captured_on_a_cold_workspace():
+    """Capture WITHOUT a warm-up call: the workspace of the module is unknown to the library, so the zeroing of its exchange area is
+    recorded with the launch and repeated by every replay (epoch 0 -> tag 1 each time); results must match eager launches and the
+    oracle, before and after eager calls have made the workspace known."""
+    se, _, cbam = _mods(64)
+    mods = [se.cuda(), cbam.cuda()]
+    torch.manual_seed(43)
+    with torch.no_grad():                                 # code objects are loaded on first launch, which HIP forbids inside a capture:
+        for m in mods:                                    # launch the kernels once on ANOTHER shape (its own workspace)
+            m(torch.randn(2, 64, 28, 28, device="cuda"))
+    torch.cuda.synchronize()
+    static_x = torch.randn(5, 64, 28, 28, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        outs = [m(static_x) for m in mods]
+    for rep in range(3):
+        x = torch.randn(5, 64, 28, 28, device="cuda")
         static_x.copy_(x)
         g.replay()
         torch.cuda.synchronize()
         got = [o.clone() for o in outs]
         with torch.no_grad():
-            want = [m(x) for m in mods]                   # eager calls in between: per-launch tags, remembered workspaces
-        for a, b, m in zip(got, want, mods):
-            assert_parity(a.cpu(), b.cpu(), 2e-6, f"replay {rep} {type(m).__name__}")
+            want = [m(x) for m in mods]
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), f"replay {rep}"
+    ref = O.se_forward(x.cpu(), se.fc[0].weight.cpu(), se.fc[2].weight.cpu())
+    assert_parity(got[0].cpu(), ref, 1e-5, "SE replay vs oracle")
+    import mi355attn
+    mi355attn.sync_status(wait=True)
 
 
 @pytest.mark.parametrize("single", [1, 0])

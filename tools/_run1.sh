@@ -1,4 +1,9 @@
-python tools/ab_so.py pmlp1 | tail -3
-python tools/ab_so.py pmlp2 | tail -3
-timeout 900 python -m pytest tests -m gpu -x -q -k "mlp or gemm or linear or vit or cswin or mixer or pa_ or xc" 2>&1 | tail -3
-python bench.py --no-cpu --no-strict --steps 10 --warmup 3 --only "Vision" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['dominant_kernel']['shapes'] if d['roofline'].get('dominant_kernel') else '')"
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+for blk in "XCABlock" "CSWinBlock s3" "MixerLayer"; do
+tag=$(echo "$blk" | tr -c 'A-Za-z0-9' '_')
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python $R/bench.py --no-cpu --no-strict --steps 5 --warmup 2 --only "$blk" > $R/gpurun_out/prof_$tag.log 2>&1
+echo "== $blk"; grep -o '"ms_per_step": [0-9.]*' $R/gpurun_out/prof_$tag.log | head -1
+python $R/tools/rocpd_stats.py $R/gpurun_out/prof_$tag/p_results.db 2>&1 | head -16 | cut -c1-150
+rm -rf $R/gpurun_out/prof_$tag
+done
