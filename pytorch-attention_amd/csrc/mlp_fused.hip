@@ -208,31 +208,36 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
     }
 }
 
-// ---- C = 128 (hidden 512: CSWin stage 2, XCiT-nano): the weights (256 KB) do not fit in LDS, so all 16 waves walk the hidden
-// blocks in lockstep and the 32-unit slices of W1 (rows) and W2 (columns, pre-arranged slice-major by the caller) stream through a
-// double-buffered 16 KB LDS stage: loads of slice kb+1 are in flight during the MFMAs of slice kb, two barriers per slice.  One
-// 16-token tile per wave (the 128-wide accumulator leaves no room for two).
-// PROJ: x1 = x + ctx Wp^T + bp first (Wp resident in LDS).  The 128-wide accumulator leaves no registers to carry x1 to the epilogue,
-// so a lane parks its x1 values in the y rows it will overwrite at the end and reads them back there (same lane, same addresses:
-// program order; the lines are L2-resident).
+// ---- C = 128 (hidden 512: CSWin stage 2, XCiT-nano): the weights (256 KB) do not fit in LDS, so the waves of a workgroup walk the
+// hidden blocks in lockstep and the 32-unit slices of W1 (rows) and W2 (columns, pre-arranged slice-major by the caller) stream
+// through a double-buffered 16 KB LDS stage: loads of slice kb+1 are in flight during the MFMAs of slice kb, one barrier per slice.
+// EIGHT waves (one workgroup per CU, <= 256 VGPRs) with TWO 16-token tiles each: a weight fragment read from LDS feeds two MFMAs
+// (with sixteen one-tile waves the stage was read 256 KB per slice -- 2048 LDS clocks against 256 matrix-pipe clocks per wave), and
+// the two tiles give a wave independent MFMA chains to run the GELU of one under.
+// PROJ: x1 = x + ctx Wp^T + bp first (Wp resident in LDS).  x1 is parked in the y rows the lane will overwrite at the end and read
+// back there (same lane, same addresses: program order; the lines are L2-resident).
 template <int PREC, int C, int HD, bool PROJ = false>
-__global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(512, 2) void mlp_fused_stream_kernel(const MlpArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
     using v4 = typename M_::v4;
     using el = typename M_::e;
-    constexpr int NWV = 16;
+    constexpr int NWV = 8, TT = 2, NTHR = 64 * NWV;
     constexpr int P1 = C + 8, P2 = 32 + 4, SPH = 64 + 4;       // W1 slice [32][P1], W2 slice [C][P2], slab [16][SPH] (64 channels at a time)
     constexpr int KS = C / 32, NT = C / 16, NKB = HD / 32;
     constexpr int W1S = 32 * P1, W2S = C * P2, STAGE = W1S + W2S;
-    static_assert(32 * C / 8 == 512 && C * 32 / 8 == 512, "one 16-byte load per thread and slice");
+    static_assert(32 * C / 8 == NTHR && C * 32 / 8 == NTHR, "one 16-byte load of each matrix per thread and slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     el* s_stage = reinterpret_cast<el*>(lds);                   // two stages
     float* s_slab = reinterpret_cast<float*>(s_stage + 2 * STAGE);
     el* s_wp = reinterpret_cast<el*>(s_slab + NWV * 16 * SPH);  // PROJ: (C, C), rows = output channels, pitch P1
+    // b1 lives in LDS: read from global memory inside the slice loop it sat BEHIND the fetch of the next weight slice in the wave's
+    // in-order memory queue, so every slice began by waiting for that fetch (the latency the double buffer is there to hide)
+    float* s_b1 = reinterpret_cast<float*>(s_wp + (PROJ ? C * P1 : 0));
+    for (int i = threadIdx.x; i < HD; i += NTHR) s_b1[i] = a.b1[i];
     if constexpr (PROJ) {
         const el* wp = static_cast<const el*>(a.wp);
-        for (int i = threadIdx.x; i < C * (C / 8); i += 1024) {
+        for (int i = threadIdx.x; i < C * (C / 8); i += NTHR) {
             const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
             *reinterpret_cast<v8*>(s_wp + r * P1 + c8) = *reinterpret_cast<const v8*>(wp + (long)r * C + c8);
         }
@@ -243,28 +248,30 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
     const float invC = 1.0f / (float)C;
     const el* w1 = static_cast<const el*>(a.w1);
     const el* w2c = static_cast<const el*>(a.w2);               // (HD/32, C, 32) slice-major
-    // this thread's element of every slice: threads 0-511 carry W1 rows, 512-1023 carry W2
-    const bool is_w1 = t < 512;
-    const int ti = t & 511;
-    const int srow = is_w1 ? ti / (C / 8) : ti / 4, scol = is_w1 ? (ti % (C / 8)) * 8 : (ti % 4) * 8;
-    const int sdst = is_w1 ? srow * P1 + scol : W1S + srow * P2 + scol;
-    auto fetch = [&](int kb) -> v8 {
-        return is_w1 ? *reinterpret_cast<const v8*>(w1 + ((long)kb * 32 + srow) * C + scol)
-                     : *reinterpret_cast<const v8*>(w2c + ((long)kb * C + srow) * 32 + scol);
+    // this thread's 16 bytes of every W1 slice (row r1, columns c1) and of every W2 slice (row r2, columns c2)
+    const int r1 = t / (C / 8), c1 = (t % (C / 8)) * 8, r2 = t / 4, c2 = (t % 4) * 8;
+    const int d1 = r1 * P1 + c1, d2 = W1S + r2 * P2 + c2;
+    v8 n1, n2;
+    auto fetch = [&](int kb) {
+        n1 = *reinterpret_cast<const v8*>(w1 + ((long)kb * 32 + r1) * C + c1);
+        n2 = *reinterpret_cast<const v8*>(w2c + ((long)kb * C + r2) * 32 + c2);
     };
-    auto commit = [&](int buf, v8 v) {
-        el* d = s_stage + buf * STAGE + sdst;
-        if (is_w1) *reinterpret_cast<v8*>(d) = v;
-        else { *reinterpret_cast<v4*>(d) = v4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<v4*>(d + 4) = v4{v[4], v[5], v[6], v[7]}; }
+    auto commit = [&](int buf) {
+        el* d = s_stage + buf * STAGE;
+        *reinterpret_cast<v8*>(d + d1) = n1;
+        *reinterpret_cast<v4*>(d + d2) = v4{n2[0], n2[1], n2[2], n2[3]};
+        *reinterpret_cast<v4*>(d + d2 + 4) = v4{n2[4], n2[5], n2[6], n2[7]};
     };
 
     const long ntile = (a.M + 15) / 16;
-    const long niter = (ntile + NWV - 1) / NWV;                   // workgroup steps: 256 tokens each, uniform trip count for the barriers
+    const long niter = (ntile + NWV * TT - 1) / (NWV * TT);       // workgroup steps: 256 tokens each, uniform trip count for the barriers
     for (long it = blockIdx.x; it < niter; it += gridDim.x) {
-        const long tok0 = (it * NWV + wave) * 16;
-        const long tok = tok0 + l15;
-        v8 xb[KS];
-        {
+        const long tok0 = (it * NWV + wave) * (16 * TT);
+        v8 xb[TT][KS];
+        f4 x1lo[PROJ ? TT : 1][KS], x1hi[PROJ ? TT : 1][KS];       // PROJ: the residual stream after the projection, kept for the epilogue
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const long tok = tok0 + tt * 16 + l15;
             f4 lo[KS], hi[KS];
             const float* xr = a.x + (tok < a.M ? tok : 0) * C + g * 8;
 #pragma unroll
@@ -288,14 +295,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
                             acc = M_::mma(*reinterpret_cast<const v8*>(s_wp + nrow * P1 + ks * 32 + g * 8), cb[ks], acc);
                         if (h == 0) lo[kp] = lo[kp] + acc; else hi[kp] = hi[kp] + acc;
                     }
-                if (tok < a.M) {
-                    float* yr = a.y + tok * C + g * 8;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        *reinterpret_cast<f4*>(yr + ks * 32) = lo[ks];
-                        *reinterpret_cast<f4*>(yr + ks * 32 + 4) = hi[ks];
-                    }
-                }
+                for (int ks = 0; ks < KS; ++ks) { x1lo[tt][ks] = lo[ks]; x1hi[tt][ks] = hi[ks]; }
             }
             float mean = 0.f, rstd = 1.f;
             if (a.do_ln) {
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
                 float q = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const f4 d0 = lo[ks] - mean, d1 = hi[ks] - mean;
-                    q += ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) + ((d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w));
+                    const f4 d0 = lo[ks] - mean, d1_ = hi[ks] - mean;
+                    q += ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) + ((d1_.x * d1_.x + d1_.y * d1_.y) + (d1_.z * d1_.z + d1_.w * d1_.w));
                 }
                 q += __shfl_xor(q, 16, WAVE);
                 q += __shfl_xor(q, 32, WAVE);
@@ -318,71 +319,90 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_stream_kernel(const MlpArgs
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v4 h0 = M_::cvt((lo[ks] - mean) * rstd), h1 = M_::cvt((hi[ks] - mean) * rstd);
-                xb[ks] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                xb[tt][ks] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             }
         }
-        f4 o[NT];
+        f4 o[TT][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) o[nt] = f4{0.f, 0.f, 0.f, 0.f};
-        v8 nxt = fetch(0);
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) o[tt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        fetch(0);
         __syncthreads();                                           // previous step's readers of stage 0 are done
-        commit(0, nxt);
+        commit(0);
         __syncthreads();
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             const int buf = kb & 1;
-            if (kb + 1 < NKB) nxt = fetch(kb + 1);                 // in flight during the MFMAs below
+            if (kb + 1 < NKB) fetch(kb + 1);                       // in flight during the MFMAs below
             const el* sw1 = s_stage + buf * STAGE;
             const el* sw2 = sw1 + W1S;
-            f4 s[2];
+            f4 s[TT][2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                s[h2] = *reinterpret_cast<const f4*>(a.b1 + kb * 32 + h2 * 16 + g * 4);
+                const f4 bias = *reinterpret_cast<const f4*>(s_b1 + kb * 32 + h2 * 16 + g * 4);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    s[h2] = M_::mma(*reinterpret_cast<const v8*>(sw1 + (h2 * 16 + l15) * P1 + ks * 32 + g * 8), xb[ks], s[h2]);
+                for (int tt = 0; tt < TT; ++tt) s[tt][h2] = bias;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v8 wf = *reinterpret_cast<const v8*>(sw1 + (h2 * 16 + l15) * P1 + ks * 32 + g * 8);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) s[tt][h2] = M_::mma(wf, xb[tt][ks], s[tt][h2]);
+                }
             }
-            const f4 p0 = gelu16_fast4(s[0]);
-            const f4 p1 = gelu16_fast4(s[1]);
-            const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
-            const v8 pf = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            v8 pf[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const f4 p0 = gelu16_fast4(s[tt][0]);
+                const f4 p1 = gelu16_fast4(s[tt][1]);
+                const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
+                pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const el* wr = sw2 + (nt * 16 + l15) * P2 + g * 4;
                 const v4 a0 = *reinterpret_cast<const v4*>(wr), a1 = *reinterpret_cast<const v4*>(wr + 16);
-                o[nt] = M_::mma(pf, v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, o[nt]);
+                const v8 vf = v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) o[tt][nt] = M_::mma(pf[tt], vf, o[tt][nt]);
             }
             if (kb + 1 < NKB) {
-                commit(buf ^ 1, nxt);                              // stage buf^1 was last read at slice kb-1: everybody passed the barrier below
+                commit(buf ^ 1);                                   // stage buf^1 was last read at slice kb-1: everybody passed the barrier below
                 __syncthreads();
             }
         }
-        // ---- epilogue, 64 channels at a time: (+ b2) * gamma -> slab -> + x -> row stores ------------------------------------------------
+        // ---- epilogue per token tile, 64 channels at a time: (+ b2) * gamma -> slab -> + x -> row stores ---------------------------------
 #pragma unroll
-        for (int hh = 0; hh < C / 64; ++hh) {
+        for (int tt = 0; tt < TT; ++tt) {
+            const long tok = tok0 + tt * 16 + l15;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cidx = hh * 64 + j * 16 + l15;
-                const float b2 = a.b2 ? a.b2[cidx] : 0.f, gm = a.gamma ? a.gamma[cidx] : 1.f;
+            for (int hh = 0; hh < C / 64; ++hh) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(g * 4 + r) * SPH + j * 16 + l15] = (o[hh * 4 + j][r] + b2) * gm;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (tok < a.M) {
-                const float* xr = (PROJ ? a.y : a.x) + tok * C + hh * 64 + g * 8;
-                float* yr = a.y + tok * C + hh * 64 + g * 8;
+                for (int j = 0; j < 4; ++j) {
+                    const int cidx = hh * 64 + j * 16 + l15;
+                    const float b2 = a.b2 ? a.b2[cidx] : 0.f, gm = a.gamma ? a.gamma[cidx] : 1.f;
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const f4 r0 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8);
-                    const f4 r1 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8 + 4);
-                    const f4 x0 = *reinterpret_cast<const f4*>(xr + k2 * 32), x1 = *reinterpret_cast<const f4*>(xr + k2 * 32 + 4);
-                    *reinterpret_cast<f4*>(yr + k2 * 32) = x0 + r0;
-                    *reinterpret_cast<f4*>(yr + k2 * 32 + 4) = x1 + r1;
+                    for (int r = 0; r < 4; ++r) slab[(g * 4 + r) * SPH + j * 16 + l15] = (o[tt][hh * 4 + j][r] + b2) * gm;
                 }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (tok < a.M) {
+                    const float* xr = a.x + tok * C + hh * 64 + g * 8;
+                    float* yr = a.y + tok * C + hh * 64 + g * 8;
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const f4 r0 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8);
+                        const f4 r1 = *reinterpret_cast<const f4*>(slab + l15 * SPH + k2 * 32 + g * 8 + 4);
+                        f4 x0, x1;
+                        if constexpr (PROJ) { x0 = x1lo[tt][hh * 2 + k2]; x1 = x1hi[tt][hh * 2 + k2]; }
+                        else { x0 = *reinterpret_cast<const f4*>(xr + k2 * 32); x1 = *reinterpret_cast<const f4*>(xr + k2 * 32 + 4); }
+                        *reinterpret_cast<f4*>(yr + k2 * 32) = x0 + r0;
+                        *reinterpret_cast<f4*>(yr + k2 * 32 + 4) = x1 + r1;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 }
@@ -409,16 +429,16 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (C == 128) {
-        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)16 * 16 * 68 * 4;
+        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)8 * 16 * 68 * 4 + (size_t)512 * 4;
         static_assert(sm <= 160 * 1024, "LDS budget");
         const long niter = ((M + 15) / 16 + 15) / 16;
         const int grid2 = (int)(niter < ncu ? niter : ncu);
         if (precision == MI355_PREC_FP16) {
             if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512>), (int)sm)) return rc;
-            mlp_fused_stream_kernel<1, 128, 512><<<grid2, 1024, sm, st>>>(a);
+            mlp_fused_stream_kernel<1, 128, 512><<<grid2, 512, sm, st>>>(a);
         } else {
             if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512>), (int)sm)) return rc;
-            mlp_fused_stream_kernel<2, 128, 512><<<grid2, 1024, sm, st>>>(a);
+            mlp_fused_stream_kernel<2, 128, 512><<<grid2, 512, sm, st>>>(a);
         }
         MI355_LAUNCH_CHECK();
         return MI355_OK;
@@ -454,16 +474,16 @@ extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ncu = mi355::resident_slots(1);
     if (C == 128) {
-        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)16 * 16 * 68 * 4 + (size_t)128 * (128 + 8) * 2;
+        constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)8 * 16 * 68 * 4 + (size_t)128 * (128 + 8) * 2 + (size_t)512 * 4;
         static_assert(sm <= 160 * 1024, "LDS budget");
         const long niter = ((M + 15) / 16 + 15) / 16;
         const int grid2 = (int)(niter < ncu ? niter : ncu);
         if (precision == MI355_PREC_FP16) {
             if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<1, 128, 512, true>), (int)sm)) return rc;
-            mlp_fused_stream_kernel<1, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
+            mlp_fused_stream_kernel<1, 128, 512, true><<<grid2, 512, sm, st>>>(a);
         } else {
             if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_stream_kernel<2, 128, 512, true>), (int)sm)) return rc;
-            mlp_fused_stream_kernel<2, 128, 512, true><<<grid2, 1024, sm, st>>>(a);
+            mlp_fused_stream_kernel<2, 128, 512, true><<<grid2, 512, sm, st>>>(a);
         }
         MI355_LAUNCH_CHECK();
         return MI355_OK;
