@@ -69,14 +69,17 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "ws_persistent" 0 (default) = the single-read kernels zero their exchange area in the workspace on every call; 1 = the caller
  *                   promises that a workspace handed to mi355_se_fwd / mi355_cbam_fwd is DEDICATED to that op and shape: nobody
  *                   else writes it between calls and it is not freed and re-allocated behind the library's back (call
- *                   mi355_workspace_forget before freeing it).  The library then remembers the buffer, stamps every launch with
- *                   a fresh tag and skips the memset (43 MB per call at the C2 shape of CBAM).
+ *                   mi355_workspace_forget before freeing it).  The library then remembers that the buffer has been zeroed for the
+ *                   shape and skips the zeroing (43 MB per call at the C2 shape of CBAM); the launch tag and the ticket of the
+ *                   SE / CBAM exchange live in the workspace itself (epoch + 1; reset by the last ticket draw of a launch).
  *   "zoo_single"    1 (default) = SimAM / SRM / GCT / LCT read x once when the shape allows; 0 = always two passes.
  *   "stem_direct"   1 (default) = mi355_conv2d_tokens_fwd runs the image layer of a narrow stem (NCHW input, Cin <= 4, Cout <= 64,
  *                   Cin*kh*kw*Cout <= 2048, e.g. 3 -> 16 3x3) on a direct fp32 kernel; 0 = implicit GEMM for every shape.
- *                   Under hipGraph stream capture the granule-exchange kernels are not used at all (a recorded launch replays with the
- *                   same tag and ticket base): mi355_se_fwd / mi355_cbam_fwd / the GCT and LCT entry points record their multi-pass
- *                   kernels instead, so captured graphs are replay-safe by construction.
+ *                   hipGraph stream capture: mi355_se_fwd / mi355_cbam_fwd record their single-read exchange kernels (nothing about
+ *                   a launch lives on the host, so replays and eager launches may share a workspace; an unknown workspace gets its
+ *                   zeroing kernel recorded with the launch).  The GCT and LCT entry points (host-side launch tags) record their
+ *                   multi-pass kernels instead.  A kernel's first launch loads its code object, which HIP forbids inside a capture:
+ *                   run every entry once eagerly before capturing it.
  *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status:
  *                   1024 .. 2^30 (default 2^22 ~ a second); 0 is accepted to force the time-out path in tests (every exchange then
  *                   fails on its first unsuccessful poll).
