@@ -288,9 +288,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], post, mneg));     // fma(-inf, post, .) = -inf -> 0
-                    s[kt][r] = p;
-                    sum += p;
+                    s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], post, mneg));         // fma(-inf, post, .) = -inf -> 0
                 }
         } else {
 #pragma unroll
@@ -313,12 +311,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                     sum += p;
                 }
         }
-        sum += __shfl_xor(sum, 16, WAVE);
-        sum += __shfl_xor(sum, 32, WAVE);
+        if constexpr (!(PREC != 0 && FMA_SM)) {
+            sum += __shfl_xor(sum, 16, WAVE);
+            sum += __shfl_xor(sum, 32, WAVE);
+        }
         // O^T = V^T . P^T : A = V^T (row d = l15, k enumerates keys as (tile 2kb, g, r) then (tile 2kb+1, g, r)); B = P^T, the S^T
     // accumulators re-packed in-lane (column q = l15, same key enumeration) -> lane holds O[q = l15][d = nt*16 + g*4 + r]
 #pragma unroll
         for (int nt = 0; nt < D / 16; ++nt) o[nt] = zero4;
+        // 16-bit operand modes: the row sum comes off the matrix pipe as well -- one more A tile whose rows are all ones gives
+        // sum_k P^T[k][q] in every row of its accumulator, i.e. in THIS lane for query l15: 56 VALU adds and two lane-group exchanges
+        // per query tile become KT/2 MFMAs (the pipe is 22 % busy), and the normaliser is the sum of the very P values (rounded to
+        // 16 bit) that enter the numerator
+        f4 osum = zero4;
+        typedef typename M_::e el1_t;
+        const v8 ones = v8{(el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f, (el1_t)1.0f};
 #pragma unroll
         for (int kb = 0; kb < KT / 2; ++kb) {
             if (2 * kb < TFULL || kb * 32 < T) {                  // compile-time true for the full key tiles
@@ -344,8 +351,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void win_attn_kernel(const AttnPair p
                     }
                     o[nt] = mma_step<PREC>(vf, pf, o[nt]);      // O^T = V^T . P^T
                 }
+                if constexpr (PREC != 0 && FMA_SM) osum = M_::mma(ones, pf[0], osum);
             }
         }
+        if constexpr (PREC != 0 && FMA_SM) sum = osum.x;
         // normalise.  O was accumulated TRANSPOSED (O^T = V^T . P^T, below): lane (l15, g) holds O[query l15][channel nt*16 + g*4 + r],
         // i.e. the accumulator rows are the rows of the softmax statistics -- the row sum is already in this lane (no shuffles), one
         // reciprocal per lane, and a lane's four values are four consecutive channels of one token: one 8- / 16-byte slab write per

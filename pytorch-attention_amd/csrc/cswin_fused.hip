@@ -282,20 +282,15 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
             m = fmaxf(m, __shfl_xor(m, 16, WAVE));
             m = fmaxf(m, __shfl_xor(m, 32, WAVE));
             const float nm = -(m * L2E);
-            float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], L2E, nm));
-                    s[kt][r] = p;
-                    sum += p;
-                }
-            sum += __shfl_xor(sum, 16, WAVE);
-            sum += __shfl_xor(sum, 32, WAVE);
+                for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], L2E, nm));
             // O^T = V^T P^T: the accumulator of a lane holds features nt*16 + g*4 + r of query l15 -- the query its softmax
             // statistics belong to, so the normaliser needs no exchange and a lane's four features leave as one 16-byte write
-            f4 o[2] = {zero4, zero4};
+            // the row sum comes off the matrix pipe too (an A tile of ones: every accumulator row = sum_k P^T[k][q], attn.hip)
+            f4 o[2] = {zero4, zero4}, osum = zero4;
+            const v8 ones = v8{(el)1.0f, (el)1.0f, (el)1.0f, (el)1.0f, (el)1.0f, (el)1.0f, (el)1.0f, (el)1.0f};
 #pragma unroll
             for (int kb = 0; kb < KT / 2; ++kb) {
                 if (kb * 32 < T) {
@@ -307,9 +302,10 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
                         const v4 a0 = *reinterpret_cast<const v4*>(vr), a1 = *reinterpret_cast<const v4*>(vr + 16);
                         o[nt] = M_::mma(v8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pf, o[nt]);
                     }
+                    osum = M_::mma(ones, pf, osum);
                 }
             }
-            const float inv = __builtin_amdgcn_rcpf(sum);
+            const float inv = __builtin_amdgcn_rcpf(osum.x);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f4*>(slab + l15 * OP + nt * 16 + g * 4) = o[nt] * inv;
             __builtin_amdgcn_wave_barrier();
