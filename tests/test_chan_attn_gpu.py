@@ -401,6 +401,42 @@ def test_exchange_kernels_under_graph_capture():
     mi355attn.sync_status(wait=True)
 
 
+def test_exchange_kernels_under_graph_capture_at_the_bench_shape():
+    """The same at the C2 geometry (256 channels, 56 x 56: 32 slices / 28 bands per image, several slices per workgroup): replays
+    interleaved with eager launches on the same workspaces, bit-equal, and equal to the multi-pass kernels within fp32 noise."""
+    import mi355attn
+    se, _, cbam = _mods(256)
+    mods = [se.cuda(), cbam.cuda()]
+    torch.manual_seed(47)
+    static_x = torch.randn(24, 256, 56, 56, device="cuda")
+    with torch.no_grad():
+        for m in mods:
+            m(static_x)                                   # loads the code objects, makes the eager workspaces known
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        outs = [m(static_x) for m in mods]
+    for rep in range(3):
+        x = torch.randn(24, 256, 56, 56, device="cuda")
+        static_x.copy_(x)
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        with torch.no_grad():
+            want = [m(x) for m in mods]
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), f"replay {rep}"
+    mi355attn.set_option("se_single", 0); mi355attn.set_option("cbam_single", 0)
+    try:
+        with torch.no_grad():
+            multi = [m(x) for m in mods]
+    finally:
+        mi355attn.set_option("se_single", 1); mi355attn.set_option("cbam_single", 1)
+    assert_parity(got[0].cpu(), multi[0].cpu(), 2e-6, "SE single-read (replayed) vs two-pass")
+    assert_parity(got[1].cpu(), multi[1].cpu(), 2e-6, "CBAM single-read (replayed) vs three-pass")
+    mi355attn.sync_status(wait=True)
+
+
 def test_exchange_kernels_captured_on_a_cold_workspace():
     """Capture WITHOUT a warm-up call: the workspace of the module is unknown to the library, so the zeroing of its exchange area is
     recorded with the launch and repeated by every replay (epoch 0 -> tag 1 each time); results must match eager launches and the
