@@ -53,7 +53,12 @@ typedef void* mi355_stream_t; /* hipStream_t */
 /* ---- library ------------------------------------------------------------------------------------- */
 int         mi355_version(void);            /* ABI version, bumped on any signature change */
 const char* mi355_last_error(void);         /* thread-local message of the last failing call */
-/* Tuning knobs of the channel-attention family (process-global, read at launch; results never depend on them):
+/* Tuning knobs (read at launch; results never depend on them unless a key says so).  Scope: mi355_set_option / mi355_get_option act
+ * on the calling thread's CURRENT HIP device -- every device has its own option block, and every launch reads the block of the device
+ * it launches on, so a host that drives several GPUs from one process can tune (or, in a test, sabotage) one of them without the
+ * others seeing it.  A device whose key was never set follows the process default, which mi355_set_default_option changes (what a
+ * binding uses for promises it makes for every device, e.g. "ws_persistent").  The failure word of mi355_sync_status and the range
+ * word of mi355_range_status are per device as well: a time-out or an fp16 overflow on one GPU never fails another GPU's next call.
  *   "chunk_images"  images per pool->scale chunk (0 = auto: ~200 MB of x per chunk so that a chunk's re-read is served
  *                   by the 256 MiB Infinity Cache -- default; a value >= B disables chunking);
  *   "nt"            bit0 = non-temporal loads, bit1 = non-temporal stores in the final streaming pass (default 3);
@@ -77,8 +82,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   Cin*kh*kw*Cout <= 2048, e.g. 3 -> 16 3x3) on a direct fp32 kernel; 0 = implicit GEMM for every shape.
  *                   hipGraph stream capture: mi355_se_fwd / mi355_cbam_fwd record their single-read exchange kernels (nothing about
  *                   a launch lives on the host, so replays and eager launches may share a workspace; an unknown workspace gets its
- *                   zeroing kernel recorded with the launch).  The GCT and LCT entry points (host-side launch tags) record their
- *                   multi-pass kernels instead.  A kernel's first launch loads its code object, which HIP forbids inside a capture:
+ *                   zeroing kernel recorded with the launch).  The GCT and LCT entry points do the same since round 4 (their launch tag
+ *                   moved into the workspace as well).  A kernel's first launch loads its code object, which HIP forbids inside a capture:
  *                   run every entry once eagerly before capturing it.
  *   "spin_limit"    poll budget (sweeps) of the exchange kernels before they give up and report through mi355_sync_status:
  *                   1024 .. 2^30 (default 2^22 ~ a second); 0 is accepted to force the time-out path in tests (every exchange then
@@ -91,10 +96,15 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_pa"       1 (default) = fp32 (+ residual) outputs with M % 128 == 0, N % 256 == 0, K >= 640 run the two-accumulator
  *                   persistent kernel (the epilogue of tile i rides in the main loop of tile i + 1; no inter-workgroup exchange, so it
  *                   is capture-safe and every row is bit-identical whatever the batch); 0 = never.
- *   "gemm_variant"  tile / schedule variant of mi355_linear16_fwd (0 = library default; others are tuning experiments).
- * Unknown key -> MI355_EINVAL. */
-int         mi355_set_option(const char* key, long value);
-long        mi355_get_option(const char* key);
+ *   "gemm_variant"  0 (default) = kernel chosen by shape; 7 / 15 / 16 force the round-1 tile kernel / the persistent 256 x 256 kernel / the
+ *                   two-accumulator persistent kernel (bit-identical results; A/B partners of the tests).  Values above 16 are refused.
+ *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
+ *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
+ *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.
+ * Unknown key or a value outside the key's range -> MI355_EINVAL. */
+int         mi355_set_option(const char* key, long value);          /* current device */
+int         mi355_set_default_option(const char* key, long value);  /* process default: devices without an own setting */
+long        mi355_get_option(const char* key);                      /* what a launch on the current device would read */
 /* Drop what the library remembers about workspaces inside [ws, ws + ws_bytes) ("ws_persistent"): call before freeing or
  * repurposing such a buffer.  The next call that uses the memory zeroes its exchange area again. */
 int         mi355_workspace_forget(const void* ws, size_t ws_bytes);
@@ -459,6 +469,35 @@ size_t mi355_patch_embed_workspace_bytes(int B, int Cin, int H, int W, int ps, i
 int mi355_patch_embed_ws_fwd(const float* img, const float* Wp, const float* bp, const float* cls, const float* pos,
                              float* tokens, int B, int Cin, int H, int W, int ps, int E, int precision,
                              void* ws, size_t ws_bytes, mi355_stream_t stream);
+
+/* ---- LayerNorm folded into the GEMMs around it (csrc/ln_fold.hip; the pre-LN chain of ViT.py:116-119) -----------------------------
+ * Replaces "GEMM -> LayerNorm launch -> GEMM" by three pieces that never re-read the fp32 stream:
+ *   mi355_linear16_emit_fwd    producer: Y (M,N) fp32 = resid + act(X16 W16^T + bias) exactly as mi355_linear16_fwd, and beside it
+ *                              a16_out[m][n] = T(Y[m][n] - cvec[m]) (16-bit operand type of `precision`, row stride N) and
+ *                              stats[(n / 32) * M + m] = {mean, sum of squared deviations} of Y[m][32 g .. 32 g + 31] (fp32 pairs,
+ *                              mi355_ln_fold_stats_bytes(M, N) bytes).  Two-accumulator persistent kernel only: M % 128 == 0,
+ *                              N % 256 == 0, K % 64 == 0, K >= 640, else MI355_EUNSUPPORTED (nothing touched).
+ *   mi355_ln_finalize_fwd      per row: exact mean mu / rstd r of Y from the group pairs; rowtau[m] = {r, r (cvec[m] - mu)};
+ *                              cvec[m] := mu.  A row with |cvec - mu| > tol * std, or std outside [2^-7, 2^10] (fp16 band of
+ *                              Y - cvec), is REWRITTEN from x (= Y, row stride cols): a16 = T((x - mu) r), rowtau = {1, 0} -- the
+ *                              plain LayerNorm operand -- so the result never depends on how well cvec predicted the mean.
+ *                              slow_rows (device word or NULL) counts such rows (diagnostics).
+ *   mi355_linear16_lnfold_fwd  consumer: Y16 = act(rowtau[m].x * (A16 W16'^T)[m][n] + rowtau[m].y * colsum[n] + bias[n]) with
+ *                              W16'[n][k] = T(gamma[k] W[n][k]), colsum[n] = sum_k W16'[n][k] (fp32 sum of the ROUNDED weights),
+ *                              bias = b + W beta: = act(LayerNorm(Y) W^T + b) of the reference.  Persistent 256 x 256 kernel.
+ *   mi355_ln_center16_fwd      first LayerNorm of a chain (no producer): a16 = T((x - mu) r), rowtau = {1, 0}, cvec = mu for every row;
+ *                              cols % 4 == 0, cols <= 2048.
+ * precision 1 (fp16) or 2 (bf16).  Results: within operand rounding of LayerNorm -> 16-bit -> GEMM (the rounding point moves from
+ * LayerNorm(x) to x - c; tests/test_ln_fold_gpu.py bounds the difference). */
+size_t mi355_ln_fold_stats_bytes(int rows, int cols);
+int mi355_ln_center16_fwd(const float* x, void* a16, float* rowtau, float* cvec, int rows, int cols, float eps, int precision,
+                          mi355_stream_t stream);
+int mi355_ln_finalize_fwd(const float* stats, const float* x, void* a16, float* cvec, float* rowtau, int rows, int cols, float eps,
+                          float tol, int precision, unsigned* slow_rows, mi355_stream_t stream);
+int mi355_linear16_emit_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K, int ldx,
+                            int act, int precision, const float* cvec, void* a16_out, float* stats, mi355_stream_t stream);
+int mi355_linear16_lnfold_fwd(const void* A16, const void* W16, const float* bias, const float* rowtau, const float* colsum, void* Y16,
+                              int M, int N, int K, int lda, int ldy, int act, int precision, mi355_stream_t stream);
 
 /* ViT Attention.forward as ONE call (ViT.py:79-89; SURVEY 8b lists `mhsa` among the exported ops):
  *   y = resid + proj( concat_heads( softmax(q k^T scale) v ) ) + b_proj,   [q | k | v] = x Wqkv^T + b_qkv  viewed (B,N,3,heads,d)

@@ -7,23 +7,61 @@
 
 namespace mi355 {
 static thread_local char g_err[512] = "";
-static std::atomic<long> g_chunk_images{0};   // 0 = auto (about 200 MB of x per chunk)
-static std::atomic<long> g_nt{3};        // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
-static std::atomic<long> g_reverse{0};
-static std::atomic<long> g_gemm_variant{0};   // tile/schedule variant of the 16-bit GEMM (gemm16.hip)
 
-static std::atomic<long> g_eca_single{1};   // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
-static std::atomic<long> g_se_single{1};    // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
-static std::atomic<long> g_cbam_single{1};  // CBAM: x read once, row bands in registers, three granule hops per band (cbam_single.hip)
-static std::atomic<long> g_ws_persistent{0};  // 1 = caller keeps workspace contents between calls: granule exchanges skip their memset
-static std::atomic<long> g_stem_direct{1};  // narrow conv stems: direct fp32 kernel (stem_conv.hip) vs implicit GEMM
-static std::atomic<long> g_zoo_single{1};   // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
-static std::atomic<long> g_spin_limit{1L << 22};   // poll budget of the exchange kernels (sweeps) before they give up with an error code
-static std::atomic<long> g_gemm_pa{1};       // fp32-output GEMMs: two-accumulator persistent kernel where it applies (gemm16_pa.hip)
-static std::atomic<long> g_gemm_splitk{1};   // persistent GEMM: cut the tiles of the last partial round along K (gemm16_p8.hip)
-std::atomic<long> g_da_fused{1};       // DoubleAttention: two-pass kernels where they apply (double_attn_fused.hip)
-std::atomic<long> g_da_ranges{0};      // ... pixel ranges per image in pass 1: 0 = from the batch size, 1..32 = fixed
-static std::atomic<long> g_se_occ{3};        // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
+// ---- tuning options: ONE BLOCK PER DEVICE --------------------------------------------------------------------------------------
+// mi355_set_option / mi355_get_option act on the block of the calling thread's CURRENT device (hipGetDevice), and every launch reads
+// the block of the device it launches on: a host that drives eight GPUs from one process (one thread per GPU) can tune --
+// or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
+constexpr int MAX_DEV = 64;
+enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_COUNT };
+struct OptDesc { const char* key; long def, lo, hi; };
+// key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
+// its first unsuccessful poll; real budgets start at 1024 sweeps)
+static const OptDesc kOpts[O_COUNT] = {
+    {"chunk_images", 0, 0, 1L << 40},    // 0 = auto (about 200 MB of x per chunk)
+    {"nt", 3, 0, 3},                       // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
+    {"reverse", 0, 0, 1},
+    {"gemm_variant", 0, 0, 16},            // tile/schedule variant of the 16-bit GEMM (gemm16.hip); 0 = dispatch by shape
+    {"eca_single", 1, 0, 1},               // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
+    {"se_single", 1, 0, 1},                // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
+    {"cbam_single", 1, 0, 1},              // CBAM: x read once, row bands in registers, granule hops per band (cbam_single.hip)
+    {"ws_persistent", 0, 0, 1},            // 1 = caller keeps workspace contents between calls: granule exchanges skip their zeroing
+    {"stem_direct", 1, 0, 1},              // narrow conv stems: direct fp32 kernel (stem_conv.hip) vs implicit GEMM
+    {"zoo_single", 1, 0, 1},               // SimAM / SRM / GCT / LCT: single-read register-resident path (chan_stat.hip) vs two passes
+    {"spin_limit", 1L << 22, 1024, 1L << 30},   // poll budget of the exchange kernels (sweeps) before they give up with an error code
+    {"gemm_pa", 1, 0, 1},                  // fp32-output GEMMs: two-accumulator persistent kernel where it applies (gemm16_pa.hip)
+    {"gemm_splitk", 1, 0, 1},              // persistent GEMM: cut the tiles of the last partial round along K (gemm16_p8.hip)
+    {"da_fused", 1, 0, 1},                 // DoubleAttention: fused kernels where they apply (double_attn_fused.hip, double_attn_small.hip)
+    {"da_ranges", 0, 0, 32},               // ... pixel ranges per image in pass 1: 0 = from the batch size, 1..32 = fixed
+    {"se_occ", 3, 2, 3},                   // single-read SE: workgroups per CU (2: <= 128 VGPRs, 3: <= 80 VGPRs)
+    {"ln_fold", 0, 0, 1},                  // ViT encoder chain: 1 = LayerNorm folded into the neighbouring GEMMs (ln_fold.hip); measured slower
+                                           // than the LayerNorm launches it removes, so it is opt-in
+};
+namespace {
+constexpr long OPT_UNSET = (long)0x8000000000000000ull;              // a device block entry that follows the process default
+struct OptBlock { std::atomic<long> v[O_COUNT]; };
+OptBlock g_opt[MAX_DEV];                 // per-device overrides (mi355_set_option on the current device)
+std::atomic<long> g_def[O_COUNT];        // process defaults (mi355_set_default_option): what a device without an override reads
+std::once_flag g_opt_once;
+int cur_dev() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev >= 0 && dev < MAX_DEV ? dev : 0;
+}
+void opt_init() {
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < O_COUNT; ++i) g_def[i].store(kOpts[i].def, std::memory_order_relaxed);
+        for (auto& b : g_opt)
+            for (int i = 0; i < O_COUNT; ++i) b.v[i].store(OPT_UNSET, std::memory_order_relaxed);
+    });
+}
+inline long opt(Opt o) {
+    opt_init();
+    const long v = g_opt[cur_dev()].v[o].load(std::memory_order_relaxed);
+    return v != OPT_UNSET ? v : g_def[o].load(std::memory_order_relaxed);
+}
+}  // namespace
 
 char* err_buf() { return g_err; }
 
@@ -34,32 +72,27 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
-long opt_chunk_images() { return g_chunk_images.load(std::memory_order_relaxed); }
-long opt_nt() { return g_nt.load(std::memory_order_relaxed); }
-long opt_reverse() { return g_reverse.load(std::memory_order_relaxed); }
-long opt_eca_single() { return g_eca_single.load(std::memory_order_relaxed); }
-long opt_se_single() { return g_se_single.load(std::memory_order_relaxed); }
-long opt_cbam_single() { return g_cbam_single.load(std::memory_order_relaxed); }
-long opt_ws_persistent() { return g_ws_persistent.load(std::memory_order_relaxed); }
+long opt_chunk_images() { return opt(O_CHUNK_IMAGES); }
+long opt_nt() { return opt(O_NT); }
+long opt_reverse() { return opt(O_REVERSE); }
+long opt_eca_single() { return opt(O_ECA_SINGLE); }
+long opt_se_single() { return opt(O_SE_SINGLE); }
+long opt_cbam_single() { return opt(O_CBAM_SINGLE); }
+long opt_ws_persistent() { return opt(O_WS_PERSISTENT); }
+long opt_ln_fold() { return opt(O_LN_FOLD); }
 
-// ---- epochs of the granule-exchange workspaces (chan_fused.hip, cbam_single.hip) ---------------------------------------------
-// A granule is valid when it carries the tag of the CURRENT launch.  With a fresh tag per launch a slot written by any earlier
-// launch -- completed or not -- can never look valid, so the region only has to be zeroed when its history is unknown: first
-// use of the pointer, a different layout key, ticket counter about to wrap, or "ws_persistent" off (the default: a C caller
-// that frees / reuses workspace memory between calls must not opt in).  The ticket word keeps counting across launches;
-// each launch subtracts the base it was handed.
+// ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
+// A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the
+// launch's last ticket draw), so a slot written by any earlier launch can never look valid and the region only has to be zeroed
+// when its history is unknown: first use of the pointer, a different layout key, or "ws_persistent" off (the default: a C caller
+// that frees / reuses workspace memory between calls must not opt in).  Nothing about a launch lives on the host, which is what
+// lets these kernels be recorded by hipGraph capture.
 namespace {
-struct WsEntry { unsigned long long key; unsigned ticket_end; };
+struct WsEntry { unsigned long long key; };
 std::mutex g_ws_mu;
 std::unordered_map<const void*, WsEntry> g_ws;
-std::atomic<unsigned> g_epoch{0x5EC0DE00u};
 }  // namespace
 
-// A launch recorded by hipGraph capture replays with the SAME kernel arguments, so it cannot carry a per-launch tag or a ticket base
-// remembered on the host, and a captured memset -> kernel pair was observed to misbehave on replay (MI355X, ROCm 7.2: replays after an
-// intervening eager launch returned stale output; tests/test_chan_attn_gpu.py::test_exchange_kernels_under_graph_capture).  The
-// exchange kernels therefore step aside under capture: their callers take the multi-pass paths, which only use kernel-to-kernel
-// dependencies through memory.  ws_epoch still answers safely (constant tag, zero base, nothing remembered) if it is ever asked.
 bool stream_is_capturing(hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
@@ -69,29 +102,6 @@ bool stream_is_capturing(hipStream_t st) {
     return cs != hipStreamCaptureStatusNone;
 }
 
-WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hipStream_t st) {
-    WsEpoch r{};
-    if (stream_is_capturing(st)) {
-        r.tag = 0x6A9F0001u;
-        r.fresh = true;
-        r.ticket_base = 0u;
-        std::lock_guard<std::mutex> lk(g_ws_mu);
-        g_ws.erase(region);
-        return r;
-    }
-    unsigned tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
-    if (tag == 0u) tag = g_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;     // 0 is what a zeroed slot holds
-    r.tag = tag;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    auto it = g_ws.find(region);
-    const bool known = opt_ws_persistent() && it != g_ws.end() && it->second.key == key &&
-                       it->second.ticket_end < 0x7FFFFFFFu - draws && tag > 0x1000u /* tags wrapped: start over */;
-    r.fresh = !known;
-    r.ticket_base = known ? it->second.ticket_end : 0u;
-    if (opt_ws_persistent()) g_ws[region] = WsEntry{key, r.ticket_base + draws};
-    else if (it != g_ws.end()) g_ws.erase(it);             // zeroed on every call from now on: what was remembered is void
-    return r;
-}
 // Workspaces of the kernels that keep their launch tag in device memory (se_single_kernel, cbam_single_kernel): the host only has to know whether the
 // region was zeroed for this shape.  Under stream capture an unknown region stays unknown (the memset the caller records runs at
 // replay time, not now); a known one needs nothing.
@@ -100,7 +110,7 @@ bool ws_known(const void* region, unsigned long long key, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     auto it = g_ws.find(region);
     if (it != g_ws.end() && it->second.key == key) return true;
-    if (!stream_is_capturing(st)) g_ws[region] = WsEntry{key, 0u};
+    if (!stream_is_capturing(st)) g_ws[region] = WsEntry{key};
     return false;
 }
 // Zero an exchange area with a KERNEL.  Under stream capture a recorded hipMemsetAsync did not reliably take effect before the kernel
@@ -133,42 +143,48 @@ void ws_forget_range(const void* base, size_t bytes) {
     }
 }
 
-// ---- exchange-kernel failure word (common.h) -----------------------------------------------------------------------------------
+// ---- exchange-kernel failure word + fp16 range word (common.h): ONE PAIR PER DEVICE ---------------------------------------------
+// One pinned, device-visible 4 KB block, 64 bytes per device ordinal: word 0 = exchange failure code, word 4 = range code.  A kernel
+// reports into the words of the device it runs on and the host checks the words of the calling thread's current device, so one
+// device's time-out (or fp16 overflow) never fails another device's next call.
 namespace {
 std::once_flag g_sync_once;
-unsigned* g_sync_word = nullptr;
+unsigned* g_sync_block = nullptr;
 }  // namespace
 unsigned* sync_err_word() {
     std::call_once(g_sync_once, [] {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && p) {
-            std::memset(p, 0, 64);
-            g_sync_word = static_cast<unsigned*>(p);
+        if (hipHostMalloc(&p, 64 * MAX_DEV, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && p) {
+            std::memset(p, 0, 64 * MAX_DEV);
+            g_sync_block = static_cast<unsigned*>(p);
         } else {
             (void)hipGetLastError();
         }
     });
-    return g_sync_word;
+    return g_sync_block ? g_sync_block + 16 * cur_dev() : nullptr;
 }
 unsigned* sync_err_word_on(hipStream_t st) {
-    if (!g_sync_word && stream_is_capturing(st)) return nullptr;          // never allocate pinned memory inside a capture
+    if (!g_sync_block && stream_is_capturing(st)) return nullptr;         // never allocate pinned memory inside a capture
     return sync_err_word();
 }
 unsigned* range_word(hipStream_t st) {
-    if (!g_sync_word && stream_is_capturing(st)) return nullptr;          // never allocate pinned memory inside a capture
+    if (!g_sync_block && stream_is_capturing(st)) return nullptr;         // never allocate pinned memory inside a capture
     unsigned* w = sync_err_word();
-    return w ? w + 4 : nullptr;                                            // second quarter of the 64-byte pinned block
+    return w ? w + 4 : nullptr;                                            // second quarter of the device's 64 bytes
 }
 int range_pending(const char* who) {
-    unsigned* w = g_sync_word ? g_sync_word + 4 : nullptr;
+    unsigned* w = g_sync_block ? g_sync_block + 16 * cur_dev() + 4 : nullptr;
     if (!w || !__atomic_load_n(w, __ATOMIC_ACQUIRE)) return MI355_OK;
     const unsigned code = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
     if (!code) return MI355_OK;
-    static const char* const names[] = {"?", "mi355_cast16_fwd", "mi355_layernorm16_fwd", "a 16-bit-output GEMM epilogue (mi355_linear16_fwd family)"};
+    static const char* const names[] = {"?", "mi355_cast16_fwd", "mi355_layernorm16_fwd", "a 16-bit-output GEMM epilogue (mi355_linear16_fwd family)",
+                                        "a fused block kernel (mi355_mlp_fused_fwd / mi355_proj_mlp_fused_fwd / mi355_cswin_stripe_attn_fwd / "
+                                        "mi355_ln_linear16_fwd / mi355_layernorm16_t_fwd)",
+                                        "the LayerNorm-folding GEMM epilogue (mi355_linear16_lnc_fwd / mi355_ln_center16_fwd)"};
     return fail(MI355_ERANGE, "%s: an EARLIER launch of %s converted a finite value of magnitude >= 65520 to fp16: that tensor holds inf "
-                "where the fp32 reference is finite.  Run the module in precision 0 (strict) or 2 (bf16)", who, names[code < 4 ? code : 0]);
+                "where the fp32 reference is finite.  Run the module in precision 0 (strict) or 2 (bf16)", who, names[code < 6 ? code : 0]);
 }
-unsigned spin_limit() { return (unsigned)g_spin_limit.load(std::memory_order_relaxed); }
+unsigned spin_limit() { return (unsigned)opt(O_SPIN_LIMIT); }
 int sync_pending(const char* who) {
     unsigned* w = sync_err_word();
     if (!w) return MI355_OK;
@@ -181,20 +197,19 @@ int sync_pending(const char* who) {
                 "output is invalid.  Typical cause: fewer workgroups resident than one image needs (partitioned / masked device)",
                 who, names[code < 5 ? code : 0], spin_limit());
 }
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remember (kernel, device ordinal) pairs, not a
-// per-process flag -- a second GPU driven from the same process would otherwise launch with the default dynamic-LDS limit and fail.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device and is a LIMIT: remember the largest byte count set per
+// (kernel, device ordinal) and raise it when a later launch asks for more (a kernel whose dynamic LDS depends on the shape --
+// double_attn_small: HW * 64 + 43008 -- first run on a small image would otherwise fail on a larger one).
 int func_dynamic_lds(const void* fn, int bytes) {
     static std::mutex mu;
-    static std::unordered_map<const void*, unsigned long long> done;      // kernel -> bit mask of device ordinals (< 64)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-    const unsigned long long bit = 1ull << (dev & 63);
+    static std::unordered_map<const void*, std::unordered_map<int, int>> done;      // kernel -> device ordinal -> bytes configured
+    const int dev = cur_dev();
     std::lock_guard<std::mutex> lk(mu);
-    unsigned long long& m = done[fn];
-    if (m & bit) return MI355_OK;
+    int& have = done[fn][dev];
+    if (have >= bytes) return MI355_OK;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return fail(MI355_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) -> %s", bytes, hipGetErrorString(e));
-    m |= bit;
+    have = bytes;
     return MI355_OK;
 }
 int resident_slots(int per_cu) {
@@ -204,14 +219,37 @@ int resident_slots(int per_cu) {
     return ncu * per_cu;
 }
 
-long opt_zoo_single() { return g_zoo_single.load(std::memory_order_relaxed); }
-long opt_stem_direct() { return g_stem_direct.load(std::memory_order_relaxed); }
-long opt_se_occ() { return g_se_occ.load(std::memory_order_relaxed); }
-long opt_gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
-long opt_gemm_splitk() { return g_gemm_splitk.load(std::memory_order_relaxed); }
-long opt_gemm_pa() { return g_gemm_pa.load(std::memory_order_relaxed); }
-long opt_da_fused() { return g_da_fused.load(std::memory_order_relaxed); }
-long opt_da_ranges() { return g_da_ranges.load(std::memory_order_relaxed); }
+long opt_zoo_single() { return opt(O_ZOO_SINGLE); }
+long opt_stem_direct() { return opt(O_STEM_DIRECT); }
+long opt_se_occ() { return opt(O_SE_OCC); }
+long opt_gemm_variant() { return opt(O_GEMM_VARIANT); }
+long opt_gemm_splitk() { return opt(O_GEMM_SPLITK); }
+long opt_gemm_pa() { return opt(O_GEMM_PA); }
+long opt_da_fused() { return opt(O_DA_FUSED); }
+long opt_da_ranges() { return opt(O_DA_RANGES); }
+static int opt_index(const char* key) {
+    for (int i = 0; i < O_COUNT; ++i)
+        if (std::strcmp(key, kOpts[i].key) == 0) return i;
+    return -1;
+}
+int opt_set(const char* key, long value, bool as_default) {
+    const int i = opt_index(key);
+    if (i < 0) return fail(MI355_EINVAL, "mi355_set_option: unknown key '%s'", key);
+    const bool ok = (value >= kOpts[i].lo && value <= kOpts[i].hi) || (i == O_SPIN_LIMIT && value == 0);
+    if (!ok) return fail(MI355_EINVAL, "mi355_set_option: '%s' accepts %ld .. %ld, got %ld", key, kOpts[i].lo, kOpts[i].hi, value);
+    opt_init();
+    if (as_default) g_def[i].store(value, std::memory_order_relaxed);
+    else g_opt[cur_dev()].v[i].store(value, std::memory_order_relaxed);
+    return MI355_OK;
+}
+long opt_get(const char* key) {
+    const int i = key ? opt_index(key) : -1;
+    if (i < 0) {
+        fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
+        return -1;
+    }
+    return opt((Opt)i);
+}
 }  // namespace mi355
 
 struct mi355_timer {
@@ -225,89 +263,12 @@ const char* mi355_last_error(void) { return mi355::err_buf(); }
 
 int mi355_set_option(const char* key, long value) {
     MI355_CHECK_ARG(key != nullptr);
-    if (std::strcmp(key, "chunk_images") == 0) {
-        MI355_CHECK_ARG(value >= 0);
-        mi355::g_chunk_images.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "nt") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= 3);
-        mi355::g_nt.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "gemm_variant") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= 31);
-        mi355::g_gemm_variant.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "eca_single") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_eca_single.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "se_single") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_se_single.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "cbam_single") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_cbam_single.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "ws_persistent") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_ws_persistent.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "zoo_single") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_zoo_single.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "stem_direct") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_stem_direct.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "spin_limit") == 0) {
-        // 0 is accepted for ONE purpose: forcing the time-out path in tests (every exchange then fails on its first unsuccessful poll);
-        // real budgets start at 1024 sweeps
-        MI355_CHECK_ARG(value == 0 || (value >= 1024 && value <= (1L << 30)));
-        mi355::g_spin_limit.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "gemm_splitk") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_gemm_splitk.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "gemm_pa") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_gemm_pa.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "da_fused") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_da_fused.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "da_ranges") == 0) {
-        MI355_CHECK_ARG(value >= 0 && value <= 32);
-        mi355::g_da_ranges.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "se_occ") == 0) {
-        MI355_CHECK_ARG(value == 2 || value == 3);
-        mi355::g_se_occ.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    if (std::strcmp(key, "reverse") == 0) {
-        MI355_CHECK_ARG(value == 0 || value == 1);
-        mi355::g_reverse.store(value, std::memory_order_relaxed);
-        return MI355_OK;
-    }
-    return mi355::fail(MI355_EINVAL, "mi355_set_option: unknown key '%s'", key);
+    return mi355::opt_set(key, value, false);
+}
+
+int mi355_set_default_option(const char* key, long value) {
+    MI355_CHECK_ARG(key != nullptr);
+    return mi355::opt_set(key, value, true);
 }
 
 int mi355_workspace_forget(const void* ws, size_t ws_bytes) {
@@ -316,26 +277,7 @@ int mi355_workspace_forget(const void* ws, size_t ws_bytes) {
     return MI355_OK;
 }
 
-long mi355_get_option(const char* key) {
-    if (key && std::strcmp(key, "chunk_images") == 0) return mi355::opt_chunk_images();
-    if (key && std::strcmp(key, "nt") == 0) return mi355::opt_nt();
-    if (key && std::strcmp(key, "reverse") == 0) return mi355::opt_reverse();
-    if (key && std::strcmp(key, "gemm_variant") == 0) return mi355::opt_gemm_variant();
-    if (key && std::strcmp(key, "eca_single") == 0) return mi355::opt_eca_single();
-    if (key && std::strcmp(key, "se_single") == 0) return mi355::opt_se_single();
-    if (key && std::strcmp(key, "se_occ") == 0) return mi355::opt_se_occ();
-    if (key && std::strcmp(key, "gemm_splitk") == 0) return mi355::opt_gemm_splitk();
-    if (key && std::strcmp(key, "gemm_pa") == 0) return mi355::opt_gemm_pa();
-    if (key && std::strcmp(key, "da_fused") == 0) return mi355::opt_da_fused();
-    if (key && std::strcmp(key, "da_ranges") == 0) return mi355::opt_da_ranges();
-    if (key && std::strcmp(key, "spin_limit") == 0) return (long)mi355::spin_limit();
-    if (key && std::strcmp(key, "zoo_single") == 0) return mi355::opt_zoo_single();
-    if (key && std::strcmp(key, "stem_direct") == 0) return mi355::opt_stem_direct();
-    if (key && std::strcmp(key, "ws_persistent") == 0) return mi355::opt_ws_persistent();
-    if (key && std::strcmp(key, "cbam_single") == 0) return mi355::opt_cbam_single();
-    mi355::fail(MI355_EINVAL, "mi355_get_option: unknown key '%s'", key ? key : "(null)");
-    return -1;
-}
+long mi355_get_option(const char* key) { return mi355::opt_get(key); }
 
 int mi355_sync_status(void) { return mi355::sync_pending("mi355_sync_status"); }
 int mi355_range_status(void) { return mi355::range_pending("mi355_range_status"); }

@@ -121,8 +121,10 @@ __global__ __launch_bounds__(NT, 4) void cbam_single_kernel(const CbamSingleArgs
         return v;
     };
     if (t == 0) {
-        const u32 ep = __hip_atomic_load(a.epoch, AGENT_RLX);         // before the first draw: the epoch cannot move until this
-        s_ep = ep;                                                    // workgroup has drawn its stop ticket
+        // before the first draw (acquire: the fetch_add below may not be performed ahead of this load): the epoch cannot move until
+        // this workgroup has drawn its stop ticket
+        const u32 ep = __hip_atomic_load(a.epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        s_ep = ep;
         s_tk[0] = draw(ep);
     }
     for (int i = t; i < 2 * ks * ks; i += NT) s_wc[i] = a.wconv[i];

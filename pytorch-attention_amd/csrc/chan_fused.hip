@@ -135,8 +135,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
         return v;
     };
     if (t == 0) {
-        const u32 ep = __hip_atomic_load(a.epoch, AGENT_RLX);         // read BEFORE the first draw: the epoch cannot move until this
-        s_ep = ep;                                                    // workgroup has drawn its stop ticket
+        // read BEFORE the first draw (acquire: the fetch_add below may not be performed ahead of this load -- they are different
+        // addresses, a relaxed pair has no order): the epoch cannot move until this workgroup has drawn its stop ticket
+        const u32 ep = __hip_atomic_load(a.epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        s_ep = ep;
         s_tk[0] = draw(ep);
     }
     if (WLDS) {                                                       // both weight matrices stay in LDS for every slice

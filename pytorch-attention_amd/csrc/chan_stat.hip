@@ -10,7 +10,7 @@
 //
 // A 512-thread workgroup keeps 8 channel rows (one per wave) in registers.  SIMAM and SRM only need their own row.  The others
 // need one number per channel of the whole image: it travels as an 8-byte {value, tag} granule exactly like the SE means
-// (one write-through store per channel, polled sweeps, ticketed slices, per-launch tags: chan_fused.hip / api.hip ws_epoch).
+// (one write-through store per channel, polled sweeps, ticketed slices, launch tag = the workspace's epoch word + 1: chan_fused.hip).
 // Shapes the register layout cannot hold (HW % 4 != 0, HW > 4096, C % 8 != 0) take two plain passes (row statistics, then
 // gate + scale); both paths accumulate in fixed orders.
 #include "common.h"
@@ -32,9 +32,9 @@ struct StatArgs {
     const float* p0; const float* p1; const float* p2; const float* p3; const float* p4;   // per-channel parameter arrays (per mode)
     float f0, f1;                         // lambda | bn eps | eps, c | eps | epsilon
     int i0;                               // LCT: channels per group;  GCT1: after_relu
-    u64* gran; u32* ticket; u32* err; u32* herr; float* stats;   // exchange area (single read) / row statistics (two pass)
+    u64* gran; u32* ticket; u32* epoch; u32* err; u32* herr; float* stats;   // exchange area (single read) / row statistics (two pass)
     int B, C, HW, n4, gpi, total;
-    u32 tag, tbase, spin;
+    u32 spin;
 };
 
 // gate of channel c from its own statistics and (exchange modes) the image's per-channel values s_p[0..C)
@@ -109,7 +109,33 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
     __shared__ u32 s_tk[2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     constexpr bool XCH = MODE >= M_GCTG;
-    if (XCH) { if (t == 0) s_tk[0] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase; }
+    // Launch state lives in the workspace, exactly as in se_single_kernel (chan_fused.hip): the tag of a launch is `epoch + 1`, a launch
+    // draws total + gridDim.x tickets (one per slice, one stop ticket per workgroup) and the workgroup that draws the last one sets the
+    // ticket word back to zero and advances the epoch -- nothing about a launch is a kernel argument, so a hipGraph replay is just
+    // another launch and eager launches and replays can share a workspace.
+    __shared__ u32 s_ep;
+    const u32 last_draw = (u32)a.total + gridDim.x - 1u;
+    auto draw = [&](u32 ep) -> u32 {
+        const u32 v = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
+        if (v == last_draw) {
+            __hip_atomic_store(a.ticket, 0u, AGENT_RLX);
+            __hip_atomic_store(a.epoch, ep + 1u, AGENT_RLX);
+        }
+        return v;
+    };
+    u32 EP = 0u, TAG = 1u;
+    if (XCH) {
+        if (t == 0) {
+            // acquire: the draw below must not be performed before this load (the epoch cannot move until this workgroup has drawn
+            // its stop ticket, but only if the load really comes first)
+            const u32 ep = __hip_atomic_load(a.epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            s_ep = ep;
+            s_tk[0] = draw(ep);
+        }
+        __syncthreads();
+        EP = s_ep;
+        TAG = (EP + 1u) ? EP + 1u : 1u;                               // 0 is what a zeroed granule holds
+    }
     int par = 0;
     u32 slice = blockIdx.x;
     for (;;) {
@@ -167,14 +193,14 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
         float red0 = 0.f, red1 = 0.f;
         if (XCH) {
             u64* gb = a.gran + (long)b * a.C;
-            if (lane == 0) __hip_atomic_store(gb + c, ((u64)a.tag << 32) | (u64)__float_as_uint(own), AGENT_RLX);
+            if (lane == 0) __hip_atomic_store(gb + c, ((u64)TAG << 32) | (u64)__float_as_uint(own), AGENT_RLX);
             u32 spins = 0;
             bool timeout = false;
             for (;;) {
                 bool ok = true;
                 for (int cc = t; cc < a.C; cc += 512) {
                     const u64 g = __hip_atomic_load(gb + cc, AGENT_RLX);
-                    if ((u32)(g >> 32) == a.tag) s_p[cc] = __uint_as_float((u32)g);
+                    if ((u32)(g >> 32) == TAG) s_p[cc] = __uint_as_float((u32)g);
                     else ok = false;
                 }
                 if (__syncthreads_and(ok)) break;
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
                 if (++spins > a.spin) { timeout = true; break; }
             }
             if (t == 0) {                                             // nobody is waited for any more: next ticket
-                s_tk[par ^ 1] = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX) - a.tbase;
+                s_tk[par ^ 1] = draw(EP);
                 if (timeout) {
                     __hip_atomic_store(a.err, 1u, AGENT_RLX);
                     if (a.herr) __hip_atomic_store(a.herr, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -280,7 +306,7 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
     const int B = a.B, C = a.C;
     a.HW = H * W;
     constexpr bool XCH = MODE >= M_GCTG;
-    const bool single = !(XCH && mi355::stream_is_capturing(st)) && mi355::opt_zoo_single() && (a.HW % 4 == 0) && (a.HW / 4 <= 16 * 64) && (C % ECW == 0) && aligned16(a.x) &&
+    const bool single = mi355::opt_zoo_single() && (a.HW % 4 == 0) && (a.HW / 4 <= 16 * 64) && (C % ECW == 0) && aligned16(a.x) &&
                         aligned16(a.y) && (size_t)C * 4 <= 48 * 1024 && (MODE != M_LCT || a.i0 <= C) &&
                         (!XCH || C / ECW <= mi355::resident_slots(2));     // an image's slices must all be resident to exchange granules
     if (single) {
@@ -295,15 +321,15 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
             char* base = static_cast<char*>(ws);
             a.ticket = reinterpret_cast<u32*>(base);
             a.err = a.ticket + 1;
-            a.herr = mi355::sync_err_word(); a.spin = mi355::spin_limit();
+            a.epoch = a.ticket + 2;
+            a.herr = mi355::sync_err_word_on(st); a.spin = mi355::spin_limit();
             if (int rc = mi355::sync_pending("channel-statistics gate")) return rc;
             a.gran = reinterpret_cast<u64*>(base + 16);
-            const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ ((unsigned long long)MODE << 56);
-            const mi355::WsEpoch ep = mi355::ws_epoch(ws, key, (unsigned)(a.total + grid), st);
-            a.tag = ep.tag; a.tbase = ep.ticket_base;
-            if (ep.fresh) {
-                hipError_t e = hipMemsetAsync(ws, 0, 16 + (size_t)B * C * 8, st);
-                if (e != hipSuccess) { mi355::ws_forget(ws); return mi355::fail(MI355_EHIP, "channel-statistics gate: memset -> %s", hipGetErrorString(e)); }
+            // the grid size is part of the key: the ticket protocol counts total + grid draws per launch
+            const unsigned long long key = ((unsigned long long)B << 32) ^ (unsigned long long)C ^ ((unsigned long long)grid << 44) ^ ((unsigned long long)MODE << 56);
+            if (!mi355::ws_known(ws, key, st)) {          // unknown history: ticket, epoch, granules (a kernel, not a memset node: api.hip ws_zero_async)
+                hipError_t e = mi355::ws_zero_async(ws, 16 + (size_t)B * C * 8, st);
+                if (e != hipSuccess) { mi355::ws_forget(ws); return mi355::fail(MI355_EHIP, "channel-statistics gate: zeroing -> %s", hipGetErrorString(e)); }
             }
         }
         const size_t smem = XCH ? (size_t)C * 4 : 0;
@@ -338,7 +364,7 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
 }  // namespace
 
 namespace mi355 {
-// ticket, err, pad (16 B) | granules B*C*8 | row statistics of the two-pass path B*C*16
+// ticket, err, epoch, pad (16 B) | granules B*C*8 | row statistics of the two-pass path B*C*16
 size_t zoo_workspace_bytes(int B, int C) { return 16 + (size_t)B * C * 8 + (size_t)B * C * 16; }
 }  // namespace mi355
 

@@ -25,8 +25,7 @@ long  opt_eca_single();
 long  opt_se_single();
 long  opt_se_occ();
 long  opt_ws_persistent();
-struct WsEpoch { unsigned tag; unsigned ticket_base; bool fresh; };
-WsEpoch ws_epoch(const void* region, unsigned long long key, unsigned draws, hipStream_t st);   // api.hip: tag + ticket base of this launch
+long  opt_ln_fold();
 void  ws_forget(const void* region);
 bool  ws_known(const void* region, unsigned long long key, hipStream_t st);   // api.hip: was this workspace zeroed for this shape? (device-resident launch tags)
 hipError_t ws_zero_async(void* p, size_t bytes, hipStream_t st);   // zero an exchange area with a kernel (capture-safe ordering)
@@ -143,12 +142,20 @@ __device__ __forceinline__ float relu_nan(float v) {
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 // ---- fp16 range guard (device side): running |max| of the values a lane converts to fp16; v_max ignores NaN operands --------------
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
+// A group of four whose largest magnitude is inf is skipped instead of poisoning the lane's running maximum: the inf is the INPUT's
+// (not reported: the reference holds it too), and a later finite value that saturates must still be seen.  (An inf and a saturating
+// finite value inside the same group of four are not told apart.)
 __device__ __forceinline__ float rg_absmax4(float m, rg_f4 v) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const float g = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    return g < __builtin_inff() ? fmaxf(m, g) : m;
 }
-// 65520 = the smallest magnitude that rounds to inf in IEEE half; an inf that was already inf in fp32 is the input's, not ours
+__device__ __forceinline__ float rg_absmax1(float m, float v) {
+    const float g = fabsf(v);
+    return g < __builtin_inff() ? fmaxf(m, g) : m;
+}
+// 65520 = the smallest magnitude that rounds to inf in IEEE half (the running maximum only ever holds finite values)
 __device__ __forceinline__ void rg_report(float m, unsigned* word, unsigned code) {
-    if (word && m >= 65520.0f && m < __builtin_inff()) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (word && m >= 65520.0f) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ float se_gate(float z, int kind) {
     if (!kind) return sigmoidf_(z);

@@ -18,6 +18,12 @@ struct G16Args {
     unsigned* ovf;      // fp16 range guard word (common.h rg_report) or null; set by the entry points for 16-bit fp16 outputs
     const float* Af;    // LNA kernels only: fp32 activation rows (row stride lda floats), normalised on the way into LDS
     float ln_eps;
+    // LayerNorm fold (ln_fold.hip), PRODUCER side -- gemm16_pa fp32 outputs only: beside Y the epilogue emits the next GEMM's operand
+    //   lnc_a[m][n] = T(Y[m][n] - lnc_c[m])    (16-bit, row stride lnc_lda)   and per (32-column group g, row m) the pair
+    //   lnc_stats[g * M + m] = {mean_g, sum_g (Y - mean_g)^2}                  (the exact row statistics, combined by mi355_ln_finalize_fwd)
+    void* lnc_a; int lnc_lda; float* lnc_stats; const float* lnc_c;
+    // ... CONSUMER side -- gemm16_p8 16-bit outputs only:  Y = act(rowtau[m].x * acc + rowtau[m].y * colsum[n] + bias[n])
+    const float* rowtau; const float* colsum;
 };
 
 template <typename T> struct Vec8;
@@ -36,6 +42,6 @@ __device__ __forceinline__ f4 mma16<__bf16>(b8 a, b8 b, f4 c) { return __builtin
 namespace mi355 {
 int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);     // gemm16_p8.hip
 size_t gemm16_p8_workspace_bytes(int M, int N, int K);
-int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl = 0);                                 // gemm16_pa.hip
+int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl = 0);        // g.lnc_a != null: emitting variant                                 // gemm16_pa.hip
 int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }

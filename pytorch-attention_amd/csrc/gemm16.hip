@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
         const float v = src[n8 * 8 + threadIdx.x];
-        if constexpr (std::is_same<T, _Float16>::value) rgmax = fmaxf(rgmax, fabsf(v));
+        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax1(rgmax, v);
         dst[n8 * 8 + threadIdx.x] = (T)v;
     }
     if constexpr (std::is_same<T, _Float16>::value) rg_report(rgmax, ovf, 1u);
@@ -461,8 +461,8 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant >= 16 && variant <= 21) {  // two-accumulator persistent 128 x 256 kernel (gemm16_pa.hip); 17..21: timing ablations
-        const int rc = mi355::gemm16_pa(g, out16, precision, st, (int)variant - 16);
+    if (variant == 16) {                   // two-accumulator persistent 128 x 256 kernel (gemm16_pa.hip)
+        const int rc = mi355::gemm16_pa(g, out16, precision, st);
         if (rc == MI355_EUNSUPPORTED) return mi355::fail(rc, "mi355_linear16_fwd: the two-accumulator kernel does not take this shape");
         if (rc != MI355_OK) return rc;
         MI355_LAUNCH_CHECK();

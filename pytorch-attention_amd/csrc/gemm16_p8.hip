@@ -49,8 +49,11 @@ struct P8Plan {
 };
 namespace {
 
-template <typename T, bool OUT16>
+// FOLD (16-bit outputs only): LayerNorm fold, consumer side (ln_fold.hip) -- the operand rows are x - c, the weights carry the
+// LayerNorm gain, and the row's rstd / mean correction arrive as rowtau[m] = {rho, tau}:  y = act(rho * acc + tau * colsum[n] + bias[n]).
+template <typename T, bool OUT16, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P8Plan pl) {
+    static_assert(!FOLD || OUT16, "the folding epilogue exists for 16-bit outputs only");
     const int tiles_n = pl.tiles_n;
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
@@ -325,13 +328,34 @@ __global__ __launch_bounds__(512) void gemm16_p8_kernel(const G16Args g, const P
                 gam4[j] = (g.gamma && n < g.N) ? *reinterpret_cast<const f4*>(g.gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
             }
             if constexpr (OUT16) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                // FOLD: a lane holds ONE row per row tile (l15) and four columns per column tile: 4 float4 of colsum per output tile and
+                // one float2 of rowtau per row tile, fetched one row tile ahead (no LayerScale on this path: gam4 is dead)
+                typedef float f2_ __attribute__((ext_vector_type(2)));
+                f4 cs4[4];
+                f2_ rt_next = f2_{1.f, 0.f};
+                auto load_rt = [&](int i) -> f2_ {
+                    const int m = m0 + wr * 128 + i * 16 + l15;
+                    return m < g.M ? *reinterpret_cast<const f2_*>(g.rowtau + 2 * (long)m) : f2_{1.f, 0.f};
+                };
+                if constexpr (FOLD) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        f4 v = acc[i][j] + bias4[j];
+                        const int n = ncol0 + j * 16 + fq4 * 4;
+                        cs4[j] = n < g.N ? *reinterpret_cast<const f4*>(g.colsum + n) : f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    rt_next = load_rt(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f2_ rt = rt_next;
+                    if constexpr (FOLD) { if (i < 7) rt_next = load_rt(i + 1); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f4 v;
+                        if constexpr (FOLD) v = acc[i][j] * rt.x + (cs4[j] * rt.y + bias4[j]);
+                        else v = acc[i][j] + bias4[j];
                         if (g.act == MI355_ACT_GELU) v = gelu16_fast4(v);
-                        if (g.gamma) v = v * gam4[j];
+                        if constexpr (!FOLD) { if (g.gamma) v = v * gam4[j]; }
                         if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);
                         *reinterpret_cast<v4*>(slab + l15 * 128 + (((j * 2 + (fq4 >> 1)) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8) =
                             v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
@@ -489,6 +513,12 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
         pl.part = reinterpret_cast<float*>(static_cast<char*>(ws) + ab);
         static std::atomic<unsigned> launch_tag{0x5EED0000u};
         do pl.tag = launch_tag.fetch_add(1u, std::memory_order_relaxed) + 1u; while (pl.tag == 0u);
+    }
+    if (g.rowtau) {                                            // LayerNorm fold, consumer side
+        if (!out16 || !g.colsum || g.gamma || !aligned16(g.colsum) || (reinterpret_cast<uintptr_t>(g.rowtau) & 7u)) return MI355_EUNSUPPORTED;
+        if (precision == MI355_PREC_FP16) gemm16_p8_kernel<_Float16, true, true><<<grid, 512, 0, st>>>(g, pl);
+        else                              gemm16_p8_kernel<__bf16, true, true><<<grid, 512, 0, st>>>(g, pl);
+        return MI355_OK;
     }
     if (precision == MI355_PREC_FP16) {
         if (out16) gemm16_p8_kernel<_Float16, true><<<grid, 512, 0, st>>>(g, pl);

@@ -89,14 +89,22 @@ __device__ __forceinline__ void pa_wait2(f4& a, f4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void pa_wait4s(f4& a, f4& b, float& c, float& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void pa_wait4(f4& a, f4& b, f4& c, f4& d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
 }
 
 // ABL: timing-only ablation mask for tuning experiments (results are WRONG when non-zero): 1 = no LDS-DMA inside the loop, 2 = no
 // fragment reads inside the loop, 4 = no MFMAs, 8 = no barriers inside the loop.
-template <typename T, bool OUT16, bool GELU, int ABL = 0>
+// LNC (fp32 outputs only): the LayerNorm fold's producer side -- beside Y every epilogue unit (16 rows x 32 columns, final values
+// already in the row layout) emits T(Y - c[row]) as the next GEMM's 16-bit operand and the unit's exact (mean, sum of squared
+// deviations) per row; +2 loads (c of the unit's two row halves, issued with the residual) and +4 stores per unit in the counts.
+template <typename T, bool OUT16, bool GELU, int ABL = 0, bool LNC = false>
 __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const PaPlan pl) {
+    static_assert(!(LNC && OUT16), "the emitting epilogue exists for fp32 outputs only");
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
     constexpr int SLOTB = 128 * BK * 2;                         // bytes per slot (16 KB)
@@ -194,6 +202,15 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     float rgmax = 0.f;
     f4 eb0, eb1, eb2, eb3, er0, er1, es0, es1;                                            // bias (16-bit path: all four column tiles) / two residual sets in flight
     eb0 = eb1 = eb2 = eb3 = er0 = er1 = es0 = es1 = f4{0.f, 0.f, 0.f, 0.f};
+    // LNC: centring value c of the unit's rows srow / srow + 8 (two sets like the residual), descriptors and lane offsets of the outputs
+    float erc0 = 0.f, erc1 = 0.f, esc0 = 0.f, esc1 = 0.f;
+    const u32x4_ d_cv = pa_desc(g.lnc_c, LNC ? (unsigned)g.M * 4u : 0u);
+    const rsrc_t rs_a = make_rsrc(g.lnc_a, LNC ? (bufops_u32)((long)g.M * g.lnc_lda * 2) : 0u);
+    const rsrc_t rs_st = make_rsrc(g.lnc_stats, LNC ? (bufops_u32)((long)(g.N / 32) * g.M * 8) : 0u);
+    // lane parts of the LNC addresses are re-derived at their uses from vo_row / the lane id (a hoisted copy of each would be three
+    // more registers alive across the main loop of a kernel that sits at 256): lnc_lda == ldc (launcher), so the operand offset is
+    // half the fp32 one; the c offset is srow * 4; one lane per row (sch == 0) writes the statistics pair, the others fall outside
+    // the descriptor's range check
     const unsigned sw_w16 = (unsigned)(l15 * 128 + (((fq4 >> 1) ^ (l15 & 7)) * 16) + (fq4 & 1) * 8);   // column tile j: ^ (j * 32)
     const unsigned sw_w32 = (unsigned)(l15 * 128 + ((fq4 ^ (l15 & 7)) * 16));                           // column tile jj: ^ (jj * 64)
     const unsigned sw_r = (unsigned)(srow * 128 + ((sch ^ (srow & 7)) * 16));                           // row h * 8 + srow: + h * 1024
@@ -220,18 +237,48 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
                      : "v"(vo_bias), "s"(d_bias), "s"(so0), "s"(so1)
                      : "memory");
     };
-    auto epi_load32_res = [&](int i, int jh, f4& r0, f4& r1) {
+    auto epi_load32_res = [&](int i, int jh, f4& r0, f4& r1, float& c0, float& c1) {
         const unsigned sr0 = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u, sr1 = sr0 + (unsigned)(8 * g.ldc) * 4u;
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
-                     "buffer_load_dwordx4 %1, %2, %3, %5 offen"
-                     : "=&v"(r0), "=&v"(r1)
-                     : "v"(vo_row), "s"(d_res), "s"(sr0), "s"(sr1)
-                     : "memory");
+        if constexpr (LNC) {
+            const unsigned sc0 = (unsigned)(pm0 + wr * 64 + i * 16) * 4u;
+            // lane id from mbcnt (two VALU ops) instead of a register kept alive across the main loop
+            unsigned vo_cv = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            vo_cv = (vo_cv >> 3) * 4u;
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
+                         "buffer_load_dwordx4 %1, %4, %5, %7 offen\n\t"
+                         "buffer_load_dword %2, %8, %9, %10 offen\n\t"
+                         "buffer_load_dword %3, %8, %9, %10 offen offset:32"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(c0), "=&v"(c1)
+                         : "v"(vo_row), "s"(d_res), "s"(sr0), "s"(sr1), "v"(vo_cv), "s"(d_cv), "s"(sc0)
+                         : "memory");
+        } else {
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3, %5 offen"
+                         : "=&v"(r0), "=&v"(r1)
+                         : "v"(vo_row), "s"(d_res), "s"(sr0), "s"(sr1)
+                         : "memory");
+        }
     };
     auto act4 = [&](f4 v) {
-        if constexpr (GELU) v = gelu_out4<OUT16>(v);
-        return v;
+        if constexpr (GELU && LNC) {
+            // one element at a time (each chain starts when the previous result exists): four interleaved polynomial chains hold
+            // twelve temporaries, and this variant has none to spare -- a spilled register costs a scratch reload whose
+            // s_waitcnt vmcnt(0) drains the whole LDS-DMA queue.  The piece rides in an MFMA interval; its latency is not exposed.
+            f4 r;
+            r.x = gelu_fast(v.x);
+            asm volatile("" : "+v"(r.x), "+v"(v.y));
+            r.y = gelu_fast(v.y);
+            asm volatile("" : "+v"(r.y), "+v"(v.z));
+            r.z = gelu_fast(v.z);
+            asm volatile("" : "+v"(r.z), "+v"(v.w));
+            r.w = gelu_fast(v.w);
+            return r;
+        } else {
+            if constexpr (GELU) v = gelu_out4<OUT16>(v);
+            return v;
+        }
     };
     // C (16-bit): one accumulator tile (row tile i, column tile j) -> slab, accumulator layout (lane = row l15, 4 columns fq4*4..)
     auto epi_c16 = [&](f4 a, f4 b, int j) {
@@ -261,7 +308,20 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         *reinterpret_cast<f4*>(slab + (wa ^ 64u)) = v1;
     };
     // F (fp32): 16 rows x 32 columns leave as whole 128-byte row lines, residual added in the row layout
-    auto epi_f32 = [&](int i, int jh, f4 r0, f4 r1) {
+    // counted wait that names the registers of one residual set (LNC: + its two c values; otherwise they stay dead)
+    auto res_wait = [&](auto NC, f4& r0, f4& r1, float& c0, float& c1) {
+        constexpr int NW = decltype(NC)::value;
+        if constexpr (LNC) pa_wait4s<NW>(r0, r1, c0, c1);
+        else pa_wait2<NW>(r0, r1);
+    };
+    // sum over the 8 lanes that share a row of the unit (lanes 8 * srow .. + 7): three DPP steps, fixed order
+    auto sum8 = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+        return v;
+    };
+    auto epi_f32 = [&](int i, int jh, f4 r0, f4 r1, float c0, float c1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const unsigned ub = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u;
@@ -269,18 +329,42 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         const f4 o1 = *reinterpret_cast<const f4*>(slab + sw_r + 1024) + r1;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o0), rs_c, vo_row + ub, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o1), rs_c, vo_row + ub + (unsigned)(8 * g.ldc) * 4u, 0, 0);
+        if constexpr (LNC) {
+            typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+            typedef float f2_ __attribute__((ext_vector_type(2)));
+            // the unit's 32 columns of a row = 8 lanes x 4: exact mean and sum of squared deviations (two-pass, in registers)
+            const float m0 = sum8((o0.x + o0.y) + (o0.z + o0.w)) * (1.0f / 32.0f);
+            const float m1 = sum8((o1.x + o1.y) + (o1.z + o1.w)) * (1.0f / 32.0f);
+            const f4 e0 = o0 - m0, e1 = o1 - m1;
+            const float q0 = sum8((e0.x * e0.x + e0.y * e0.y) + (e0.z * e0.z + e0.w * e0.w));
+            const float q1 = sum8((e1.x * e1.x + e1.y * e1.y) + (e1.z * e1.z + e1.w * e1.w));
+            const f4 a0 = o0 - c0, a1 = o1 - c1;
+            const v4 h0 = v4{(T)a0.x, (T)a0.y, (T)a0.z, (T)a0.w}, h1 = v4{(T)a1.x, (T)a1.y, (T)a1.z, (T)a1.w};
+            unsigned vo_a = vo_row, vo_st = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(vo_a));
+            vo_a >>= 1;
+            vo_st = (vo_st & 7u) ? OOB : vo_st;                 // sch == 0: lane = 8 * srow -> byte offset srow * 8
+            const unsigned ua = ub >> 1;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, h0), rs_a, vo_a + ua, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, h1), rs_a, vo_a + ua + (unsigned)(8 * g.ldc) * 2u, 0, 0);
+            const unsigned us = (unsigned)(((pn0 + wc * 64 + jh * 32) >> 5) * g.M + pm0 + wr * 64 + i * 16) * 8u;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f2_{m0, q0}), rs_st, vo_st, us, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f2_{m1, q1}), rs_st, vo_st, us + 64u, 0);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
     auto bias_of = [&](int j) -> f4 { return j == 0 ? eb0 : (j == 1 ? eb1 : (j == 2 ? eb2 : eb3)); };
     // vector-memory operations an epilogue piece issues in its phase-0 interval
+    constexpr int FST = LNC ? 6 : 2;                 // stores of one F step: Y (+ operand + statistics)
+    constexpr int LLD = LNC ? 4 : 2;                 // loads of one L step: residual (+ c)
     auto e0_of = [](int E) constexpr {
         if (E < 0) return 0;
         if (OUT16) return E == 0 ? 4 : ((E >= 2 && (E & 1) == 0) ? 2 : 0);
-        return (E >= 2 ? 2 : 0) + ((E == 0 || E == 5) ? 2 : 0);
+        return (E >= 2 ? FST : 0) + ((E == 0 || E == 5) ? 2 : 0);
     };
     // ... and in its phase-1 interval (fp32: the residual loads of unit E)
-    auto e1_of = [](int E) constexpr { return (!OUT16 && E >= 0 && E < 8) ? 2 : 0; };
+    auto e1_of = [](int E) constexpr { return (!OUT16 && E >= 0 && E < 8) ? LLD : 0; };
     // phase-0 part of piece E of the draining accumulator set.  A residual load is behind the 4 B DMAs of its own K-tile and the 2 A
     // DMAs of this one (or behind nothing: at the end of the stream the phases wait with a smaller count instead of issuing)
     auto epi_even = [&](auto EC, f4 (&prv)[4][4]) {
@@ -294,9 +378,9 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             // unit E-2 leaves: its residual was loaded at the end of K-tile E-2; behind it 2 A + e0(E-1) + 4 B + e1(E-1) of K-tile E-1
             // and 2 A DMAs of this K-tile (at the end of the stream the phases wait vmcnt(0) instead of issuing)
             if constexpr (E >= 2) {
-                constexpr int NV = 8 + ((E - 1) >= 2 ? 2 : 0) + (((E - 1) == 0 || (E - 1) == 5) ? 2 : 0) + ((E - 1) < 8 ? 2 : 0);
-                if constexpr ((E & 1) == 0) { pa_wait2<NV>(er0, er1); epi_f32((E - 2) & 3, (E - 2) >> 2, er0, er1); }
-                else                        { pa_wait2<NV>(es0, es1); epi_f32((E - 2) & 3, (E - 2) >> 2, es0, es1); }
+                constexpr int NV = 8 + ((E - 1) >= 2 ? FST : 0) + (((E - 1) == 0 || (E - 1) == 5) ? 2 : 0) + ((E - 1) < 8 ? LLD : 0);
+                if constexpr ((E & 1) == 0) { res_wait(IC<NV>{}, er0, er1, erc0, erc1); epi_f32((E - 2) & 3, (E - 2) >> 2, er0, er1, erc0, erc1); }
+                else                        { res_wait(IC<NV>{}, es0, es1, esc0, esc1); epi_f32((E - 2) & 3, (E - 2) >> 2, es0, es1, esc0, esc1); }
             }
             if constexpr (E == 0 || E == 5) epi_load32_bias(E == 0 ? 0 : 1);
         }
@@ -311,8 +395,8 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             } else {
                 if constexpr (E == 0 || E == 5) pa_wait2<4>(eb0, eb1);
                 if constexpr (E >= 1) epi_c32(prv[(E - 1) & 3][((E - 1) >> 2) * 2], prv[(E - 1) & 3][((E - 1) >> 2) * 2 + 1]);
-                if constexpr ((E & 1) == 0) epi_load32_res(E & 3, E >> 2, er0, er1);
-                else                        epi_load32_res(E & 3, E >> 2, es0, es1);
+                if constexpr ((E & 1) == 0) epi_load32_res(E & 3, E >> 2, er0, er1, erc0, erc1);
+                else                        epi_load32_res(E & 3, E >> 2, es0, es1, esc0, esc1);
             }
         }
         if constexpr (!OUT16 && E == 8) epi_c32(prv[3][2], prv[3][3]);           // C(7)
@@ -428,10 +512,10 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
                 pa_wait2<0>(eb0, eb1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    epi_load32_res(i, jh, er0, er1);
-                    pa_wait2<0>(er0, er1);
+                    epi_load32_res(i, jh, er0, er1, erc0, erc1);
+                    res_wait(IC<0>{}, er0, er1, erc0, erc1);
                     epi_c32(acc[i][jh * 2], acc[i][jh * 2 + 1]);
-                    epi_f32(i, jh, er0, er1);
+                    epi_f32(i, jh, er0, er1, erc0, erc1);
                 }
             }
         }
@@ -489,7 +573,22 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
     pl.full = (int)(ntiles / grid);
     pl.left = (int)(ntiles - (long)pl.full * grid);
     const bool gelu = g.act == MI355_ACT_GELU;
-    if (abl) {                                                  // tuning experiments only: fp16, 16-bit output, no GELU
+    if (g.lnc_a) {                                              // emitting variant (LayerNorm fold, producer side)
+        if (out16 || !g.lnc_stats || !g.lnc_c || abl || (g.N & 31) || g.lnc_lda != g.ldc) return MI355_EUNSUPPORTED;
+        if ((long)g.M * g.lnc_lda * 2 >= (1L << 31) || (long)(g.N / 32) * g.M * 8 >= (1L << 31)) return MI355_EUNSUPPORTED;
+        if (precision == MI355_PREC_FP16) {
+            if (gelu) gemm16_pa_kernel<_Float16, false, true, 0, true><<<grid, 512, 0, st>>>(g, pl);
+            else      gemm16_pa_kernel<_Float16, false, false, 0, true><<<grid, 512, 0, st>>>(g, pl);
+        } else {
+            if (gelu) gemm16_pa_kernel<__bf16, false, true, 0, true><<<grid, 512, 0, st>>>(g, pl);
+            else      gemm16_pa_kernel<__bf16, false, false, 0, true><<<grid, 512, 0, st>>>(g, pl);
+        }
+        return MI355_OK;
+    }
+#ifdef MI355_PA_ABLATION
+    // Timing ablations (results are WRONG by construction: fp16 operands, 16-bit output, no GELU, whatever the caller asked for).
+    // Compiled only with -DMI355_PA_ABLATION for tuning sessions (tools/pa_probe.py); the shipped library has no route to them.
+    if (abl) {
         switch (abl) {
             case 1: gemm16_pa_kernel<_Float16, true, false, 1><<<grid, 512, 0, st>>>(g, pl); break;
             case 2: gemm16_pa_kernel<_Float16, true, false, 2><<<grid, 512, 0, st>>>(g, pl); break;
@@ -499,6 +598,9 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
         }
         return MI355_OK;
     }
+#else
+    if (abl) return MI355_EUNSUPPORTED;
+#endif
 #define PA_LAUNCH(T_, O_, G_) gemm16_pa_kernel<T_, O_, G_><<<grid, 512, 0, st>>>(g, pl)
 #define PA_BY_EPI(T_)                                                    \
     do {                                                                 \

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
         for (int i = lane; i < cols; i += 64) {
             const float o = (xr[i] - mean) * rstd * w[i] + b[i];
-            if constexpr (std::is_same<OT, _Float16>::value) rgmax = fmaxf(rgmax, fabsf(o));
+            if constexpr (std::is_same<OT, _Float16>::value) rgmax = rg_absmax1(rgmax, o);
             y[row * cols + i] = (OT)o;
         }
     }

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mi355_version": (c_int, []),
     "mi355_last_error": (ctypes.c_char_p, []),
     "mi355_set_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
+    "mi355_set_default_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
     "mi355_get_option": (ctypes.c_long, [ctypes.c_char_p]),
     "mi355_workspace_forget": (c_int, [c_vp, ctypes.c_size_t]),
     "mi355_sync_status": (c_int, []),
@@ -89,6 +90,11 @@ SIGNATURES = {
     "mi355_zpool_fwd": (c_int, [c_vp, c_vp] + [c_int] * 4 + [c_vp]),
     "mi355_attention_gate_workspace_bytes": (ctypes.c_size_t, [c_int] * 3),
     "mi355_attention_gate_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp, ctypes.c_size_t, c_vp]),
+    "mi355_ln_fold_stats_bytes": (ctypes.c_size_t, [c_int] * 2),
+    "mi355_ln_center16_fwd": (c_int, [c_vp] * 4 + [c_int, c_int, c_float, c_int, c_vp]),
+    "mi355_ln_finalize_fwd": (c_int, [c_vp] * 5 + [c_int, c_int, c_float, c_float, c_int, c_vp, c_vp]),
+    "mi355_linear16_emit_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 4),
+    "mi355_linear16_lnfold_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
     "mi355_mhsa_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
     "mi355_mhsa_fwd": (c_int, [c_vp, c_int] + [c_vp] * 6 + [c_int] * 4 + [c_float, c_int, c_vp, ctypes.c_size_t, c_vp]),
     "mi355_sk_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
@@ -149,8 +155,9 @@ def lib():
         v = handle.mi355_version()
         if v != ABI_VERSION:
             raise Mi355Error(f"libmi355attn ABI version {v} != binding version {ABI_VERSION}; rebuild")
-        # the single-read SE / CBAM ops get dedicated workspaces from workspace_dedicated() below, so the promise holds
-        handle.mi355_set_option(b"ws_persistent", 1)
+        # the single-read SE / CBAM ops get dedicated workspaces from workspace_dedicated() below, so the promise holds -- on every
+        # device this process uses (options are per device; the process default covers devices nobody has touched yet)
+        handle.mi355_set_default_option(b"ws_persistent", 1)
         _lib = handle
     return _lib
 

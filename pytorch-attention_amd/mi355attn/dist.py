@@ -31,10 +31,19 @@ class RcclComm:
     is issued by libmi355attn on torch's current stream, RCCL over xGMI underneath.  The 128-byte unique id is created by rank 0 and
     handed to the other ranks through the already initialised torch.distributed group (its store is the bootstrap; any backend)."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, check="always"):
+        """`group`: the torch.distributed group whose ranks form the communicator (default: WORLD); it also carries the bootstrap and
+        the equal-shard check.  `check`: "always" = every all_gather verifies on the host that all ranks pass the same shape (safe
+        default: a mismatch is a ValueError on every rank instead of an ncclAllGather with unequal counts); "first" = only the first
+        all_gather of this communicator is verified and the caller guarantees the shape never changes afterwards (what a timed loop
+        wants: no host collective inside it); "never".  The decision depends on a call counter that is the same on every rank --
+        never on what an individual rank has seen -- so the ranks always enter the host collective together."""
         import ctypes
         from . import _ffi
+        if check not in ("always", "first", "never"):
+            raise ValueError("RcclComm: check must be 'always', 'first' or 'never'")
         self._ffi = _ffi
+        self.group, self.check, self._ncalls = group, check, 0
         if dist.is_available() and dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         else:
@@ -48,7 +57,6 @@ class RcclComm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             buf = ctypes.create_string_buffer(box[0], 128)
         self._h = ctypes.c_void_p()
-        self._shape_checked = set()
         with torch.cuda.device(self.device):
             _ffi.check(_ffi.lib().mi355_comm_init(buf, 128, self.rank, self.world, ctypes.byref(self._h)), "mi355_comm_init")
 
@@ -66,16 +74,24 @@ class RcclComm:
             pass
 
     def _check_equal_shards(self, shape):
-        """ncclAllGather needs the same count on every rank: verified once per shape through the torch.distributed group (a host-side
-        object all-gather, outside any timed region: call sites warm up first)."""
-        if self.world == 1 or shape in self._shape_checked or not (dist.is_available() and dist.is_initialized()):
+        """ncclAllGather needs the same count on every rank: verified through the communicator's torch.distributed group (a host-side
+        object all-gather over exactly the ranks of this communicator).  Whether a call verifies is a function of the call counter
+        only (see __init__), so a rank that has seen a shape before can never skip a collective another rank enters."""
+        n, self._ncalls = self._ncalls, self._ncalls + 1
+        if self.world == 1 or self.check == "never" or (self.check == "first" and n > 0):
+            return
+        if not (dist.is_available() and dist.is_initialized()):
             return
         shapes = [None] * self.world
-        dist.all_gather_object(shapes, tuple(shape))
+        dist.all_gather_object(shapes, tuple(shape), group=self.group)
         if any(s != tuple(shape) for s in shapes):
             raise ValueError(f"RcclComm.all_gather: shard shapes differ across ranks: {shapes} (equal shards only; use gather_batch with "
                              "global_batch for ragged batches)")
-        self._shape_checked.add(shape)
+
+    def fix_shape(self):
+        """From now on the caller gathers ONE shape: the next all_gather is verified, later ones are not (check = "first" with the
+        call counter restarted).  Must be called on every rank at the same point, like the collectives themselves."""
+        self.check, self._ncalls = "first", 0
 
     def all_gather(self, y_local):
         """(n, ...) fp32 on every rank -> (world * n, ...) in rank order on every rank (equal shards)."""

@@ -68,31 +68,77 @@ def _range_check():
     range_status(wait=os.environ.get("MI355_CHECK_RANGE") == "1")
 
 
+def _tensors_of(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_of(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_of(o)
+
+
+def _all_finite(obj):
+    return all(bool(torch.isfinite(t).all()) for t in _tensors_of(obj) if t.is_floating_point())
+
+
+class _forced_strict:
+    """Strict mode for a re-run: the package default AND every sub-module that was built with an explicit 16-bit `precision=`
+    (an explicit setting beats the default, so switching the default alone would recompute those modules in fp16)."""
+
+    def __init__(self, module):
+        self.module, self.saved, self.old = module, [], None
+
+    def __enter__(self):
+        self.old = default_precision()
+        set_default_precision(PREC_STRICT)
+        mods = self.module.modules() if isinstance(self.module, torch.nn.Module) else ()
+        for m in mods:
+            p = m.__dict__.get("precision", None)
+            if p is not None and p != PREC_STRICT:
+                self.saved.append((m, p))
+                m.precision = PREC_STRICT
+        return self
+
+    def __exit__(self, *exc):
+        for m, p in self.saved:
+            m.precision = p
+        set_default_precision(self.old)
+        return False
+
+
 def guarded_forward(module, *args, **kwargs):
-    """Run `module(*args)` in the package's default precision; if the fp16 range guard fires, warn and run it again in strict mode
-    (precision 0: bf16 hi / lo split, fp32 range and fp32-class accuracy at a third of the MFMA rate).  Synchronises the device once
-    per call -- a convenience for checkpoints with outlier activations, not the fast path."""
+    """Run `module(*args)` in the package's default precision; if fp16 operands overflowed, warn and run it again in strict mode
+    (precision 0: bf16 hi / lo split, fp32 range and fp32-class accuracy at a third of the MFMA rate).  Two detectors:
+      * the range guard (mi355_range_status): cast16, the 16-bit LayerNorms and every 16-bit GEMM epilogue report a finite value that
+        saturates to inf;
+      * a non-finite OUTPUT for finite inputs: the fused block kernels (mlp_fused.hip, cswin_fused.hip, xcit.hip, the LayerNorm-in-GEMM
+        operand paths) keep their 16-bit intermediates in registers / LDS and do not track them -- a saturated intermediate there
+        always reaches the block's output as inf / NaN (GELU, the second product, the softmax all propagate it), so it is caught here.
+    The strict re-run overrides sub-modules built with an explicit 16-bit `precision=` as well.  Synchronises the device once per
+    call -- a convenience for checkpoints with outlier activations, not the fast path."""
     import warnings
     try:
         range_status(wait=True)                               # nothing pending from earlier work
     except _ffi.Mi355RangeError:
         pass
+    why = None
     try:
         y = module(*args, **kwargs)                           # a later launch of the same forward may already see the report
         range_status(wait=True)
-        return y
+        if _all_finite(y) or not _all_finite((args, kwargs)):
+            return y                                          # finite, or the input itself was not (the reference is not either)
+        why = "non-finite output for finite inputs (a 16-bit intermediate of a fused kernel saturated)"
     except _ffi.Mi355RangeError as e:
-        warnings.warn(f"{type(module).__name__}: fp16 operands overflowed ({e}); re-running in strict mode", RuntimeWarning)
+        why = str(e)
+    warnings.warn(f"{type(module).__name__}: fp16 operands overflowed ({why}); re-running in strict mode", RuntimeWarning)
     try:
         range_status(wait=True)                               # launches of the abandoned forward that were still in flight may report too
     except _ffi.Mi355RangeError:
         pass
-    old = default_precision()
-    try:
-        set_default_precision(PREC_STRICT)
+    with _forced_strict(module):
         return module(*args, **kwargs)
-    finally:
-        set_default_precision(old)
 
 
 def _sync_check():
@@ -720,6 +766,105 @@ def weight16_padk(w, K, precision=None):
     return _derived_get((w,), ("w16padk", K, _prec(precision)), tag, build)
 
 
+# ---- LayerNorm folded into the neighbouring GEMMs (csrc/ln_fold.hip) ---------------------------------------------------------
+LN_FOLD_TOL = 1.0      # |c - mean| <= tol * std keeps a row on the fast path (mi355_ln_finalize_fwd)
+
+
+class LnState:
+    """What a folded LayerNorm hands to its consumer GEMM: a16 (rows, C) = T(x - c) (or the plain operand for rewritten rows),
+    rowtau (rows, 2) fp32 = {rstd, rstd (c - mean)}, cvec (rows) fp32 = the exact row mean (the next producer's c)."""
+    __slots__ = ("a16", "rowtau", "cvec")
+
+    def __init__(self, a16, rowtau, cvec):
+        self.a16, self.rowtau, self.cvec = a16, rowtau, cvec
+
+
+def ln_fold_ok(rows, C, N, K, precision=None):
+    """Envelope of the fold around a residual-stream GEMM (N = C outputs, K inputs) on `rows` token rows: 16-bit operand mode, the
+    two-accumulator producer (rows % 128 == 0, C % 256 == 0, K % 64 == 0, K >= 640) and the option switch."""
+    return (_prec(precision) in (PREC_FP16, PREC_BF16) and rows % 128 == 0 and N == C and C % 256 == 0 and C <= 2048 and
+            K % 64 == 0 and K >= 640 and _ffi.get_option("ln_fold") == 1 and rows * C * 4 < (1 << 31))
+
+
+def lnfold_weights(ln, lin, precision=None):
+    """(W16', colsum, bias') of a Linear behind a LayerNorm: W' = T(gamma * W) (N, K), colsum[n] = sum_k float(W'[n][k]) -- of the
+    ROUNDED weights, so that the rank-1 mean correction cancels against the products exactly --, bias' = b + W beta.  Cached with
+    the four parameters; None when gamma * W leaves the fp16 range."""
+    p = _prec(precision)
+    anchors = (ln.weight, ln.bias, lin.weight) + ((lin.bias,) if lin.bias is not None else ())
+    tag = tuple((t._version, t.data_ptr()) for t in anchors)
+
+    def build():
+        w = lin.weight.detach()
+        wg = w * ln.weight.detach()[None, :]
+        if p == PREC_FP16 and not bool((wg.abs() < 65504.0).all()):
+            return None
+        w16 = wg.to(dtype16(p)).contiguous()
+        colsum = w16.double().sum(dim=1).float().contiguous()
+        b = w.double() @ ln.bias.detach().double()
+        if lin.bias is not None:
+            b = b + lin.bias.detach().double()
+        return w16, colsum, b.float().contiguous()
+
+    return _derived_get(anchors, ("lnfold", p), tag, build)
+
+
+def ln_center16(x, eps=1e-5, precision=None):
+    """First LayerNorm of a folded chain: x (..., C) fp32 -> LnState with the plain operand (x - mean) * rstd for every row."""
+    p = _prec(precision)
+    x = require_device_f32(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    a16 = torch.empty(x.shape, dtype=dtype16(p), device=x.device)
+    rowtau = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    cvec = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().mi355_ln_center16_fwd(dptr(x), dptr(a16), dptr(rowtau), dptr(cvec), rows, C, float(eps), p, stream_ptr(x.device)),
+          "mi355_ln_center16_fwd")
+    return LnState(a16, rowtau, cvec)
+
+
+def linear16_lnfold(state, w16, bias, colsum, act=ACT_NONE, precision=None):
+    """Consumer of a folded LayerNorm: act(LayerNorm(x) W^T + b) in 16 bit from LnState and lnfold_weights()."""
+    _range_check()
+    p = _prec(precision)
+    a16 = _require16(state.a16, "a16", p)
+    w16 = _require16(w16, "w16", p)
+    N, K = w16.shape
+    if a16.shape[-1] != K:
+        raise ValueError(f"linear16_lnfold: operand width {a16.shape[-1]} != weight in_features {K}")
+    M = a16.numel() // K
+    y = torch.empty(*a16.shape[:-1], N, dtype=dtype16(p), device=a16.device)
+    check(lib().mi355_linear16_lnfold_fwd(dptr(a16), dptr(w16), dptr(_opt(bias, "bias")), dptr(state.rowtau), dptr(colsum), dptr(y),
+                                          M, N, K, K, N, act, p, stream_ptr(a16.device)), "mi355_linear16_lnfold_fwd")
+    return y
+
+
+def linear16_emit(x16, w16, bias, resid, cvec, eps=1e-5, act=ACT_NONE, precision=None, slow_rows=None):
+    """Producer + finalize: y = resid + act(x16 W^T + b) (fp32) AND the LnState of LayerNorm(y) for the next GEMM.  `cvec` (rows)
+    holds the rows' means before this update and is overwritten with the new ones."""
+    _range_check()
+    p = _prec(precision)
+    x16 = _require16(x16, "x16", p)
+    w16 = _require16(w16, "w16", p)
+    N, K = w16.shape
+    if x16.shape[-1] != K:
+        raise ValueError(f"linear16_emit: x last dim {x16.shape[-1]} != weight in_features {K}")
+    M = x16.numel() // K
+    resid = _opt(resid, "resid")
+    if resid is not None and resid.numel() != M * N:
+        raise ValueError("linear16_emit: residual shape mismatch")
+    dev = x16.device
+    y = torch.empty(*x16.shape[:-1], N, dtype=torch.float32, device=dev)
+    a16 = torch.empty(*x16.shape[:-1], N, dtype=dtype16(p), device=dev)
+    stats = _ffi.workspace_named("ln_fold_stats", lib().mi355_ln_fold_stats_bytes(M, N), dev)
+    rowtau = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    check(lib().mi355_linear16_emit_fwd(dptr(x16), dptr(w16), dptr(_opt(bias, "bias")), dptr(resid), dptr(y), M, N, K, K, act, p,
+                                        dptr(cvec), dptr(a16), dptr(stats), stream_ptr(dev)), "mi355_linear16_emit_fwd")
+    check(lib().mi355_ln_finalize_fwd(dptr(stats), dptr(y), dptr(a16), dptr(cvec), dptr(rowtau), M, N, float(eps), float(LN_FOLD_TOL), p,
+                                      dptr(slow_rows), stream_ptr(dev)), "mi355_ln_finalize_fwd")
+    return y, LnState(a16, rowtau, cvec)
+
+
 def mhsa16(x, wqkv16, bqkv, wproj16, bproj, num_heads, scale, resid=None, precision=None):
     """ViT Attention.forward as one C call (mi355_mhsa_fwd): x (B,N,C) fp32 or already in the 16-bit operand format."""
     _range_check()
@@ -936,10 +1081,11 @@ def _rows3(t, name):
     return t, t.stride(1)
 
 
-def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None):
+def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None, out=None):
     """softmax(q k^T * scale + bias) v for (B,Nq,C) queries and (B,Nkv,C) keys / values (views into fused projections welcome).
     fp32 tensors -> fp32 result; fp16 / bf16 tensors (the operand type of `precision`) -> same type.  bias: (heads,Nq,Nkv) or
-    (B,heads,Nq,Nkv) fp32."""
+    (B,heads,Nq,Nkv) fp32.  out: optional (B,Nq,C) destination view with unit channel stride and a dense batch axis (a channel
+    slice of a wider tensor: the C entry takes the row stride)."""
     p = _prec(precision)
     q, ldq = _rows3(q, "q")
     k, ldk = _rows3(k, "k")
@@ -960,9 +1106,13 @@ def sdpa_general(q, k, v, num_heads, scale, bias=None, precision=None):
             bstride = num_heads * Nq * Nkv
         if bias.numel() != (B if bstride else 1) * num_heads * Nq * Nkv:
             raise ValueError("sdpa_general: bias must be (heads,Nq,Nkv) or (B,heads,Nq,Nkv)")
-    out = torch.empty(B, Nq, C, dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty(B, Nq, C, dtype=q.dtype, device=q.device)
+    elif (tuple(out.shape) != (B, Nq, C) or out.dtype != q.dtype or out.device != q.device or out.stride(2) != 1 or
+          out.stride(0) != Nq * out.stride(1)):
+        raise ValueError("sdpa_general: out must be a (B,Nq,C) view of q's type with unit channel stride and a dense batch axis")
     check(lib().mi355_sdpa_general_fwd(dptr(q), dptr(k), dptr(v), dptr(bias), dptr(out), B, num_heads, Nq, Nkv, C // num_heads,
-                                       ldq, ldk, ldv, C, bstride, float(scale), 1 if io16 else 0, p, stream_ptr(q.device)),
+                                       ldq, ldk, ldv, out.stride(1), bstride, float(scale), 1 if io16 else 0, p, stream_ptr(q.device)),
           "mi355_sdpa_general_fwd")
     return out
 

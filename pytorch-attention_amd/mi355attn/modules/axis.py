@@ -244,8 +244,8 @@ class SKLayer(nn.Module):
 class PAM(nn.Module):
     """Position attention of DANet (dual_attention.py:10-28): the three 1x1 convs as ONE token-major GEMM, the streaming attention
     kernel with a single head of width `dim` and scale 1, and a transposing alpha * y + x epilogue.  The logits are unscaled dot
-    products, so the default is the fp32-class precision mode (0); head widths other than 32 / 64 are outside the attention
-    kernel's envelope and raise."""
+    products, so the default is the fp32-class precision mode (0).  dim <= 256 is one head; wider maps (DANet itself: 512) run as
+    two channel halves whose logits are added through the kernel's bias input."""
 
     def __init__(self, dim):
         super().__init__()
@@ -269,8 +269,26 @@ class PAM(nn.Module):
         n, c, h, w = x.shape
         rows, bias = self._fused()
         bcd, _ = F.conv2d_tokens(x, None, bias, 1, 1, 0, 0, precision=self.precision, wrows=rows)        # (n, hw, 3c)
-        y = F.sdpa_general(bcd[:, :, :c], bcd[:, :, c:2 * c], bcd[:, :, 2 * c:], 1, 1.0, precision=self.precision)
+        q, k, v = bcd[:, :, :c], bcd[:, :, c:2 * c], bcd[:, :, 2 * c:]
+        if c <= F.SDPA_WIDTHS[-1]:
+            y = F.sdpa_general(q, k, v, 1, 1.0, precision=self.precision)
+        else:
+            # dim above the kernel's widest head (DANet's own PAM is 512 wide): cut the channel axis in two, c = c0 + c1.  The logits
+            # are a SUM over channels, q k^T = q0 k0^T + q1 k1^T, so half i attends with its own product on the matrix pipe and the
+            # other half's logits (mi355_qk_logits_fwd, fp32) as the additive bias; its output is the i-th channel slice of y.
+            c0 = self._split(c)
+            y = torch.empty(n, h * w, c, dtype=torch.float32, device=x.device)
+            for lo, hi, blo, bhi in ((0, c0, c0, c), (c0, c, 0, c0)):
+                other = F.qk_logits(q[:, :, blo:bhi], k[:, :, blo:bhi], 1, precision=F.PREC_STRICT)        # (n, 1, hw, hw)
+                F.sdpa_general(q[:, :, lo:hi], k[:, :, lo:hi], v[:, :, lo:hi], 1, 1.0, bias=other, precision=self.precision, out=y[:, :, lo:hi])
         return F.tokens_to_nchw_axpy(y, x, self.alpha)
+
+    @staticmethod
+    def _split(c):
+        for c0 in sorted(F.SDPA_WIDTHS, reverse=True):
+            if c - c0 in F.SDPA_WIDTHS:
+                return c0
+        raise NotImplementedError(f"PAM: dim {c} is not a sum of two head widths the attention kernel is built for {F.SDPA_WIDTHS}")
 
 
 class CAM(nn.Module):

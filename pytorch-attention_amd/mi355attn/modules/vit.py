@@ -124,9 +124,47 @@ class TransformerEncoder(nn.Module):
         return F.layernorm(x, ln.weight, ln.bias, ln.eps)
 
     def forward(self, x):
+        if self.fold_ok(x):
+            return self.forward_folded(x)[0]
         fast = self.attn.fast_ok(x.shape[1]) and _fast(self.attn.precision, self.mlp.fc1, self.mlp.fc2)
         x = self.attn(self._norm(self.layernorm1, x, fast), resid=x)
         return self.mlp(self._norm(self.layernorm2, x, fast), resid=x)
+
+    # ---- LayerNorm folded into the GEMMs around it (csrc/ln_fold.hip): no LayerNorm launch between proj and fc1, nor between fc2 and
+    #      the next block's qkv; the first LayerNorm of a chain is one mi355_ln_center16_fwd ---------------------------------------
+    def fold_ok(self, x):
+        """The folded path applies: 16-bit dataflow, K/V-resident attention core, the producer kernel's shape envelope
+        (rows % 128 == 0: B = 128, 256, ... at 197 tokens) and LayerNorm gains that keep gamma * W inside fp16."""
+        if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+            return False
+        B, N, C = x.shape
+        p = F._prec(self.attn.precision)
+        d = C // self.attn.num_heads
+        if not (self.attn.fast_ok(N) and _fast(p, self.mlp.fc1, self.mlp.fc2) and d in (32, 64) and N <= 224):
+            return False
+        if not (F.ln_fold_ok(B * N, C, C, C, p) and F.ln_fold_ok(B * N, C, C, self.mlp.fc1.out_features, p)):
+            return False
+        return (F.lnfold_weights(self.layernorm1, self.attn.qkv, p) is not None and
+                F.lnfold_weights(self.layernorm2, self.mlp.fc1, p) is not None)
+
+    def forward_folded(self, x, state=None, next_eps=None):
+        """x (B,N,C) fp32 -> (y, LnState of the NEXT block's LayerNorm 1 or None).  `state`: the LnState of THIS block's LayerNorm 1
+        when the previous block emitted it (else computed here from x); `next_eps`: eps of the next block's LayerNorm 1 when fc2
+        should emit for it."""
+        p = F._prec(self.attn.precision)
+        ln1, ln2, at, mlp = self.layernorm1, self.layernorm2, self.attn, self.mlp
+        wq, sq, bq = F.lnfold_weights(ln1, at.qkv, p)
+        w1, s1, b1 = F.lnfold_weights(ln2, mlp.fc1, p)
+        if state is None:
+            state = F.ln_center16(x, ln1.eps, p)
+        qkv = F.linear16_lnfold(state, wq, bq, sq, precision=p)                                  # LayerNorm 1 + qkv (+ bias)
+        ctx = F.sdpa16(qkv, at.num_heads, at.scale, precision=p)
+        x1, st = F.linear16_emit(ctx, F.weight16(at.proj.weight, p), at.proj.bias, x, state.cvec, ln2.eps, precision=p)   # proj + residual, emits LN2
+        h = F.linear16_lnfold(st, w1, b1, s1, act=F.ACT_GELU, precision=p)                     # LayerNorm 2 + fc1 + GELU
+        w2 = F.weight16(mlp.fc2.weight, p)
+        if next_eps is None:
+            return F.linear16(h, w2, mlp.fc2.bias, act=F.ACT_GELU, resid=x1, precision=p), None
+        return F.linear16_emit(h, w2, mlp.fc2.bias, x1, st.cvec, next_eps, act=F.ACT_GELU, precision=p)   # fc2 + GELU + residual, emits the next LN1
 
 
 class VisionTransformer(nn.Module):
@@ -165,8 +203,13 @@ class VisionTransformer(nn.Module):
         pos = F.vit_pos_table(self.position_embedding, ps, H, W)     # ViT.py:160-178: bicubic resize off the native grid (cached)
         tok = F.patch_embed(x, self.patch_embedding.proj.weight, self.patch_embedding.proj.bias,
                             self.cls_token.reshape(-1), pos, ps, self.precision)
-        for blk in self.blocks:
-            tok = blk(tok)
+        blocks, state = list(self.blocks), None
+        for i, blk in enumerate(blocks):
+            if blk.fold_ok(tok):                                  # LayerNorms folded into the GEMMs; the state travels block to block
+                nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                tok, state = blk.forward_folded(tok, state, nxt.layernorm1.eps if nxt is not None and nxt.fold_ok(tok) else None)
+            else:
+                tok, state = blk(tok), None
         if self.global_pool == "token":
             pooled = tok[:, 0]                                   # row-strided view, consumed in place by the GEMM
         elif self.global_pool == "avg":

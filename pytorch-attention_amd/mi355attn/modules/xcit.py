@@ -18,6 +18,7 @@ from torch import nn
 
 from .. import functional as F
 from .vit import _fast, _mlp16
+from .mhsa import _dropout_is_identity, _no_dropout
 
 
 class Mlp(nn.Module):
@@ -25,11 +26,15 @@ class Mlp(nn.Module):
         super().__init__()
         if act_layer is not nn.GELU:
             raise NotImplementedError("only the exact-erf GELU epilogue is built")
+        _no_dropout(drop)
         self.fc1 = nn.Linear(in_features, hidden_features or in_features, bias=bias)
+        self.drop1 = nn.Dropout(drop)                      # xcit.py:28,30: the identity in eval mode, refused in train mode
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features, bias=bias)
+        self.drop2 = nn.Dropout(drop)
         self.precision = None
 
     def forward(self, x, gamma=None, resid=None):
+        _dropout_is_identity(self)
         if self.fc1.bias is not None and _fast(self.precision, self.fc1, self.fc2):
             return _mlp16(x, self.fc1, self.fc2, self.precision, second_gelu=False, gamma=gamma, resid=resid)
         h = F.linear(x, self.fc1.weight, self.fc1.bias, act=F.ACT_GELU, precision=self.precision)
@@ -57,14 +62,18 @@ class XCA(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., precision=None):
         super().__init__()
         self.num_heads = num_heads
+        _no_dropout(attn_drop, proj_drop)
         self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)             # xcit.py:241,243: eval-mode identities
         self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
         self.precision = precision
 
     def forward(self, x, gamma=None, resid=None, ln=None):
         """`ln`: the LayerNorm in front of the block (XCABlock passes norm1 with the un-normalised x) -- applied on the way into the qkv
         GEMM when the width allows (functional.ln_linear16), else by the caller."""
+        _dropout_is_identity(self)
         if _fast(self.precision, self.qkv, self.proj):
             p = F._prec(self.precision)      # GEMMs on 16-bit operands; the d x d covariance core itself is exact fp32
             if ln is not None:
@@ -99,6 +108,7 @@ class XCABlock(nn.Module):
         self.gamma3 = nn.Parameter(eta * torch.ones(dim), requires_grad=True)
 
     def forward(self, x, H, W):
+        _dropout_is_identity(self)
         p = F._prec(self.attn.precision)
         fast = _fast(p, self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
 
@@ -215,9 +225,12 @@ class ClassAttention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., precision=None):
         super().__init__()
         self.num_heads = num_heads
+        _no_dropout(attn_drop, proj_drop)
         self.scale = qk_scale or (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)             # xcit.py:170,172: eval-mode identities
         self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
         self.precision = precision
 
     def cls_out(self, u):
@@ -230,6 +243,7 @@ class ClassAttention(nn.Module):
         return F.linear(att, self.proj.weight, self.proj.bias, precision=self.precision)
 
     def forward(self, x):
+        _dropout_is_identity(self)
         B, N, C = x.shape
         out = torch.empty_like(x)
         F.axpby(x[:, 1:], out[:, 1:], B, (N - 1) * C, N * C, N * C)                  # tokens pass through (xcit.py:187)
@@ -300,8 +314,7 @@ class XCiT(nn.Module):
                  mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., norm_layer=None, cls_attn_layers=2,
                  use_pos=True, patch_proj='linear', eta=None, tokens_norm=False, precision=None):
         super().__init__()
-        if drop_rate or attn_drop_rate:
-            raise NotImplementedError("inference engine: dropout rates must be 0")
+        _no_dropout(drop_rate, attn_drop_rate)             # accepted as the reference accepts them: eval-mode identities (xcit.py:333-346)
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.patch_embed = ConvPatchEmbed(img_size=img_size, embed_dim=embed_dim, patch_size=patch_size, precision=precision)
@@ -333,6 +346,7 @@ class XCiT(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward_features(self, x):
+        _dropout_is_identity(self)
         B = x.shape[0]
         ps = self.patch_embed.patch_size
         Hp, Wp = x.shape[2] // ps, x.shape[3] // ps

@@ -81,3 +81,34 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, f"product files import the oracle: {bad}"
+
+
+def test_options_are_per_device_with_process_defaults(built_lib):
+    """mi355_set_option acts on the calling thread's current device, mi355_set_default_option on what devices without an own setting
+    read (no process-global knobs).  Without a GPU the current device is ordinal 0, which is enough to
+    check the override / default semantics, the range checks and that the tuning-only GEMM variants are no longer reachable."""
+    import ctypes
+    lib = ctypes.CDLL(built_lib)
+    lib.mi355_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    lib.mi355_set_default_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    lib.mi355_get_option.argtypes = [ctypes.c_char_p]
+    lib.mi355_get_option.restype = ctypes.c_long
+    lib.mi355_last_error.restype = ctypes.c_char_p
+    # (the library may already be loaded in this process by the binding, which sets the DEFAULT of "ws_persistent": use another key)
+    assert lib.mi355_get_option(b"nt") == 3 and lib.mi355_get_option(b"reverse") == 0 and lib.mi355_get_option(b"ln_fold") == 0
+    assert lib.mi355_set_default_option(b"reverse", 1) == 0                # what the Python binding does for "ws_persistent" at load time
+    assert lib.mi355_get_option(b"reverse") == 1                           # no override on this device: the default shows
+    assert lib.mi355_set_option(b"reverse", 0) == 0                        # override on the current device wins ...
+    assert lib.mi355_get_option(b"reverse") == 0
+    assert lib.mi355_set_default_option(b"reverse", 1) == 0                # ... also over a later change of the default
+    assert lib.mi355_get_option(b"reverse") == 0
+    assert lib.mi355_set_default_option(b"reverse", 0) == 0
+    assert lib.mi355_set_option(b"gemm_variant", 16) == 0 and lib.mi355_get_option(b"gemm_variant") == 16
+    for bad in (17, 21, 31, -1):                                           # 17..21 were timing ablations that produce wrong results
+        assert lib.mi355_set_option(b"gemm_variant", bad) == -1
+        assert b"gemm_variant" in lib.mi355_last_error()
+    assert lib.mi355_get_option(b"gemm_variant") == 16
+    assert lib.mi355_set_option(b"gemm_variant", 0) == 0
+    assert lib.mi355_set_option(b"spin_limit", 0) == 0 and lib.mi355_set_option(b"spin_limit", 5) == -1
+    assert lib.mi355_set_option(b"spin_limit", 1 << 22) == 0
+    assert lib.mi355_set_option(b"no_such_key", 1) == -1 and lib.mi355_get_option(b"no_such_key") == -1

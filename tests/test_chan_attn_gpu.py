@@ -363,8 +363,8 @@ def test_exchange_kernels_under_graph_capture():
     """hipGraph capture of the channel-attention modules.  SE and CBAM record their single-read exchange kernels: the granule tag of a
     launch and the ticket word live in the workspace (epoch + 1; the last ticket draw of a launch resets the ticket and advances the
     epoch), so a replay is just another launch and eager calls may be interleaved with replays on the same workspace -- the results
-    are the same bits either way.  GCT (host-side launch tags) still steps aside to its multi-pass kernels under capture; ECA has no
-    exchange."""
+    are the same bits either way.  GCT records its single-read kernel the same way since round 4 (tests/test_round4_gpu.py checks
+    bit equality for GCT / LCT / Gaussian GCT); ECA has no exchange."""
     from mi355attn.modules import GCT
     se, _, cbam = _mods(64)
     gct = GCT(64)

@@ -67,3 +67,55 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _shape_check_worker(rank, world, port, q):
+    """RcclComm._check_equal_shards on a SUB-GROUP (ranks 0 and 2 of 3): the host collective must run over exactly the communicator's
+    ranks, a ragged call must raise on every member (not deadlock), and the decision to verify must not depend on what an individual
+    rank has seen before (a per-rank shape cache turned the ragged case into a hang)."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mi355attn.dist import RcclComm
+        grp = dist.new_group([0, 2])                      # every rank creates it; rank 1 is not a member
+        out = []
+        if rank in (0, 2):
+            c = RcclComm.__new__(RcclComm)                # the check needs no device: build the object without the C communicator
+            c.group, c.check, c._ncalls, c._h = grp, "always", 0, None
+            c.rank, c.world = dist.get_rank(grp), dist.get_world_size(grp)
+            c._check_equal_shards((4, 10))                # equal: passes
+            c._check_equal_shards((4, 10))                # seen before on both: still a collective, still passes
+            try:                                          # ragged, and rank 0 has "seen" its shape before while rank 2 has not
+                c._check_equal_shards((4, 10) if rank == 0 else (3, 10))
+                out.append("no error")
+            except ValueError:
+                out.append("raised")
+            c.fix_shape()
+            c._check_equal_shards((2, 2))                 # verified (first call after fix_shape)
+            c._check_equal_shards((2, 2) if rank == 0 else (9, 9))     # not verified any more: no collective, no error, no hang
+            out.append(c._ncalls)
+        dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_comm_shape_check_is_group_aware_and_collective_safe():
+    import sys
+    from conftest import PKG
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shape_check_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == ["raised", 2] and results[2] == ["raised", 2] and results[1] == []

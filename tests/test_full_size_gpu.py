@@ -47,7 +47,9 @@ def _device_batch(shape, slab=32):
     return x, host
 
 
-def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5, pin=("gemm_splitk", 0)):
+def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5, pin=(("gemm_splitk", 0),), path_tol=5e-4):
+    """`pin`: the options that make the kernel path independent of the batch size; `path_tol`: how far the default paths of the
+    full batch and of the 3-image batch may be apart."""
     import mi355attn
     m = module.cuda()
     x, host = _device_batch(shape)
@@ -67,19 +69,22 @@ def _check(name, module, shape, ref_fn, fwd_args=(), tol=1e-3, strict_tol=5e-5, 
         # summation order of those tiles changes, and a 1e-7 difference in front of a 16-bit re-rounding of the next operand shows up
         # at the operand format's rounding level downstream -- inside the parity tolerance by a factor of two at least.  With the
         # split off every row must be bit-identical whatever the batch around it.
-        assert_parity(sub.cpu(), y[PICK].cpu(), 5e-4, name + " [batch independence, split-K on]")
+        assert_parity(sub.cpu(), y[PICK].cpu(), path_tol, name + " [batch independence, default options]")
         # DoubleAttention's analogue: the number of pixel ranges an image is cut into follows the batch size ("da_ranges" pins it).
-        old_pin = mi355attn.get_option(pin[0])
-        mi355attn.set_option(*pin)
+        # ViT encoder chain (round 4): the LayerNorm fold needs rows % 128 == 0, so B = 256 folds and B = 3 does not ("ln_fold" pins it).
+        old_pin = [(k, mi355attn.get_option(k)) for k, _ in pin]
+        for k, v in pin:
+            mi355attn.set_option(k, v)
         try:
             with torch.no_grad():
                 y0 = m(x, *fwd_args)
                 sub0 = m(x[PICK].contiguous(), *fwd_args)
             torch.cuda.synchronize()
         finally:
-            mi355attn.set_option(pin[0], old_pin)
-        assert torch.equal(y0[PICK], sub0), name + f": output of an image depends on its batch neighbours ({pin[0]} = {pin[1]})"
-        assert_parity(y0[PICK].cpu(), ref, tol, name + f" [B=256, {pin[0]} = {pin[1]}]")
+            for k, v in old_pin:
+                mi355attn.set_option(k, v)
+        assert torch.equal(y0[PICK], sub0), name + f": output of an image depends on its batch neighbours ({pin})"
+        assert_parity(y0[PICK].cpu(), ref, tol, name + f" [B=256, {pin}]")
         del y0, sub0
     assert_parity(sub.cpu(), ref, tol, name + " [3-image batch]")
     del y2, sub
@@ -148,6 +153,21 @@ def test_c5_vit_base_full_size():
     _check("VisionTransformer(ViT-Base/16)", m, (B, 3, 224, 224), lambda xs: O.vit_forward(xs, sd, 12, 12))
 
 
+def test_c5_vit_base_full_size_with_the_layernorm_fold():
+    """The same forward with the opt-in LayerNorm fold ("ln_fold" = 1): B = 256 folds (rows % 128 == 0), the 3-image batch cannot, so
+    batch independence is checked with the fold pinned off."""
+    import mi355attn
+    from mi355attn.modules import VisionTransformer
+    m = _seeded(lambda: VisionTransformer(num_heads=12))
+    sd = _sd(m)
+    mi355attn.set_option("ln_fold", 1)
+    try:
+        _check("VisionTransformer(ViT-Base/16) + ln_fold", m, (B, 3, 224, 224), lambda xs: O.vit_forward(xs, sd, 12, 12),
+               pin=(("gemm_splitk", 0), ("ln_fold", 0)), path_tol=1e-3)
+    finally:
+        mi355attn.set_option("ln_fold", 0)
+
+
 def test_mixer_layer_full_size():
     from mi355attn.modules import MixerLayer
     m = _seeded(lambda: MixerLayer(512, 196))
@@ -161,4 +181,4 @@ def test_double_attention_full_size():
     sd = _sd(m)
     keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight", "proj.bias")
     _check("DoubleAttention(256,128,128)@56x56", m, (B, 256, 56, 56),
-           lambda xs: O.double_attention_forward(xs, *[sd[k] for k in keys]), pin=("da_ranges", 1))
+           lambda xs: O.double_attention_forward(xs, *[sd[k] for k in keys]), pin=(("da_ranges", 1),))

@@ -3,7 +3,9 @@ a yardstick for csrc/gemm16.hip, not a product path.    python tools/blas_probe.
 import torch, time
 dev = torch.device("cuda", 0)
 shapes = [("vit qkv", 50432, 2304, 768), ("vit proj", 50432, 768, 768), ("vit fc1", 50432, 3072, 768), ("vit fc2", 50432, 768, 3072),
-          ("cswin s3 qkv", 50176, 768, 256), ("cswin s3 fc1", 50176, 1024, 256), ("cswin s3 fc2", 50176, 256, 1024), ("mixer fc1", 50176, 2048, 512)]
+          ("cswin s3 qkv", 50176, 768, 256), ("cswin s3 fc1", 50176, 1024, 256), ("cswin s3 fc2", 50176, 256, 1024), ("mixer fc1", 50176, 2048, 512),
+          ("xcit qkv", 50176, 1152, 384), ("xcit proj", 50176, 384, 384), ("xcit fc1", 50176, 1536, 384), ("xcit fc2", 50176, 384, 1536),
+          ("cswin s3 proj", 50176, 256, 256), ("mixer tok fc1", 131072, 256, 256), ("mixer fc2", 50176, 512, 2048)]
 for name, M, N, K in shapes:
     a = torch.randn(M, K, device=dev, dtype=torch.float16)
     w = torch.randn(N, K, device=dev, dtype=torch.float16) / K ** 0.5
