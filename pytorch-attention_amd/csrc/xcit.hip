@@ -11,6 +11,7 @@
 // LPI (xcit.py:149-157): tokens -> (C,H,W) image -> dw3x3 -> GELU -> BatchNorm(eval) -> dw3x3 -> tokens, fused in one
 // kernel per (image, 32-channel group): the token tile and the intermediate sit in LDS, a lane owns 4 channels (16-byte LDS
 // and HBM accesses, 128-byte row pieces per token); LayerScale + residual fused.
+#include <type_traits>
 #include "common.h"
 #include "mma.h"
 
@@ -24,17 +25,31 @@ constexpr int XCA_TC = 64;      // tokens per chunk
 
 // OT: output element type (float, or the 16-bit operand type of the proj GEMM that follows: saves the cast pass over ctx);
 // IT: element type of qkv (float, or the 16-bit output of the qkv GEMM: halves the 3C-wide tensor the core streams twice).
-// The arithmetic is fp32 (exact-fp32 MFMA) either way.
+// Round 4 (the kernel sat at 82 us for three rounds; its busiest wave issued 336 exact-fp32 MFMAs of 32 cycles per (image, head)):
+//   * phase 1 is split along the TOKENS: wave w owns tokens 16 w .. 16 w + 15 of a chunk and accumulates all DT x DT tiles of
+//     G = Q^T K for them -- balanced (the tile-per-wave form left 9 tiles on 4 waves as 3 / 2 / 2 / 2), every q / k value is read
+//     from LDS once per row tile instead of once per tile pair, the squared column norms ride on the very values that feed the
+//     MFMAs, and 16-token slices beyond N are skipped (N = 196: 13 slices instead of 16).  The four partial sums are added in a
+//     fixed order (waves 0 + 3, then 1, then 2), so results stay bit-identical run to run;
+//   * phase 3 with 16-bit I/O (PV16): O = A V^T on the 16-bit matrix pipe -- A in [0, 1] rounded to the operand type (relative
+//     2^-11, the rounding v already carries), the V fragments come straight from global memory in operand layout (a lane's 8
+//     consecutive channels of one token = 16 bytes), no LDS staging and no barriers.  G, the norms and the softmax stay exact fp32;
+//     with fp32 I/O (strict mode) phase 3 stays on the exact-fp32 MFMA as well.
 template <int D, typename OT = float, typename IT = float>
-__global__ __launch_bounds__(256) void xca_kernel(const IT* __restrict__ qkv, const float* __restrict__ temperature,
+__global__ __launch_bounds__(256, D <= 48 ? 4 : 2) void xca_kernel(const IT* __restrict__ qkv, const float* __restrict__ temperature,
                                                  OT* __restrict__ out, int N, int heads) {
+    constexpr bool PV16 = !std::is_same<IT, float>::value && std::is_same<OT, IT>::value;
     constexpr int P = D + 1;                 // LDS pitch (floats): odd -> conflict-free column walks
     constexpr int DT = D / 16, D4 = D / 4;
     constexpr int NLD = (XCA_TC * D4 + 255) / 256;          // float4 loads per thread per array per chunk
-    __shared__ float s_a[XCA_TC * P];        // q chunk, later v chunk
-    __shared__ float s_b[XCA_TC * P];        // k chunk
-    __shared__ float s_g[D * P];             // G, then A = softmax(G)
-    __shared__ float s_n[2 * D];             // squared column norms of q and k (running), then the norms
+    constexpr int GD = D * D;                               // a dense partial G
+    __shared__ __attribute__((aligned(16))) float s_ab[2 * XCA_TC * P];   // q | k chunk (fp32 path: later the v chunk); after phase 1: two dense partial Gs
+    __shared__ __attribute__((aligned(16))) float s_g[D * P];             // G partial of waves 0 + 3, then A = softmax(G) (PV16: as a 16-bit image, pitch AP)
+    __shared__ float s_nw[4][2 * D];         // per-wave squared column norms of q and k
+    __shared__ float s_n[2 * D];             // the norms
+    static_assert(2 * GD <= 2 * XCA_TC * P, "two dense partials must fit the chunk buffers");
+    float* s_a = s_ab;
+    float* s_b = s_ab + XCA_TC * P;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
     const int lid = xcd_contiguous_block();                 // the heads of an image read adjacent column blocks of the same rows
     const int h = lid % heads, b = lid / heads;
@@ -44,14 +59,6 @@ __global__ __launch_bounds__(256) void xca_kernel(const IT* __restrict__ qkv, co
     typedef IT i4 __attribute__((ext_vector_type(4)));
     auto ld4 = [&](const IT* p) { const i4 v = *reinterpret_cast<const i4*>(p); return f4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; };
     const int nchunks = (N + XCA_TC - 1) / XCA_TC;
-
-    // which G tiles this wave accumulates (DT*DT tiles round-robin over the 4 waves, at most 4 each for D = 64)
-    constexpr int TPW = (DT * DT + 3) / 4;
-    f4 gacc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) gacc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float nsq = 0.f;                                        // threads t < 2D: running sum of squares of one q / k column
-    if (t < 2 * D) s_n[t] = 0.f;
 
     auto stage = [&](int chunk, int which_a, int which_b, bool two) {     // which_*: 0 = q, 1 = k, 2 = v
         f4 ra[NLD], rb[NLD];
@@ -79,93 +86,182 @@ __global__ __launch_bounds__(256) void xca_kernel(const IT* __restrict__ qkv, co
         }
     };
 
-    // ---- phase 1: G = Q^T K and the column norms, chunk by chunk (exact fp32 MFMA 16x16x4) -------------------------------------
+    // ---- phase 1: G = Q^T K and the squared column norms; wave w owns tokens 16 w .. 16 w + 15 of every chunk -------------------
+    f4 gacc[DT][DT];
+    float nq[DT], nk[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+        nq[i] = nk[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) gacc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
         stage(ch, 0, 1, true);
         __syncthreads();
-        if (t < 2 * D) {
-            const float* src = (t < D ? s_a : s_b) + (t % D);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 4
-            for (int n = 0; n < XCA_TC; n += 4) {
-                const float v0 = src[n * P], v1 = src[(n + 1) * P], v2 = src[(n + 2) * P], v3 = src[(n + 3) * P];
-                a0 += v0 * v0; a1 += v1 * v1; a2 += v2 * v2; a3 += v3 * v3;
-            }
-            nsq += (a0 + a1) + (a2 + a3);
-        }
+        if (ch * XCA_TC + wave * 16 < N) {                  // wave-uniform: slices beyond N hold only zero rows
 #pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-            const int tl = wave + 4 * ti;
-            if (tl < DT * DT) {
-                const int it = tl / DT, jt = tl % DT;
-                f4 acc = gacc[ti];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = wave * 16 + ks * 4 + g;
+                float av[DT], bv[DT];
 #pragma unroll
-                for (int ks = 0; ks < XCA_TC / 4; ++ks) {
-                    const float av = s_a[(ks * 4 + g) * P + it * 16 + l15];
-                    const float bv = s_b[(ks * 4 + g) * P + jt * 16 + l15];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                for (int i = 0; i < DT; ++i) {
+                    av[i] = s_a[row * P + i * 16 + l15];
+                    bv[i] = s_b[row * P + i * 16 + l15];
+                    nq[i] += av[i] * av[i];
+                    nk[i] += bv[i] * bv[i];
                 }
-                gacc[ti] = acc;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) gacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], gacc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    if (t < 2 * D) s_n[t] = fmaxf(sqrtf(nsq), 1e-12f);      // F.normalize: x / max(||x||, 1e-12)
+    // column norms: a lane saw the tokens of its quarter g; quarters, then waves, are added in a fixed order
 #pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int tl = wave + 4 * ti;
-        if (tl < DT * DT) {
-            const int it = tl / DT, jt = tl % DT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_g[(it * 16 + g * 4 + r) * P + jt * 16 + l15] = gacc[ti][r];
+    for (int i = 0; i < DT; ++i) {
+        nq[i] += __shfl_xor(nq[i], 16, WAVE);
+        nq[i] += __shfl_xor(nq[i], 32, WAVE);
+        nk[i] += __shfl_xor(nk[i], 16, WAVE);
+        nk[i] += __shfl_xor(nk[i], 32, WAVE);
+        if (g == 0) {
+            s_nw[wave][i * 16 + l15] = nq[i];
+            s_nw[wave][D + i * 16 + l15] = nk[i];
         }
     }
+    // partial Gs: wave 0 -> s_g, waves 1 / 2 -> the two dense buffers over the (now free) chunk area, wave 3 is added to s_g afterwards
+    {
+        float* dst = wave == 1 ? s_ab : s_ab + GD;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = i * 16 + g * 4 + r, gj = j * 16 + l15;
+                    if (wave == 0) s_g[gi * P + gj] = gacc[i][j][r];
+                    else if (wave != 3) dst[gi * D + gj] = gacc[i][j][r];
+                }
+    }
     __syncthreads();
-    // ---- phase 2: A = softmax_rows(G / (|q_i| |k_j|) * temperature): 16 lanes per row ------------------------------------------
+    if (wave == 3) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_g[(i * 16 + g * 4 + r) * P + j * 16 + l15] += gacc[i][j][r];
+    }
+    if (t < 2 * D) s_n[t] = fmaxf(sqrtf(((s_nw[0][t] + s_nw[1][t]) + s_nw[2][t]) + s_nw[3][t]), 1e-12f);     // F.normalize: x / max(||x||, 1e-12)
+    __syncthreads();
+    // ---- phase 2: A = softmax_rows(G / (|q_i| |k_j|) * temperature): 16 lanes per row; rows stay in registers until every thread has
+    //      read the partial sums, then A replaces G (PV16: as the 16-bit operand image) ------------------------------------------
+    constexpr int KSA = (D + 31) / 32;       // 16x16x32 steps over j
+    constexpr int AP = KSA * 32 + 8;         // pitch (elements) of the 16-bit A image: KSA * 32 k columns (D .. zero) + 8 of padding
+    constexpr int RPT = (D + 15) / 16;       // rows per thread
     {
         const float temp = temperature[h];
         const int tj = t & 15;
-        for (int i = t >> 4; i < D; i += 16) {
-            float v[DT];
+        float pv[RPT][DT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int i = (t >> 4) + 16 * rr;
             float m = -INFINITY;
 #pragma unroll
             for (int c = 0; c < DT; ++c) {
                 const int j = tj + 16 * c;
-                v[c] = s_g[i * P + j] / (s_n[i] * s_n[D + j]) * temp;
-                m = fmaxf(m, v[c]);
+                const float gij = i < D ? (s_g[i * P + j] + s_ab[i * D + j]) + s_ab[GD + i * D + j] : 0.f;
+                pv[rr][c] = i < D ? gij / (s_n[i] * s_n[D + j]) * temp : 0.f;
+                m = fmaxf(m, pv[rr][c]);
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
             float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < DT; ++c) { v[c] = expf(v[c] - m); sum += v[c]; }
+            for (int c = 0; c < DT; ++c) { pv[rr][c] = expf(pv[rr][c] - m); sum += pv[rr][c]; }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
 #pragma unroll
-            for (int c = 0; c < DT; ++c) s_g[i * P + tj + 16 * c] = v[c] / sum;
+            for (int c = 0; c < DT; ++c) pv[rr][c] = pv[rr][c] / sum;
+        }
+        __syncthreads();
+        if constexpr (PV16) {
+            IT* a16 = reinterpret_cast<IT*>(s_g);
+            static_assert(D * AP * 2 <= D * P * 4, "the 16-bit A image must fit the G buffer");
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) {
+                const int i = (t >> 4) + 16 * rr;
+                if (i < D) {
+#pragma unroll
+                    for (int c = 0; c < 2 * KSA; ++c) a16[i * AP + tj + 16 * c] = c < DT ? (IT)pv[rr][c < DT ? c : 0] : (IT)0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) {
+                const int i = (t >> 4) + 16 * rr;
+                if (i < D) {
+#pragma unroll
+                    for (int c = 0; c < DT; ++c) s_g[i * P + tj + 16 * c] = pv[rr][c];
+                }
+            }
         }
     }
     __syncthreads();
-    // ---- phase 3: O[i][n] = sum_j A[i][j] v[n][j], chunk by chunk; lane holds 4 consecutive i of one token -> 16-byte stores ----
-    for (int ch = 0; ch < nchunks; ++ch) {
-        stage(ch, 2, 2, false);
-        __syncthreads();
-        for (int tl = wave; tl < DT * (XCA_TC / 16); tl += 4) {
-            const int it = tl % DT, nt = tl / DT;
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- phase 3: O[i][n] = sum_j A[i][j] v[n][j]; lane holds 4 consecutive i of one token -> 8 / 16-byte stores -----------------
+    if constexpr (PV16) {
+        typedef IT v8 __attribute__((ext_vector_type(8)));
+        typedef OT o4 __attribute__((ext_vector_type(4)));
+        constexpr int KS = KSA;
+        const IT* a16 = reinterpret_cast<const IT*>(s_g);
+        v8 af[DT][KS];
 #pragma unroll
-            for (int ks = 0; ks < D / 4; ++ks) {
-                const float av = s_g[(it * 16 + l15) * P + ks * 4 + g];
-                const float bv = s_a[(nt * 16 + l15) * P + ks * 4 + g];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) af[i][kk] = *reinterpret_cast<const v8*>(a16 + (i * 16 + l15) * AP + kk * 32 + g * 8);
+        const int ntiles = (N + 15) >> 4;
+        for (int nt = wave; nt < ntiles; nt += 4) {
+            const int n = nt * 16 + l15;
+            v8 bf[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                bf[kk] = v8{};
+                if (n < N && kk * 32 + g * 8 < D) bf[kk] = *reinterpret_cast<const v8*>(base + (long)n * row3 + 2 * C + kk * 32 + g * 8);
             }
-            const int n = ch * XCA_TC + nt * 16 + l15;
-            if (n < N) {
-                typedef OT o4 __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<o4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = o4{(OT)acc.x, (OT)acc.y, (OT)acc.z, (OT)acc.w};
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    if constexpr (std::is_same<IT, _Float16>::value) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[kk], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[kk], acc, 0, 0, 0);
+                }
+                if (n < N) *reinterpret_cast<o4*>(out + ((long)b * N + n) * C + h * D + i * 16 + g * 4) = o4{(OT)acc.x, (OT)acc.y, (OT)acc.z, (OT)acc.w};
             }
         }
-        __syncthreads();
+    } else {
+        for (int ch = 0; ch < nchunks; ++ch) {
+            stage(ch, 2, 2, false);
+            __syncthreads();
+            for (int tl = wave; tl < DT * (XCA_TC / 16); tl += 4) {
+                const int it = tl % DT, nt = tl / DT;
+                if (ch * XCA_TC + nt * 16 >= N) continue;   // wave-uniform: token tiles beyond N
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < D / 4; ++ks) {
+                    const float av = s_g[(it * 16 + l15) * P + ks * 4 + g];
+                    const float bv = s_a[(nt * 16 + l15) * P + ks * 4 + g];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+                const int n = ch * XCA_TC + nt * 16 + l15;
+                if (n < N) {
+                    typedef OT o4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<o4*>(out + ((long)b * N + n) * C + h * D + it * 16 + g * 4) = o4{(OT)acc.x, (OT)acc.y, (OT)acc.z, (OT)acc.w};
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
