@@ -496,8 +496,11 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         // fp32 (+ residual) outputs: the two-accumulator persistent kernel (gemm16_pa.hip) hides the residual / store round trips of
         // tile i under the main loop of tile i + 1 (ViT-Base proj 0.130 -> 0.106 ms, fc2 0.266 -> 0.259; profiles/r03_gemm_pa.md).
         // No inter-workgroup exchange: safe under hipGraph capture, and a row's bits never depend on where its tile falls.
+        // Round 4: widths that are a multiple of 128 but not of 256 (XCiT: N = 384) run 256 x 128 tiles (operand roles swapped), and
+        // half a round of tiles is enough (CSWin stage 4 fc2: 196 tiles, 41 -> 36 us).
         const int ncu = mi355::resident_slots(1);
-        if ((long)cdiv(M, 128) * (N / 256) >= ncu) {
+        const long tiles = (N & 255) ? (long)(M / 256) * (N / 128) : (long)cdiv(M, 128) * (N / 256);
+        if (2 * tiles >= ncu) {
             const int rc = mi355::gemm16_pa(g, out16, precision, st);
             if (rc == MI355_OK) {
                 MI355_LAUNCH_CHECK();

@@ -102,9 +102,16 @@ __device__ __forceinline__ void pa_wait4(f4& a, f4& b, f4& c, f4& d) {
 // LNC (fp32 outputs only): the LayerNorm fold's producer side -- beside Y every epilogue unit (16 rows x 32 columns, final values
 // already in the row layout) emits T(Y - c[row]) as the next GEMM's 16-bit operand and the unit's exact (mean, sum of squared
 // deviations) per row; +2 loads (c of the unit's two row halves, issued with the residual) and +4 stores per unit in the counts.
-template <typename T, bool OUT16, bool GELU, int ABL = 0, bool LNC = false>
+// SWAP: the roles of the operands are exchanged -- the 128-row slot carries W (128 OUTPUT COLUMNS per tile), the two 128-row B slots
+// carry X (256 output rows per tile): a 256 (M) x 128 (N) tile for widths like N = 384 that a 256-column tile covers with a quarter
+// of its MFMAs on padding.  Nothing in the staging, the LDS image or the fragment reads knows which matrix it moves; what changes is
+// the operand order of the MFMA (the lane's "four consecutive" axis must stay the output-column axis), the accumulator index order
+// (cur[row tile][column tile]) and which wave index belongs to which output axis in the epilogue addresses.  Same K order per output:
+// bit-identical results.
+template <typename T, bool OUT16, bool GELU, int ABL = 0, bool LNC = false, bool SWAP = false>
 __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const PaPlan pl) {
     static_assert(!(LNC && OUT16), "the emitting epilogue exists for fp32 outputs only");
+    static_assert(!(LNC && SWAP), "the emitting epilogue is built for the 128 x 256 orientation");
     using v8 = typename Vec8<T>::t;
     using v4 = typename Vec8<T>::t4;
     constexpr int SLOTB = 128 * BK * 2;                         // bytes per slot (16 KB)
@@ -116,9 +123,11 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const T* __restrict__ A = static_cast<const T*>(g.A);
-    const T* __restrict__ B = static_cast<const T*>(g.B);
+    const int wr = wave >> 2, wc = wave & 3;                    // wave index along the 128-row slot / along the 256-row slots
+    const int wm = SWAP ? wc : wr, wn = SWAP ? wr : wc;         // ... along the output rows / columns (64 each)
+    const T* __restrict__ A = static_cast<const T*>(SWAP ? g.B : g.A);      // operand of the 128-row slot, row stride sld_a
+    const T* __restrict__ B = static_cast<const T*>(SWAP ? g.A : g.B);      // operand of the 256-row slots, row stride sld_b
+    const int sld_a = SWAP ? g.ldb : g.lda, sld_b = SWAP ? g.lda : g.ldb;
     const int nk = g.K / BK;
     const int tiles_n = pl.tiles_n;
 
@@ -141,12 +150,14 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // further = a different scalar base.  The cursor itself is scalar state.
     struct Cursor { const T* ta; const T* tb; int kt; int ent; };
     const int rb0 = wave * 16 + lrow;
-    const unsigned la = (unsigned)((wr * 64 + wc * 16 + lrow) * g.lda + csw) * 2u;
-    const unsigned lbo = (unsigned)(((rb0 >> 5) * 64 + (rb0 & 31)) * g.ldb + csw) * 2u;
+    const unsigned la = (unsigned)((wr * 64 + wc * 16 + lrow) * sld_a + csw) * 2u;
+    const unsigned lbo = (unsigned)(((rb0 >> 5) * 64 + (rb0 & 31)) * sld_b + csw) * 2u;
     auto seek = [&](Cursor& c, int e) {
         const int tile = entry_tile(e);
-        c.ta = A + (long)((tile / tiles_n) * 128) * g.lda;
-        c.tb = B + (long)((tile % tiles_n) * 256) * g.ldb;
+        // pl.tiles_n = tiles along the fast axis of the tile order = the OUTPUT COLUMN axis in both orientations (the row panel of X
+        // that the column tiles of a row share is then used by neighbouring workgroups at the same time)
+        c.ta = A + (long)((SWAP ? tile % tiles_n : tile / tiles_n) * 128) * sld_a;
+        c.tb = B + (long)((SWAP ? tile / tiles_n : tile % tiles_n) * 256) * sld_b;
         c.kt = 0;
         c.ent = e;
     };
@@ -156,12 +167,12 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     const unsigned dA = (unsigned)(S_A + (wr * 64 + wc * 16) * 128), dB = (unsigned)((wave * 16) * 128);
     auto stage_a = [&](const Cursor& c, unsigned base) {
         const T* s0 = c.ta + (long)c.kt * BK;
-        pa_dma2(s0, s0 + (long)8 * g.lda, la, base + dA, base + dA + 1024u);
+        pa_dma2(s0, s0 + (long)8 * sld_a, la, base + dA, base + dA + 1024u);
     };
     auto stage_b = [&](const Cursor& c, unsigned base, int half) {
         const unsigned d = base + (half ? S_B1 : S_B0) + dB;
-        const T* s0 = c.tb + (long)c.kt * BK + (half ? (long)32 * g.ldb : 0);
-        pa_dma2(s0, s0 + (long)8 * g.ldb, lbo, d, d + 1024u);
+        const T* s0 = c.tb + (long)c.kt * BK + (half ? (long)32 * sld_b : 0);
+        pa_dma2(s0, s0 + (long)8 * sld_b, lbo, d, d + 1024u);
     };
 
     // ---- fragment reads ------------------------------------------------------------------------------------------------------------
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
 
     // L (16-bit): the bias of the wave's four column tiles, once per tile
     auto epi_load16 = [&]() {
-        const unsigned so0 = (unsigned)(pn0 + wc * 64) * 4u, so1 = so0 + 64u, so2 = so0 + 128u, so3 = so0 + 192u;
+        const unsigned so0 = (unsigned)(pn0 + wn * 64) * 4u, so1 = so0 + 64u, so2 = so0 + 128u, so3 = so0 + 192u;
         asm volatile("s_nop 4\n\t"
                      "buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
                      "buffer_load_dwordx4 %1, %4, %5, %7 offen\n\t"
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     };
     // L (fp32): residual row lines of unit (i, jh) [behind the bias of column half jh]
     auto epi_load32_bias = [&](int jh) {
-        const unsigned so0 = (unsigned)(pn0 + wc * 64 + jh * 32) * 4u, so1 = so0 + 64u;
+        const unsigned so0 = (unsigned)(pn0 + wn * 64 + jh * 32) * 4u, so1 = so0 + 64u;
         asm volatile("s_nop 4\n\t"
                      "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
                      "buffer_load_dwordx4 %1, %2, %3, %5 offen"
@@ -238,9 +249,9 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
                      : "memory");
     };
     auto epi_load32_res = [&](int i, int jh, f4& r0, f4& r1, float& c0, float& c1) {
-        const unsigned sr0 = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u, sr1 = sr0 + (unsigned)(8 * g.ldc) * 4u;
+        const unsigned sr0 = (unsigned)((pm0 + wm * 64 + i * 16) * g.ldc + pn0 + wn * 64 + jh * 32) * 4u, sr1 = sr0 + (unsigned)(8 * g.ldc) * 4u;
         if constexpr (LNC) {
-            const unsigned sc0 = (unsigned)(pm0 + wr * 64 + i * 16) * 4u;
+            const unsigned sc0 = (unsigned)(pm0 + wm * 64 + i * 16) * 4u;
             // lane id from mbcnt (two VALU ops) instead of a register kept alive across the main loop
             unsigned vo_cv = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             vo_cv = (vo_cv >> 3) * 4u;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     auto epi_f16 = [&](int i) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned ub = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64) * 2u;
+        const unsigned ub = (unsigned)((pm0 + wm * 64 + i * 16) * g.ldc + pn0 + wn * 64) * 2u;
         const u32x4_ o0 = *reinterpret_cast<const u32x4_*>(slab + sw_r), o1 = *reinterpret_cast<const u32x4_*>(slab + sw_r + 1024);
         __builtin_amdgcn_raw_buffer_store_b128(o0, rs_c, vo_row + ub, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o1, rs_c, vo_row + ub + (unsigned)(8 * g.ldc) * 2u, 0, 0);
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     auto epi_f32 = [&](int i, int jh, f4 r0, f4 r1, float c0, float c1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned ub = (unsigned)((pm0 + wr * 64 + i * 16) * g.ldc + pn0 + wc * 64 + jh * 32) * 4u;
+        const unsigned ub = (unsigned)((pm0 + wm * 64 + i * 16) * g.ldc + pn0 + wn * 64 + jh * 32) * 4u;
         const f4 o0 = *reinterpret_cast<const f4*>(slab + sw_r) + r0;
         const f4 o1 = *reinterpret_cast<const f4*>(slab + sw_r + 1024) + r1;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o0), rs_c, vo_row + ub, 0, 0);
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             const unsigned ua = ub >> 1;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, h0), rs_a, vo_a + ua, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, h1), rs_a, vo_a + ua + (unsigned)(8 * g.ldc) * 2u, 0, 0);
-            const unsigned us = (unsigned)(((pn0 + wc * 64 + jh * 32) >> 5) * g.M + pm0 + wr * 64 + i * 16) * 8u;
+            const unsigned us = (unsigned)(((pn0 + wn * 64 + jh * 32) >> 5) * g.M + pm0 + wm * 64 + i * 16) * 8u;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f2_{m0, q0}), rs_st, vo_st, us, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f2_{m1, q1}), rs_st, vo_st, us + 64u, 0);
         }
@@ -430,7 +441,10 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if constexpr (!(ABL & 4)) cur[i][j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][j]);
+                    if constexpr (!(ABL & 4)) {
+                        if constexpr (SWAP) cur[j][i] = mma16<T>(fa[i][kk], fb[j][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[j][i]);
+                        else cur[i][j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][j]);
+                    }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PA_BAR();
@@ -457,7 +471,10 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if constexpr (!(ABL & 4)) cur[i][2 + j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][2 + j]);
+                    if constexpr (!(ABL & 4)) {
+                        if constexpr (SWAP) cur[2 + j][i] = mma16<T>(fa[i][kk], fb[j][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[2 + j][i]);
+                        else cur[i][2 + j] = mma16<T>(fb[j][kk], fa[i][kk], (FIRST && kk == 0) ? f4{0.f, 0.f, 0.f, 0.f} : cur[i][2 + j]);
+                    }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PA_BAR();
@@ -490,8 +507,8 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         }
         for (; kt < nk; ++kt) ktile(IC<-1>{}, IC<0>{}, cur, prv);
         const int tl = entry_tile(ent);
-        pm0 = (tl / tiles_n) * 128;
-        pn0 = (tl % tiles_n) * 256;
+        pm0 = (tl / tiles_n) * (SWAP ? 256 : 128);
+        pn0 = (tl % tiles_n) * (SWAP ? 128 : 256);
         ++ent;
     };
     // ---- serial drain (last tile of the workgroup): the same pieces back to back, nothing else in flight ----------------------------
@@ -560,13 +577,16 @@ namespace mi355 {
 // Launch the two-accumulator persistent kernel when the shape suits it; MI355_EUNSUPPORTED (nothing touched) otherwise.
 int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl) {
     const int nk = g.K / g16::BK;
-    if ((g.K % g16::BK) || nk < (out16 ? 9 : 10) || (g.N & 255) || g.gamma || g.resid_period || (out16 && g.resid)) return MI355_EUNSUPPORTED;
+    if ((g.K % g16::BK) || nk < (out16 ? 9 : 10) || g.gamma || g.resid_period || (out16 && g.resid)) return MI355_EUNSUPPORTED;
     if ((long)g.M * g.ldc * 4 >= (1L << 31) || (long)g.M * g.lda * 2 >= (1L << 32) || (long)g.N * g.ldb * 2 >= (1L << 32))
         return MI355_EUNSUPPORTED;                                                                           // 32-bit buffer / lane offsets
-    if (g.M & 127) return MI355_EUNSUPPORTED;
+    // orientation: 128 (M) x 256 (N) tiles when N is a multiple of 256; 256 (M) x 128 (N) tiles (SWAP) for the other multiples of
+    // 128 (N = 384: three exact column tiles instead of 256 + a half-empty 256)
+    const bool swap = (g.N & 255) != 0;
+    if (swap ? ((g.N & 127) || (g.M & 255) || g.lnc_a || abl) : (g.M & 127) != 0) return MI355_EUNSUPPORTED;
     PaPlan pl{};
-    pl.tiles_n = g.N / 256;
-    const long ntiles = (long)cdiv(g.M, 128) * pl.tiles_n;
+    pl.tiles_n = swap ? g.N / 128 : g.N / 256;
+    const long ntiles = (long)(swap ? g.M / 256 : g.M / 128) * pl.tiles_n;
     if (ntiles > (1L << 30)) return MI355_EUNSUPPORTED;
     const int ncu = resident_slots(1);
     const int grid = ntiles < ncu ? (int)ntiles : ncu;
@@ -601,7 +621,11 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
 #else
     if (abl) return MI355_EUNSUPPORTED;
 #endif
-#define PA_LAUNCH(T_, O_, G_) gemm16_pa_kernel<T_, O_, G_><<<grid, 512, 0, st>>>(g, pl)
+#define PA_LAUNCH(T_, O_, G_)                                                          \
+    do {                                                                               \
+        if (swap) gemm16_pa_kernel<T_, O_, G_, 0, false, true><<<grid, 512, 0, st>>>(g, pl);   \
+        else      gemm16_pa_kernel<T_, O_, G_><<<grid, 512, 0, st>>>(g, pl);           \
+    } while (0)
 #define PA_BY_EPI(T_)                                                    \
     do {                                                                 \
         if (out16) { if (gelu) PA_LAUNCH(T_, true, true); else PA_LAUNCH(T_, true, false); }   \

@@ -618,6 +618,22 @@ def weight16(param, precision=None):
     return _derived_get((param,), ("w16", p), tag, lambda: cast16(param.detach(), p))
 
 
+def weight16_scaled(weight, bias, gamma, precision=None):
+    """(W16', b') with a LayerScale folded in: y = resid + gamma * (x W^T + b) = resid + x (gamma[:, None] * W)^T + gamma * b when no
+    activation sits between the product and the scale (XCiT: x + gamma1 * proj(..), x + gamma2 * fc2(..), xcit.py:290-294).  The GEMM
+    then needs no per-column scale in its epilogue and can take the two-accumulator kernel.  Cached with the parameters."""
+    p = _prec(precision)
+    anchors = (weight, gamma) + ((bias,) if bias is not None else ())
+    tag = tuple((t._version, t.data_ptr(), tuple(t.shape)) for t in anchors)
+
+    def build():
+        g = gamma.detach().reshape(-1)
+        w16 = cast16((weight.detach() * g[:, None]).contiguous(), p)
+        return w16, (None if bias is None else (bias.detach() * g).contiguous())
+
+    return _derived_get(anchors, ("w16scaled", p), tag, build)
+
+
 def mlp_fused_ok(C, hidden, precision=None):
     """Shape / precision envelope of mi355_mlp_fused_fwd."""
     return _prec(precision) in (PREC_FP16, PREC_BF16) and (C, hidden) in ((64, 256), (128, 512))

@@ -29,6 +29,9 @@ def _mlp16(x, fc1, fc2, precision, second_gelu, gamma=None, resid=None):
     p = F._prec(precision)
     x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
     h16 = F.linear16(x16, F.weight16(fc1.weight, p), fc1.bias, act=F.ACT_GELU, out16=True, precision=p)
+    if gamma is not None and not second_gelu:                 # LayerScale folded into fc2 (XCiT: no activation behind fc2)
+        w16, b = F.weight16_scaled(fc2.weight, fc2.bias, gamma, p)
+        return F.linear16(h16, w16, b, resid=resid, precision=p)
     return F.linear16(h16, F.weight16(fc2.weight, p), fc2.bias, act=F.ACT_GELU if second_gelu else F.ACT_NONE, gamma=gamma,
                       resid=resid, precision=p)
 

@@ -33,6 +33,11 @@ PA_SHAPES = [  # (M, N, K): M % 128 == 0, N % 256 == 0, K >= 640
     (128 * 394, 768, 768),           # ViT-Base proj: 4.6 rounds
     (128 * 200, 768, 3072),          # long reduction (ViT-Base fc2 geometry)
     (128 * 37, 1024, 1152),
+    # round 4, swapped orientation (256 x 128 tiles): M % 256 == 0, N % 128 == 0 but not % 256
+    (256, 128, 640),                 # one tile
+    (256 * 3, 384, 768),             # 9 tiles, three column tiles per row panel
+    (256 * 196, 384, 1536),          # XCiT-S fc2 at B = 256: 588 tiles = 2.3 rounds
+    (256 * 70, 640, 1024),           # five column tiles
 ]
 
 

@@ -24,7 +24,8 @@ if os.environ.get("GEMM_SET") == "narrow":
               ("s4_qkv", 1536, 512, True, False, False, 12544), ("s4_proj", 512, 512, False, True, False, 12544),
               ("s4_fc1", 2048, 512, True, False, True, 12544), ("s4_fc2", 512, 2048, False, True, False, 12544),
               ("x_qkv", 1152, 384, True, False, False, 50176), ("x_proj", 384, 384, False, True, False, 50176),
-              ("x_fc1", 1536, 384, True, False, True, 50176), ("x_fc2", 384, 1536, False, True, False, 50176)]
+              ("x_fc1", 1536, 384, True, False, True, 50176), ("x_fc2", 384, 1536, False, True, False, 50176),
+              ("m_fc1", 2048, 512, True, False, True, 50176), ("m_fc2", 512, 2048, False, True, False, 50176)]
 if os.environ.get("GEMM_SHAPES"):
     shapes = [s_ for s_ in shapes if s_[0] in os.environ["GEMM_SHAPES"].split(",")]
 if os.environ.get("GEMM_LONGK"):
@@ -43,7 +44,10 @@ for shp in shapes:
     for v in variants:
         mi355attn.set_option("gemm_variant", v)
         act = F.ACT_GELU if gelu else F.ACT_NONE
-        y = F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
+        try:
+            y = F.linear16(x16, w16, b, act=act, resid=resid, out16=out16, precision=1)
+        except mi355attn.Mi355Error:
+            continue                                         # this variant does not take the shape
         torch.cuda.synchronize()
         same = True if ref is None else bool(torch.equal(y, ref))
         relerr = 0.0 if ref is None else float((y.float() - ref.float()).norm() / ref.float().norm())
