@@ -360,7 +360,7 @@ def main(argv=None):
                     rec["strict_ms"] = round(time_block(b, max(3, args.steps // 4)), 4)
         finally:
             mi355attn.set_default_precision(1 if args.precision is None else args.precision)
-    dominant = None if args.only else dominant_kernel_probe(blocks, dev, args)     # --only runs feed the PMC passes: block kernels only
+    dominant = None
 
     # achievable-bandwidth yardstick: float4 streaming copy of the same footprint
     copy_gbs = None
@@ -395,6 +395,8 @@ def main(argv=None):
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
     dom = max(per_block, key=lambda r: r["ms"])
+    if rank == 0 and not args.only:                            # --only runs feed the PMC passes: block kernels only
+        dominant = dominant_kernel_tally(blocks[per_block.index(dom)], run_block, args, dom["ms"])
     out = {
         "metric": "forward images/sec through one step (+ ms/block), B=%d per GPU, 224x224-derived shapes; CPU leg = oracle port "
                   "of the reference forward on this host" % args.batch,
@@ -410,11 +412,12 @@ def main(argv=None):
                    "gather": gather_kind, "ranks_seen": ranks_seen, "ms_per_step_by_rank": rank_ms,
                    "rccl_self_test": ("passed on every rank" if comm_ok else ("not run (single rank)" if world == 1 else "FAILED or skipped: see gather")),
                    "blocks": per_block, "stream_copy_GBps": copy_gbs, "traffic_source": pmc_note},
-        # `roofline` grades the slowest BLOCK of the step (a block is many launches: `block` names it); `dominant_kernel` is the one
-        # kernel that takes the largest share of that block, timed on its own in this process
+        # `roofline` grades the slowest BLOCK of the step (a block is many launches: `block` names it, achieved / frac are the block's);
+        # `kernel` names the one kernel that takes the largest share of that block and `dominant_kernel` carries its own figures, both
+        # from an in-process HIP-event tally of the block's own launches
         "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                     "frac": dom["frac"], "traffic": dom["traffic"], "block": dom["block"], "kernel": dom["block"], "ms": dom["ms"],
-                     "dominant_kernel": dominant},
+                     "frac": dom["frac"], "traffic": dom["traffic"], "block": dom["block"],
+                     "kernel": dominant["name"] if dominant else dom["block"], "ms": dom["ms"], "dominant_kernel": dominant},
     }
 
     if world == 1 and not args.no_cpu:
@@ -424,45 +427,56 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def dominant_kernel_probe(blocks, dev, args):
-    """The single kernel that dominates the slowest block, on its own: when the step contains the ViT-Base forward that is the
-    persistent 256 x 256 GEMM with 16-bit output (gemm16_p8_kernel<f16, out16>: the qkv and fc1 launches, 24 of the 48 GEMM
-    launches and the largest share of the forward).  Each of its two shapes is launched back to back on synthetic operands of the
-    timed size and bracketed with HIP events on the launch stream: one launch = one kernel, so the interval / launches is the
-    kernel's average duration (the rocprofv3 table under profiles/ lists the same kernel; it must agree).  FLOPs = 2 M N K."""
+def dominant_kernel_tally(block, run_block, args, ms_block):
+    """The kernel that takes the largest share of the slowest block, from an IN-PROCESS tally of that block's OWN launches: the library
+    brackets every instrumented launch with HIP events on the launch stream (include/mi355attn.h mi355_trace_begin / _end) while the
+    block's forward runs `reps` times; a tag = kernel name + the shape parameters that tell its launches apart.  Returns the per-tag
+    table and the dominant KERNEL (tags of one kernel summed), with its own roofline figure when its work is known (GEMM: 2 M N K)."""
+    import re
     import torch
     import mi355attn
-    from mi355attn import StreamTimer
-    from mi355attn import functional as F
-    if not any(b["name"].startswith("VisionTransformer") for b in blocks) or mi355attn.default_precision() != 1:
-        return None
-    M = args.batch * 197
-    out, tot_flop, tot_ms, n = [], 0.0, 0.0, 0
-    for tag, N, K, gelu, per_fwd in (("qkv 2304x768", 2304, 768, False, 12), ("fc1 3072x768 + erf-GELU", 3072, 768, True, 12)):
-        torch.manual_seed(0)
-        x16 = torch.randn(M, K, device=dev).half()
-        w16 = (torch.randn(N, K, device=dev) / K ** 0.5).half()
-        bias = torch.randn(N, device=dev)
-        act = F.ACT_GELU if gelu else F.ACT_NONE
-        for _ in range(3):
-            F.linear16(x16, w16, bias, act=act, out16=True, precision=1)
+    reps = max(2, min(5, args.steps))
+
+    def body():
+        with torch.no_grad():
+            for _ in range(reps):
+                run_block(block)
         torch.cuda.synchronize()
-        tm = StreamTimer(dev)
-        tm.start()
-        reps = 20
-        for _ in range(reps):
-            F.linear16(x16, w16, bias, act=act, out16=True, precision=1)
-        ms = tm.stop_ms() / reps
-        flop = 2.0 * M * N * K
-        out.append({"shape": tag, "avg_us": round(ms * 1e3, 1), "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "launches_per_forward": per_fwd})
-        tot_flop += flop * per_fwd
-        tot_ms += ms * per_fwd
-        n += per_fwd
-    ach = tot_flop / (tot_ms * 1e-3) / 1e12
-    return {"name": "gemm16_p8_kernel<_Float16, out16=true> (csrc/gemm16_p8.hip)", "block": "VisionTransformer(ViT-Base/16, h12)",
-            "launches_per_forward": n, "avg_us": round(tot_ms / n * 1e3, 1), "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "shapes": out,
-            "source": "HIP events around 20 back-to-back launches per shape in this process (one launch = one kernel)"}
+
+    rows = mi355attn.kernel_trace(body)
+    if not rows:
+        return None
+    table, by_kernel = [], {}
+    for tag, cnt, tot, mn, mx in rows:
+        rec = {"tag": tag, "launches_per_forward": round(cnt / reps, 2), "avg_us": round(tot / cnt, 1), "min_us": round(mn, 1),
+               "us_per_forward": round(tot / reps, 1)}
+        m = re.search(r"M=(\d+) N=(\d+) K=(\d+)", tag)
+        if m and tag.startswith("gemm"):
+            flop = 2.0 * int(m.group(1)) * int(m.group(2)) * int(m.group(3))
+            rec["TFLOPs"] = round(flop / (tot / cnt * 1e-6) / 1e12, 1)
+            rec["flop"] = flop
+        table.append(rec)
+        k = tag.split(" ")[0]
+        d = by_kernel.setdefault(k, {"us": 0.0, "launches": 0, "flop": 0.0, "all_flop": True})
+        d["us"] += tot / reps
+        d["launches"] += cnt / reps
+        if "flop" in rec:
+            d["flop"] += rec["flop"] * cnt / reps
+        else:
+            d["all_flop"] = False
+    name, d = max(by_kernel.items(), key=lambda kv: kv[1]["us"])
+    out = {"name": name, "block": block["name"], "launches_per_forward": round(d["launches"], 2),
+           "avg_us": round(d["us"] / d["launches"], 1), "us_per_forward": round(d["us"], 1),
+           "share_of_block": round(d["us"] / (ms_block * 1e3), 3),
+           "traced_us_per_forward": round(sum(r["us_per_forward"] for r in table), 1),
+           "source": "in-process HIP-event tally of the block's own launches (mi355_trace_begin / mi355_trace_end), %d forwards" % reps}
+    if d["all_flop"] and d["flop"] > 0:
+        ach = d["flop"] / (d["us"] * 1e-6) / 1e12
+        out.update({"achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)})
+    for r in table:
+        r.pop("flop", None)
+    out["kernels"] = table[:12]
+    return out
 
 
 def make_comm(dist, dev, rank, world):
@@ -498,25 +512,30 @@ def cpu_baseline(blocks, args):
     # The torch thread count that is fastest differs per block on a big dual-socket host (all 128 cores suit the streaming channel
     # attention, 16-32 the transformer blocks: with 128 threads ViT-Base ran 6x slower than with 32), so it is probed PER BLOCK:
     # one pass per candidate count on the block's sample, then median of 3 at the best one.
-    cands = sorted({min(threads, n) for n in (16, 32, 64, cores)})
+    cands = sorted({min(threads, n) for n in (32, 64, 128, 256)})
     per_image, reps, detail, used = 0.0, 3, [], 0
     for b in blocks:
-        ns = min(args.cpu_sample or b.get("cpu_n", 16), b["x"].shape[0])
+        ns = min(args.cpu_sample or b.get("cpu_n", 64), b["x"].shape[0])
         xs = b["x"][:ns].cpu()
+        # thread count: probed on the first 8 images of the sample (one warm-up at the first count, then one pass per candidate), so
+        # that the slow candidates -- 256 threads on the transformer blocks -- cost seconds, not minutes; the timed passes then run
+        # the whole sample at the winner
+        xp = xs[:min(8, ns)]
         torch.set_num_threads(cands[0])
-        b["cpu"](xs)                                           # warm-up
+        b["cpu"](xp)
         best_t, best_n = None, cands[0]
         for nthr in cands:
             torch.set_num_threads(nthr)
             t1 = time.perf_counter()
-            b["cpu"](xs)
+            b["cpu"](xp)
             dt = time.perf_counter() - t1
             if best_t is None or dt < best_t:
                 best_t, best_n = dt, nthr
         torch.set_num_threads(best_n)
         used = max(used, best_n)
-        ts = [best_t]
-        for _ in range(reps - 1):
+        b["cpu"](xs)                                           # warm-up at the sample size
+        ts = []
+        for _ in range(reps):
             t1 = time.perf_counter()
             b["cpu"](xs)
             ts.append(time.perf_counter() - t1)
@@ -527,8 +546,8 @@ def cpu_baseline(blocks, args):
     return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
             "host_cores": cores, "host_threads": threads, "host_cpu": model, "blocks": detail,
             "sample": "oracle (torch-CPU restatement of the reference forward; the reference checkout does not exist on the GPU box) "
-                      "on the first n images of the same batch per block (n listed per block), median of %d after 1 warm-up, torch "
-                      "threads probed per block over {16, 32, 64, all cores} (listed per block; `cores` = the largest count used), host has "
+                      "on the first n images of the same batch per block (n listed per block: 64), median of %d after 1 warm-up, torch "
+                      "threads probed per block over {32, 64, 128, 256} on the first 8 images (capped at the host's hardware threads; listed per block; `cores` = the largest count used), host has "
                       "%d cores / %d hardware threads"
                       % (reps, cores, threads)}
 

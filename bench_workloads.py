@@ -24,7 +24,7 @@ def workload_c3(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 197, 768, device=dev)
     sd = _sd(m)
-    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=16,
+    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=64,
                    cpu=lambda xs: O.vit_attention_forward(xs, sd, 12))]
     return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, dtype="f16")
 
@@ -44,7 +44,7 @@ def workload_c4(B, dev):
         m = _seeded(lambda: CSWinBlock(*args, **kw))
         torch.manual_seed(4321)
         x = torch.randn(B, *shp, device=dev)
-        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=16,
+        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=64,
                            cpu_note="ATen-sequence restatement (strided window views, bmm, softmax, grouped conv2d, fused layer_norm / linear / "
                                     "gelu): the operator sequence of cswin.py:101-127,176-197; within 0.9-1.4x of the real reference on the "
                                     "build container's CPU"))
@@ -53,9 +53,9 @@ def workload_c4(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 196, 384, device=dev)
     sdb, sda = _sd(xb), _sd(xa)
-    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B, cpu_n=16,
+    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B, cpu_n=64,
                        cpu=lambda xs: O.xca_block_forward(xs, sdb, 8, 14, 14)))
-    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B, cpu_n=16,
+    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B, cpu_n=64,
                        cpu=lambda xs: O.xca_forward(xs, sda, 8)))
     return dict(name="CSWin-T blocks s1-s4 + XCiT-S XCABlock/XCA fwd, B=%d (BASELINE configs[3])" % B, blocks=blocks,
                 dtype="f16")
@@ -70,7 +70,7 @@ def workload_c5(B, dev):
 
     # gather=True: bench.py all-gathers this block's logits (mi355attn.dist.gather_batch: one RCCL all-gather over xGMI, 1 MB per rank)
     blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
-                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12), cpu_n=8, gather=True)]
+                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12), cpu_n=64, gather=True)]
     return dict(name="ViT-Base full fwd, %d images per GPU, logits all-gathered (BASELINE configs[4])" % B, blocks=blocks,
                 gather=True, dtype="f16")
 
@@ -81,7 +81,7 @@ def workload_mixer(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 196, 512, device=dev)
     sd = _sd(m)
-    blocks = [dict(name="MixerLayer(512,196)", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B, cpu_n=16,
+    blocks = [dict(name="MixerLayer(512,196)", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B, cpu_n=64,
                    cpu=lambda xs: O.mixer_layer_forward(xs, sd))]
     return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, dtype="f16")
 
@@ -102,7 +102,7 @@ def workload_da(B, dev):
         # DoubleAttention is a mixed block -- graded on the HBM roofline (algorithmic bytes = read x + write y), FLOP rate
         # reported next to it (alt_*)
         blocks.append(dict(name="DoubleAttention(%d,%d,%d)@%dx%d" % (C, cm, cn, hw, hw), module=m.to(dev), x=x, bound="hbm",
-                           work=2.0 * C * hw * hw * 4 * B, alt_work=flop * B, cpu_n=16,
+                           work=2.0 * C * hw * hw * 4 * B, alt_work=flop * B, cpu_n=64,
                            cpu=(lambda sd_: (lambda xs: O.double_attention_forward(xs, *[sd_[k] for k in keys])))(sd)))
     return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, dtype="f16")
 
@@ -113,7 +113,7 @@ def _full_model(ctor, title, flop_per_image, cpu_fn, B, dev):
     x = torch.randn(B, 3, 224, 224, device=dev)
     sd = _sd(m)
 
-    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd), cpu_n=8,
+    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd), cpu_n=64,
                    gather=True)]
     return dict(name="%s full fwd, %d images per GPU, logits all-gathered" % (title, B), blocks=blocks, gather=True, dtype="f16")
 

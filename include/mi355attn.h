@@ -105,6 +105,14 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
 int         mi355_set_option(const char* key, long value);          /* current device */
 int         mi355_set_default_option(const char* key, long value);  /* process default: devices without an own setting */
 long        mi355_get_option(const char* key);                      /* what a launch on the current device would read */
+/* In-process kernel tally: between mi355_trace_begin() and mi355_trace_end() every launch of the instrumented kernels (the GEMM engine,
+ * the attention cores, LayerNorm / cast / im2col passes, the XCiT kernels) on the calling thread's current device is bracketed by a
+ * pair of HIP events on its launch stream.  mi355_trace_end waits for those launches and writes one line per kernel tag,
+ *   "count\ttotal_us\tmin_us\tmax_us\ttag\n"   (largest total first; the tag = kernel name + the shape parameters that tell its
+ * launches apart), NUL-terminated, truncated to report_bytes; it returns the size of the full report.  One trace at a time per
+ * process; launches under hipGraph stream capture are not recorded.  What bench.py fills roofline.dominant_kernel from. */
+int         mi355_trace_begin(void);
+long        mi355_trace_end(char* report, size_t report_bytes);
 /* Drop what the library remembers about workspaces inside [ws, ws + ws_bytes) ("ws_persistent"): call before freeing or
  * repurposing such a buffer.  The next call that uses the memory zeroes its exchange area again. */
 int         mi355_workspace_forget(const void* ws, size_t ws_bytes);

@@ -3,7 +3,11 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <unordered_map>
+#include <map>
+#include <string>
+#include <vector>
 
 namespace mi355 {
 static thread_local char g_err[512] = "";
@@ -212,6 +216,80 @@ int func_dynamic_lds(const void* fn, int bytes) {
     have = bytes;
     return MI355_OK;
 }
+// ---- in-process kernel tally (common.h TraceScope) --------------------------------------------------------------------------------
+namespace {
+struct TraceRec { std::string tag; hipEvent_t a, b; };
+std::atomic<int> g_trace_dev{-1};             // device ordinal with an open trace, -1 = none
+std::mutex g_trace_mu;
+std::vector<TraceRec> g_trace;
+}  // namespace
+bool trace_on() { return g_trace_dev.load(std::memory_order_relaxed) >= 0; }
+TraceScope::TraceScope(hipStream_t st_, const char* fmt, ...) : idx(-1), st(st_) {
+    const int dev = g_trace_dev.load(std::memory_order_relaxed);
+    if (dev < 0 || dev != cur_dev() || stream_is_capturing(st_)) return;
+    char tag[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tag, sizeof(tag), fmt, ap);
+    va_end(ap);
+    TraceRec r{tag, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess || hipEventRecord(r.a, st_) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    idx = (int)g_trace.size();
+    g_trace.push_back(r);
+}
+TraceScope::~TraceScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (idx < (int)g_trace.size()) (void)hipEventRecord(g_trace[idx].b, st);
+}
+int trace_begin() {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    for (auto& r : g_trace) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_trace.clear();
+    g_trace_dev.store(cur_dev(), std::memory_order_relaxed);
+    return MI355_OK;
+}
+// closes the trace, waits for the recorded launches and writes one line per tag: "count\ttotal_us\tmin_us\tmax_us\ttag\n", largest
+// total first; returns the number of bytes the full report needs (like snprintf)
+long trace_end(char* buf, size_t n) {
+    g_trace_dev.store(-1, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    struct Acc { long cnt; double tot, mn, mx; };
+    std::map<std::string, Acc> acc;
+    for (auto& r : g_trace) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto it = acc.find(r.tag);
+            const double us = ms * 1e3;
+            if (it == acc.end()) acc[r.tag] = Acc{1, us, us, us};
+            else { it->second.cnt++; it->second.tot += us; if (us < it->second.mn) it->second.mn = us; if (us > it->second.mx) it->second.mx = us; }
+        } else {
+            (void)hipGetLastError();
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_trace.clear();
+    std::vector<std::pair<std::string, Acc>> rows(acc.begin(), acc.end());
+    std::sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.second.tot > y.second.tot; });
+    std::string out;
+    char line[256];
+    for (auto& kv : rows) {
+        snprintf(line, sizeof(line), "%ld\t%.1f\t%.1f\t%.1f\t%s\n", kv.second.cnt, kv.second.tot, kv.second.mn, kv.second.mx, kv.first.c_str());
+        out += line;
+    }
+    if (buf && n) {
+        const size_t m = out.size() < n - 1 ? out.size() : n - 1;
+        std::memcpy(buf, out.data(), m);
+        buf[m] = 0;
+    }
+    return (long)out.size();
+}
+
 int resident_slots(int per_cu) {
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
@@ -278,6 +356,9 @@ int mi355_workspace_forget(const void* ws, size_t ws_bytes) {
 }
 
 long mi355_get_option(const char* key) { return mi355::opt_get(key); }
+
+int mi355_trace_begin(void) { return mi355::trace_begin(); }
+long mi355_trace_end(char* report, size_t report_bytes) { return mi355::trace_end(report, report_bytes); }
 
 int mi355_sync_status(void) { return mi355::sync_pending("mi355_sync_status"); }
 int mi355_range_status(void) { return mi355::range_pending("mi355_range_status"); }

@@ -435,6 +435,7 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
     }
     if (IO16 && precision == MI355_PREC_STRICT)
         return mi355::fail(MI355_EINVAL, "16-bit activation I/O needs precision 1 (fp16) or 2 (bf16)");
+    MI355_TRACE(st, "win_attn_kernel<d=%d%s%s> B=%d windows=%d heads=%d tokens=%d", D, LEPE ? ",lepe" : "", IO16 ? ",io16" : "", B, a.nwin, a.heads, a.T);
 #define GO(P, KT_, NW_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_><<<grid, NW_ * 64, 0, st>>>(pr)
 #define GO_OCC(P, KT_, NW_, OCC_) win_attn_kernel<P, D, KT_, LEPE, (IO16 && P != 0), NW_, ((IO16 && P != 0 && D == 32) ? OCC_ : 1)><<<grid, NW_ * 64, 0, st>>>(pr)
 #define GO_FULL(P, KT_, NW_, OCC_, TF_) \

@@ -49,6 +49,22 @@ int   range_pending(const char* who);  // MI355_OK or MI355_ERANGE (reported onc
 unsigned  spin_limit();
 int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
 int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
+// ---- in-process kernel tally (api.hip; mi355_trace_begin / mi355_trace_end) ---------------------------------------------------
+// While a trace is open on the calling thread's device, a TraceScope brackets ONE kernel launch with a pair of HIP events on the
+// launch stream and files the interval under a tag (kernel name + the shape parameters that tell its launches apart).  Closed: one
+// relaxed atomic load per launch.  Never active under hipGraph stream capture.
+bool  trace_on();
+int   trace_begin();
+long  trace_end(char* buf, size_t n);
+struct TraceScope {
+    int idx;
+    hipStream_t st;
+    TraceScope(hipStream_t st_, const char* fmt, ...);
+    ~TraceScope();
+    TraceScope(const TraceScope&) = delete;
+    TraceScope& operator=(const TraceScope&) = delete;
+};
+#define MI355_TRACE(st, ...) mi355::TraceScope trace_scope_(st, __VA_ARGS__)
 int   func_dynamic_lds(const void* fn, int bytes);   // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): api.hip
 long  opt_zoo_single();
 long  opt_stem_direct();

@@ -322,6 +322,7 @@ template <int BMODE, int AMODE>
 int launch(const GemmArgs& g, int batch, int precision, hipStream_t st) {
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     dim3 grid(tiles, batch);
+    MI355_TRACE(st, "gemm_kernel<prec %d,b%d,a%d> batch=%d M=%d N=%d K=%d", precision, BMODE, AMODE, batch, g.M, g.N, g.K);
     switch (precision) {
         case MI355_PREC_STRICT: gemm_kernel<0, BMODE, AMODE><<<grid, 256, 0, st>>>(g); break;
         case MI355_PREC_FP16:   gemm_kernel<1, BMODE, AMODE><<<grid, 256, 0, st>>>(g); break;
@@ -451,11 +452,17 @@ int mi355_patch_embed_ws_fwd(const float* img, const float* Wp, const float* bp,
     float* table = reinterpret_cast<float*>(p);
     int rc = mi355_cast16_fwd(Wp, w16, (size_t)E * K, precision, stream);
     if (rc) return rc;
-    patch_table_kernel<<<cdiv((long)(P + 1) * E, 256), 256, 0, st>>>(cls, pos, bp, table, P, E);
+    {
+        MI355_TRACE(st, "patch_table_kernel rows=%d E=%d", P + 1, E);
+        patch_table_kernel<<<cdiv((long)(P + 1) * E, 256), 256, 0, st>>>(cls, pos, bp, table, P, E);
+    }
     const int blocks = B * (H / ps) * Cin;
     const size_t shm = (size_t)ps * W * 4;
-    if (precision == MI355_PREC_FP16) im2col16_kernel<_Float16><<<blocks, 256, shm, st>>>(img, static_cast<_Float16*>(a16), Cin, H, W, ps, P + 1, K);
-    else                              im2col16_kernel<__bf16><<<blocks, 256, shm, st>>>(img, static_cast<__bf16*>(a16), Cin, H, W, ps, P + 1, K);
+    {
+        MI355_TRACE(st, "im2col16_kernel B=%d %dx%d ps=%d", B, H, W, ps);
+        if (precision == MI355_PREC_FP16) im2col16_kernel<_Float16><<<blocks, 256, shm, st>>>(img, static_cast<_Float16*>(a16), Cin, H, W, ps, P + 1, K);
+        else                              im2col16_kernel<__bf16><<<blocks, 256, shm, st>>>(img, static_cast<__bf16*>(a16), Cin, H, W, ps, P + 1, K);
+    }
     g16::G16Args g{};
     g.A = a16; g.B = w16; g.C = tokens; g.bias = bp; g.resid = table; g.resid_period = P + 1;
     g.M = B * (P + 1); g.N = E; g.K = K; g.lda = K; g.ldb = K; g.ldc = E; g.act = MI355_ACT_NONE;

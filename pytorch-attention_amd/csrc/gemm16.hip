@@ -414,6 +414,7 @@ int mi355_cast16_fwd(const float* src, void* dst16, size_t n, int precision, mi3
     const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 + 1 : 4096);
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned* ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
+    MI355_TRACE(st, "cast16_kernel n=%zu", n);
     if (precision == MI355_PREC_FP16) cast16_kernel<_Float16><<<grid, 256, 0, st>>>(src, static_cast<_Float16*>(dst16), n8, (long)n, ovf);
     else                              cast16_kernel<__bf16><<<grid, 256, 0, st>>>(src, static_cast<__bf16*>(dst16), n8, (long)n, ovf);
     MI355_LAUNCH_CHECK();
@@ -479,6 +480,7 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         if (workers < 1) workers = 1;
         if (workers > tiles_m) workers = tiles_m;
         const int grid = tiles_n * workers;
+        MI355_TRACE(st, "gemm16_ws_kernel<%s> M=%d N=%d K=%d", out16 ? "out16" : "out32", M, N, K);
 #define WS(T_, O_, BN_, KK_) gemm16_ws_kernel<T_, O_, BN_, KK_><<<grid, 512, 0, st>>>(g, workers)
 #define WS_BY_SHAPE(T_, O_)                                                   \
         do {                                                                  \
@@ -535,6 +537,7 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         if (variant == 7 && (long)cdiv(M, 128) * cdiv(N, 256) < ncu) variant = 1;
     }
     else if (variant == 8) variant = 0;     // 8 = plain 128x128 without priority hints (tuning experiments)
+    MI355_TRACE(st, "gemm16_kernel<variant %ld,%s> M=%d N=%d K=%d%s", variant, out16 ? "out16" : "out32", M, N, K, g.act == MI355_ACT_GELU ? " gelu" : "");
 #define LAUNCH(T_, O_, BM_, BN_, WM_, WN_, P_, S_)                                                         \
     gemm16_kernel<T_, O_, BM_, BN_, WM_, WN_, P_, S_><<<cdiv(M, BM_) * cdiv(N, BN_), WM_ * WN_ * 64, 0, st>>>(g)
 #define BY_VARIANT(T_, O_)                                                 \
@@ -577,6 +580,7 @@ int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, c
     g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = N; g.act = MI355_ACT_NONE; g.tr_rows = rows_per_image;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool wide = N > 128 && ((N & 255) == 0 || (N & 127) != 0);    // N = 384: three exact 128-wide tiles instead of 256 + half-empty 256
+    MI355_TRACE(st, "gemm16_kernel<transposed out> M=%d N=%d K=%d", M, N, K);
 #define TRL(T_, BN_, WN_) gemm16_kernel<T_, false, 128, BN_, 2, WN_, true, 1, true><<<cdiv(M, 128) * cdiv(N, BN_), 2 * WN_ * 64, 0, st>>>(g)
     if (precision == MI355_PREC_FP16) { if (wide) TRL(_Float16, 256, 4); else TRL(_Float16, 128, 2); }
     else                              { if (wide) TRL(__bf16, 256, 4); else TRL(__bf16, 128, 2); }

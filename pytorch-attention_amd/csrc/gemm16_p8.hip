@@ -514,6 +514,8 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
         static std::atomic<unsigned> launch_tag{0x5EED0000u};
         do pl.tag = launch_tag.fetch_add(1u, std::memory_order_relaxed) + 1u; while (pl.tag == 0u);
     }
+    MI355_TRACE(st, "gemm16_p8_kernel<%s,%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
+                g.rowtau ? ",fold" : "", g.M, g.N, g.K, g.act == MI355_ACT_GELU ? " gelu" : "");
     if (g.rowtau) {                                            // LayerNorm fold, consumer side
         if (!out16 || !g.colsum || g.gamma || !aligned16(g.colsum) || (reinterpret_cast<uintptr_t>(g.rowtau) & 7u)) return MI355_EUNSUPPORTED;
         if (precision == MI355_PREC_FP16) gemm16_p8_kernel<_Float16, true, true><<<grid, 512, 0, st>>>(g, pl);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
 template <typename OT>
 int launch_ln(const float* x, const float* weight, const float* bias, OT* y, int rows, int cols, float eps, hipStream_t st) {
     unsigned* ovf = std::is_same<OT, _Float16>::value ? mi355::range_word(st) : nullptr;
+    MI355_TRACE(st, "layernorm_kernel<%s> rows=%d cols=%d", std::is_same<OT, float>::value ? "out32" : "out16", rows, cols);
     const bool vec = (cols % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) && aligned16(bias);
 #define LN(LPR_, NV_)                                                                                                \
     do {                                                                                                             \

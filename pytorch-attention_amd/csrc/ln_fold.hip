@@ -162,6 +162,7 @@ int mi355_ln_center16_fwd(const float* x, void* a16, float* rowtau, float* cvec,
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_ln_center16_fwd: needs cols %% 4 == 0, cols <= 2048, 16-byte aligned rows (cols=%d)", cols);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = (int)(((long)rows + 3) / 4 < 8192 ? ((long)rows + 3) / 4 : 8192);
+    MI355_TRACE(st, "ln_center16_kernel rows=%d cols=%d", rows, cols);
 #define LC(T_, NV_) ln_center16_kernel<T_, NV_><<<grid, 256, 0, st>>>(x, static_cast<T_*>(a16), rowtau, cvec, (long)rows, cols, eps)
 #define LC_BY_NV(T_) do { if (cols <= 256) LC(T_, 1); else if (cols <= 512) LC(T_, 2); else if (cols <= 1024) LC(T_, 4); else LC(T_, 8); } while (0)
     if (precision == MI355_PREC_FP16) LC_BY_NV(_Float16);
@@ -180,6 +181,7 @@ int mi355_ln_finalize_fwd(const float* stats, const float* x, void* a16, float* 
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_ln_finalize_fwd: needs cols %% 32 == 0 and aligned buffers (cols=%d)", cols);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = (rows + 31) / 32;                          // 4 waves x 8 rows per workgroup
+    MI355_TRACE(st, "ln_finalize_kernel rows=%d cols=%d", rows, cols);
     if (precision == MI355_PREC_FP16)
         ln_finalize_kernel<_Float16><<<grid, 256, 0, st>>>(stats, x, static_cast<_Float16*>(a16), cvec, rowtau, rows, cols, eps, tol, slow_rows);
     else

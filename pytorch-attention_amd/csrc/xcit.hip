@@ -437,6 +437,7 @@ int mi355_xca16_fwd(const void* qkv, int qkv_is16, const float* temperature, voi
     MI355_CHECK_ARG(aligned16(qkv) && aligned16(out16));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = B * heads;
+    MI355_TRACE(st, "xca_kernel<d=%d,out16%s> B=%d N=%d heads=%d", d, qkv_is16 ? ",in16" : "", B, N, heads);
 #define XCA16(D_)                                                                                                              \
     do {                                                                                                                       \
         if (qkv_is16) {                                                                                                        \
@@ -468,6 +469,7 @@ static int lpi_launch(const float* x, const float* w1, const float* b1, const fl
     if (H * W > 32 * LPI_TMAX) return mi355::fail(MI355_EUNSUPPORTED, "mi355_lpi_fwd: %dx%d token grid exceeds the LDS tile (<= 256 tokens)", H, W);
     const size_t smem = (size_t)(H + 2) * (W + 2) * LPI_CG * sizeof(float);
     const int groups = cdiv(C, LPI_CG);
+    MI355_TRACE(st, "lpi_kernel%s B=%d %dx%d C=%d", stats ? "<ln>" : "", B, H, W, C);
     lpi_kernel<<<B * groups, 256, smem, st>>>(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, H, W, C, groups,
                                               stats, ln_w, ln_b);
     MI355_LAUNCH_CHECK();
@@ -495,7 +497,10 @@ int mi355_ln_lpi_fwd(const float* x, const float* ln_w, const float* ln_b, float
     float* stats = static_cast<float*>(ws);
     const long rows = (long)B * H * W;
     const int grid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
-    ln_stats_kernel<<<grid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
+    {
+        MI355_TRACE(st, "ln_stats_kernel rows=%ld cols=%d", rows, C);
+        ln_stats_kernel<<<grid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
+    }
     return lpi_launch(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, B, H, W, C, stats, ln_w, ln_b, st);
 }
 

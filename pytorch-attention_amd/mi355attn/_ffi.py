@@ -37,6 +37,8 @@ SIGNATURES = {
     "mi355_set_default_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
     "mi355_get_option": (ctypes.c_long, [ctypes.c_char_p]),
     "mi355_workspace_forget": (c_int, [c_vp, ctypes.c_size_t]),
+    "mi355_trace_begin": (c_int, []),
+    "mi355_trace_end": (ctypes.c_long, [ctypes.c_char_p, c_size]),
     "mi355_sync_status": (c_int, []),
     "mi355_range_status": (c_int, []),
     "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
@@ -285,6 +287,22 @@ def set_option(key, value):
 
 def get_option(key):
     return lib().mi355_get_option(key.encode())
+
+
+def kernel_trace(fn):
+    """In-process kernel tally (include/mi355attn.h mi355_trace_begin / mi355_trace_end): run fn() with every instrumented launch
+    timed by HIP events on its launch stream; returns [(tag, count, total_us, min_us, max_us)], largest total first."""
+    check(lib().mi355_trace_begin(), "mi355_trace_begin")
+    buf = ctypes.create_string_buffer(1 << 16)
+    try:
+        fn()
+    finally:
+        lib().mi355_trace_end(buf, len(buf))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        cnt, tot, mn, mx, tag = line.split("\t", 4)
+        rows.append((tag, int(cnt), float(tot), float(mn), float(mx)))
+    return rows
 
 
 class StreamTimer:
