@@ -494,6 +494,24 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
+    if (variant == 0 && out16 && K >= 256 && K <= 512 && !g.gamma && !g.resid && mi355::opt_gemm_pa()) {
+        // 16-bit outputs with a SHORT reduction (4 .. 8 K-tiles: CSWin stage 3 / 4, XCiT, the Mixer's token mixing): on the persistent
+        // 256 x 256 kernel the epilogue of such a tile (bias / GELU / convert / store, nothing to overlap it with) is as long as its
+        // main loop; the two-accumulator kernel packs two or three convert pieces into every barrier interval of the next tile's
+        // main loop.  Round 4, same box, same process: CSWin s3 qkv 40 -> 32 us, fc1 74 -> 60, XCiT qkv 70 -> 54, fc1 106 -> 89,
+        // Mixer fc1 167 -> 136 (profiles/r04_gemm_short_k.md); bit-identical results.  K >= 576 stays on the 256 x 256 kernel (its
+        // main loop is the faster one once the epilogue is a small share: profiles/r03_gemm_pa.md).
+        const int ncu = mi355::resident_slots(1);
+        const long tiles = (N & 255) ? (long)(M / 256) * (N / 128) : (long)cdiv(M, 128) * (N / 256);
+        if (2 * tiles >= ncu) {
+            const int rc = mi355::gemm16_pa(g, out16, precision, st);
+            if (rc == MI355_OK) {
+                MI355_LAUNCH_CHECK();
+                return MI355_OK;
+            }
+            if (rc != MI355_EUNSUPPORTED) return rc;
+        }
+    }
     if (variant == 0 && !out16 && (g.resid || N <= 768) && mi355::opt_gemm_pa()) {
         // fp32 (+ residual) outputs: the two-accumulator persistent kernel (gemm16_pa.hip) hides the residual / store round trips of
         // tile i under the main loop of tile i + 1 (ViT-Base proj 0.130 -> 0.106 ms, fc2 0.266 -> 0.259; profiles/r03_gemm_pa.md).

@@ -50,6 +50,20 @@ typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 
 template <int N>
 struct IC { static constexpr int value = N; };
+// f(IC<E>{}) for E = B .. N-1, unrolled at compile time
+template <int B, int N>
+struct KtUnroll {
+    template <class F>
+    static __device__ __forceinline__ void run(F& f) {
+        f(IC<B>{});
+        KtUnroll<B + 1, N>::run(f);
+    }
+};
+template <int N>
+struct KtUnroll<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F&) {}
+};
 
 struct PaPlan {
     int tiles_n;
@@ -108,8 +122,13 @@ __device__ __forceinline__ void pa_wait4(f4& a, f4& b, f4& c, f4& d) {
 // the operand order of the MFMA (the lane's "four consecutive" axis must stay the output-column axis), the accumulator index order
 // (cur[row tile][column tile]) and which wave index belongs to which output axis in the epilogue addresses.  Same K order per output:
 // bit-identical results.
-template <typename T, bool OUT16, bool GELU, int ABL = 0, bool LNC = false, bool SWAP = false>
+// CPI (16-bit outputs): accumulator tiles converted per barrier interval.  The epilogue of a tile is 16 convert pieces (row tile i,
+// column tile j) + 4 row-line flushes; at one piece per interval it needs nine K-tiles of the next tile's main loop (K >= 576), at
+// two five (K >= 320), at three four (K = 256): short reductions -- CSWin stage 3 / 4, XCiT, the Mixer's token mixing -- get the
+// overlapped epilogue as well (round 4).
+template <typename T, bool OUT16, bool GELU, int ABL = 0, bool LNC = false, bool SWAP = false, int CPI = 1>
 __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const PaPlan pl) {
+    static_assert(CPI == 1 || OUT16, "piece packing exists for the 16-bit epilogue only");
     static_assert(!(LNC && OUT16), "the emitting epilogue exists for fp32 outputs only");
     static_assert(!(LNC && SWAP), "the emitting epilogue is built for the 128 x 256 orientation");
     using v8 = typename Vec8<T>::t;
@@ -369,13 +388,36 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // vector-memory operations an epilogue piece issues in its phase-0 interval
     constexpr int FST = LNC ? 6 : 2;                 // stores of one F step: Y (+ operand + statistics)
     constexpr int LLD = LNC ? 4 : 2;                 // loads of one L step: residual (+ c)
-    auto e0_of = [](int E) constexpr {
+    // 16-bit epilogue: interval v = 2 E (phase 0 of K-tile E) / 2 E + 1 (phase 1) converts pieces (v - 1) * CPI .. v * CPI - 1 of the 16
+    // (piece c = row tile c / 4, column tile c % 4); a row tile's lines leave right behind its last piece (c % 4 == 3: two stores)
+    auto nflush = [](int v) constexpr {
+        int n = 0;
+        for (int c = (v - 1) * CPI; v >= 1 && c < v * CPI && c < 16; ++c) n += (c & 3) == 3;
+        return n;
+    };
+    auto e0_of = [nflush](int E) constexpr {
         if (E < 0) return 0;
-        if (OUT16) return E == 0 ? 4 : ((E >= 2 && (E & 1) == 0) ? 2 : 0);
+        if (OUT16) return (E == 0 ? 4 : 0) + 2 * nflush(2 * E);
         return (E >= 2 ? FST : 0) + ((E == 0 || E == 5) ? 2 : 0);
     };
     // ... and in its phase-1 interval (fp32: the residual loads of unit E)
-    auto e1_of = [](int E) constexpr { return (!OUT16 && E >= 0 && E < 8) ? LLD : 0; };
+    auto e1_of = [nflush](int E) constexpr {
+        if (E < 0) return 0;
+        if (OUT16) return 2 * nflush(2 * E + 1);
+        return E < 8 ? LLD : 0;
+    };
+    // the pieces of interval v (16-bit epilogue)
+    auto epi_pieces16 = [&](auto VC, f4 (&prv)[4][4]) {
+        constexpr int V = decltype(VC)::value;
+#pragma unroll
+        for (int k = 0; k < CPI; ++k) {
+            const int c = (V - 1) * CPI + k;                 // compile-time after unrolling
+            if (V >= 1 && c < 16) {
+                epi_c16(prv[c >> 2][c & 3], bias_of(c & 3), c & 3);
+                if ((c & 3) == 3) epi_f16(c >> 2);
+            }
+        }
+    };
     // phase-0 part of piece E of the draining accumulator set.  A residual load is behind the 4 B DMAs of its own K-tile and the 2 A
     // DMAs of this one (or behind nothing: at the end of the stream the phases wait with a smaller count instead of issuing)
     auto epi_even = [&](auto EC, f4 (&prv)[4][4]) {
@@ -383,8 +425,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         if constexpr (E < 0) {
         } else if constexpr (OUT16) {
             if constexpr (E == 0) epi_load16();
-            if constexpr (E >= 1) epi_c16(prv[(E - 1) >> 1][((E - 1) & 1) * 2 + 1], bias_of(((E - 1) & 1) * 2 + 1), ((E - 1) & 1) * 2 + 1);
-            if constexpr (E >= 2 && (E & 1) == 0) epi_f16(E / 2 - 1);
+            epi_pieces16(IC<2 * E>{}, prv);
         } else {
             // unit E-2 leaves: its residual was loaded at the end of K-tile E-2; behind it 2 A + e0(E-1) + 4 B + e1(E-1) of K-tile E-1
             // and 2 A DMAs of this K-tile (at the end of the stream the phases wait vmcnt(0) instead of issuing)
@@ -399,10 +440,12 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // phase-1 part: a bias load of phase 0 is behind at most the four B DMAs of this K-tile (and, fp32, the two residual loads)
     auto epi_odd = [&](auto EC, f4 (&prv)[4][4]) {
         constexpr int E = decltype(EC)::value;
+        if constexpr (OUT16) {
+            if constexpr (E == 0) pa_wait4<4>(eb0, eb1, eb2, eb3);
+            if constexpr (E >= 0) epi_pieces16(IC<2 * E + 1>{}, prv);
+        }
         if constexpr (E >= 0 && E < 8) {
             if constexpr (OUT16) {
-                if constexpr (E == 0) pa_wait4<4>(eb0, eb1, eb2, eb3);
-                epi_c16(prv[E >> 1][(E & 1) * 2], bias_of((E & 1) * 2), (E & 1) * 2);
             } else {
                 if constexpr (E == 0 || E == 5) pa_wait2<4>(eb0, eb1);
                 if constexpr (E >= 1) epi_c32(prv[(E - 1) & 3][((E - 1) >> 2) * 2], prv[(E - 1) & 3][((E - 1) >> 2) * 2 + 1]);
@@ -482,25 +525,15 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         buf = buf == 2 ? 0 : buf + 1;
         nbuf = nbuf == 2 ? 0 : nbuf + 1;
     };
-    // ---- one output tile: K-tiles 0 .. 8 carry the pieces of the previous tile's epilogue -------------------------------------------
+    // ---- one output tile: K-tiles 0 .. NE-1 carry the pieces of the previous tile's epilogue ------------------------------------------
+    constexpr int NE = OUT16 ? ((16 + CPI - 1) / CPI) / 2 + 1 : 10;
     int ent = 0;
     auto tile = [&](f4 (&cur)[4][4], f4 (&prv)[4][4]) __attribute__((always_inline)) {
         int kt;
         if (ent > 0) {
-            ktile(IC<0>{}, IC<1>{}, cur, prv);
-            ktile(IC<1>{}, IC<0>{}, cur, prv);
-            ktile(IC<2>{}, IC<0>{}, cur, prv);
-            ktile(IC<3>{}, IC<0>{}, cur, prv);
-            ktile(IC<4>{}, IC<0>{}, cur, prv);
-            ktile(IC<5>{}, IC<0>{}, cur, prv);
-            ktile(IC<6>{}, IC<0>{}, cur, prv);
-            ktile(IC<7>{}, IC<0>{}, cur, prv);
-            ktile(IC<8>{}, IC<0>{}, cur, prv);
-            kt = 9;
-            if constexpr (!OUT16) {
-                ktile(IC<9>{}, IC<0>{}, cur, prv);
-                kt = 10;
-            }
+            auto one = [&](auto EC) __attribute__((always_inline)) { ktile(EC, IC<(decltype(EC)::value == 0)>{}, cur, prv); };
+            KtUnroll<0, NE>::run(one);                       // K-tiles 0 .. NE-1 carry the pieces of the previous tile's epilogue
+            kt = NE;
         } else {
             ktile(IC<-1>{}, IC<1>{}, cur, prv);
             kt = 1;
@@ -577,7 +610,8 @@ namespace mi355 {
 // Launch the two-accumulator persistent kernel when the shape suits it; MI355_EUNSUPPORTED (nothing touched) otherwise.
 int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl) {
     const int nk = g.K / g16::BK;
-    if ((g.K % g16::BK) || nk < (out16 ? 9 : 10) || g.gamma || g.resid_period || (out16 && g.resid)) return MI355_EUNSUPPORTED;
+    if ((g.K % g16::BK) || nk < (out16 ? 4 : 10) || g.gamma || g.resid_period || (out16 && g.resid)) return MI355_EUNSUPPORTED;
+    const int cpi = !out16 ? 1 : (nk >= 9 ? 1 : (nk >= 5 ? 2 : 3));       // accumulator tiles converted per barrier interval (16-bit epilogue)
     if ((long)g.M * g.ldc * 4 >= (1L << 31) || (long)g.M * g.lda * 2 >= (1L << 32) || (long)g.N * g.ldb * 2 >= (1L << 32))
         return MI355_EUNSUPPORTED;                                                                           // 32-bit buffer / lane offsets
     // orientation: 128 (M) x 256 (N) tiles when N is a multiple of 256; 256 (M) x 128 (N) tiles (SWAP) for the other multiples of
@@ -593,8 +627,8 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
     pl.full = (int)(ntiles / grid);
     pl.left = (int)(ntiles - (long)pl.full * grid);
     const bool gelu = g.act == MI355_ACT_GELU;
-    MI355_TRACE(st, "gemm16_pa_kernel<%s,%s%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
-                g.lnc_a ? ",emit" : "", swap ? ",256x128" : "", g.M, g.N, g.K, gelu ? " gelu" : "");
+    MI355_TRACE(st, "gemm16_pa_kernel<%s,%s%s%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
+                g.lnc_a ? ",emit" : "", swap ? ",256x128" : "", cpi == 1 ? "" : (cpi == 2 ? ",2 pieces" : ",3 pieces"), g.M, g.N, g.K, gelu ? " gelu" : "");
     if (g.lnc_a) {                                              // emitting variant (LayerNorm fold, producer side)
         if (out16 || !g.lnc_stats || !g.lnc_c || abl || (g.N & 31) || g.lnc_lda != g.ldc) return MI355_EUNSUPPORTED;
         if ((long)g.M * g.lnc_lda * 2 >= (1L << 31) || (long)(g.N / 32) * g.M * 8 >= (1L << 31)) return MI355_EUNSUPPORTED;
@@ -623,10 +657,20 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
 #else
     if (abl) return MI355_EUNSUPPORTED;
 #endif
+#define PA_LAUNCH_C(T_, O_, G_, C_)                                                    \
+    do {                                                                               \
+        if (swap) gemm16_pa_kernel<T_, O_, G_, 0, false, true, C_><<<grid, 512, 0, st>>>(g, pl);   \
+        else      gemm16_pa_kernel<T_, O_, G_, 0, false, false, C_><<<grid, 512, 0, st>>>(g, pl);  \
+    } while (0)
 #define PA_LAUNCH(T_, O_, G_)                                                          \
     do {                                                                               \
-        if (swap) gemm16_pa_kernel<T_, O_, G_, 0, false, true><<<grid, 512, 0, st>>>(g, pl);   \
-        else      gemm16_pa_kernel<T_, O_, G_><<<grid, 512, 0, st>>>(g, pl);           \
+        if constexpr (O_) {                                                            \
+            if (cpi == 1) PA_LAUNCH_C(T_, O_, G_, 1);                                  \
+            else if (cpi == 2) PA_LAUNCH_C(T_, O_, G_, 2);                             \
+            else PA_LAUNCH_C(T_, O_, G_, 3);                                           \
+        } else {                                                                       \
+            PA_LAUNCH_C(T_, O_, G_, 1);                                                \
+        }                                                                              \
     } while (0)
 #define PA_BY_EPI(T_)                                                    \
     do {                                                                 \
@@ -637,6 +681,7 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
     else PA_BY_EPI(__bf16);
 #undef PA_BY_EPI
 #undef PA_LAUNCH
+#undef PA_LAUNCH_C
     return MI355_OK;
 }
 

@@ -25,7 +25,8 @@ if os.environ.get("GEMM_SET") == "narrow":
               ("s4_fc1", 2048, 512, True, False, True, 12544), ("s4_fc2", 512, 2048, False, True, False, 12544),
               ("x_qkv", 1152, 384, True, False, False, 50176), ("x_proj", 384, 384, False, True, False, 50176),
               ("x_fc1", 1536, 384, True, False, True, 50176), ("x_fc2", 384, 1536, False, True, False, 50176),
-              ("m_fc1", 2048, 512, True, False, True, 50176), ("m_fc2", 512, 2048, False, True, False, 50176)]
+              ("m_fc1", 2048, 512, True, False, True, 50176), ("m_fc2", 512, 2048, False, True, False, 50176),
+              ("m_tok1", 256, 256, True, False, True, 131072)]
 if os.environ.get("GEMM_SHAPES"):
     shapes = [s_ for s_ in shapes if s_[0] in os.environ["GEMM_SHAPES"].split(",")]
 if os.environ.get("GEMM_LONGK"):
