@@ -188,7 +188,12 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // Abramowitz-Stegun 7.1.26 form used before also needed v_rcp_f32) and a smaller error.  x + |x| (not max(x, 0)) keeps a NaN in x
 // alive like torch.  Measured on the fc1 epilogue of ViT-Base (155 M evaluations, same box, same process): this form 0.371-0.374 ms,
 // the 7.1.26 form 0.374-0.378, this form on pairs of elements with v_pk_fma_f32 (gelu_fast2) 0.357-0.381 -- the epilogue is bound by
-// the instruction count (14-15 either way; the transcendental unit overlaps), packed fp32 issues at half rate on gfx950.
+// the instruction count (14-15 either way; the transcendental unit overlaps).  Round 4 measured the packed form properly
+// (tools/valu_probe.hip: v_pk_fma_f32 delivers 1.64x the results of v_fma_f32 per unit time in a pure FMA loop -- 115 vs 70 TFLOP/s --
+// so it is NOT half rate, as this comment used to say) and rebuilt gelu16_fast on pairs (the Horner chain is five v_pk_fma_f32 instead
+// of five scalar v_fmaak_f32, which have no packed form because of their literal): the fc1 epilogue of ViT-Base and the fused CSWin
+// MLPs did not move (88 us of GELU in a 371 us fc1; 185 / 174 us) -- the evaluation is bound by v_exp_f32 (quarter rate, a third of
+// its ~50 cycles per value), v_min, the conversions and the slab round trip, not by FMA issue.  The scalar form stays.
 // max |gelu error| 5e-7 over [-12, 12] (the rounding of the result itself); tools/fit_gelu.py reproduces fit and check.
 typedef float gelu_f2 __attribute__((ext_vector_type(2)));
 #define MI355_GELU_C0 2.1717760034789535e-08f

@@ -36,7 +36,7 @@ struct StripeArgs {
 
 
 // One LePE tap on eight channels: r += w * (float)nb.  fp16: v_fma_mix_f32 reads the packed 16-bit neighbour values as they are
-// (hipcc otherwise converts all eight and pairs the products into half-rate v_pk_fma_f32: 2 x the issue slots); same arithmetic.
+// (hipcc otherwise converts all eight first -- eight v_cvt_f32_f16 in front of four v_pk_fma_f32; the mixed form needs no conversions); same arithmetic.
 template <int PREC, typename V8>
 __device__ __forceinline__ void lepe_tap(f4& r0, f4& r1, const V8 nb, const f4 w0, const f4 w1) {
     if constexpr (PREC == 1) {
