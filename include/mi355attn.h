@@ -98,6 +98,9 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   is capture-safe and every row is bit-identical whatever the batch); 0 = never.
  *   "gemm_variant"  0 (default) = kernel chosen by shape; 7 / 15 / 16 force the round-1 tile kernel / the persistent 256 x 256 kernel / the
  *                   two-accumulator persistent kernel (bit-identical results; A/B partners of the tests).  Values above 16 are refused.
+ *   "gemm_pa16"     16-bit outputs with a long reduction (K >= 576) on the two-accumulator kernel: 1 (default) = those with a GELU epilogue
+ *                   (its pieces hide most of the GELU that the persistent 256 x 256 kernel exposes), 2 = all, 0 = none.  Shorter
+ *                   reductions (K = 256 .. 512) always take it ("gemm_pa" = 1).  Bit-identical results either way.
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.

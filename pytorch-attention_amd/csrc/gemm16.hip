@@ -494,13 +494,16 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant == 0 && out16 && K >= 256 && K <= 512 && !g.gamma && !g.resid && mi355::opt_gemm_pa()) {
+    if (variant == 0 && out16 && K >= 256 && !g.gamma && !g.resid && mi355::opt_gemm_pa() &&
+        (K <= 512 || (mi355::opt_gemm_pa16() >= 1 && g.act == MI355_ACT_GELU) || mi355::opt_gemm_pa16() >= 2)) {
         // 16-bit outputs with a SHORT reduction (4 .. 8 K-tiles: CSWin stage 3 / 4, XCiT, the Mixer's token mixing): on the persistent
         // 256 x 256 kernel the epilogue of such a tile (bias / GELU / convert / store, nothing to overlap it with) is as long as its
         // main loop; the two-accumulator kernel packs two or three convert pieces into every barrier interval of the next tile's
         // main loop.  Round 4, same box, same process: CSWin s3 qkv 40 -> 32 us, fc1 74 -> 60, XCiT qkv 70 -> 54, fc1 106 -> 89,
-        // Mixer fc1 167 -> 136 (profiles/r04_gemm_short_k.md); bit-identical results.  K >= 576 stays on the 256 x 256 kernel (its
-        // main loop is the faster one once the epilogue is a small share: profiles/r03_gemm_pa.md).
+        // Mixer fc1 167 -> 136; bit-identical results.  Longer reductions (K >= 576): the 256 x 256 kernel's main
+        // loop stages 1.5 x fewer bytes per flop, but its GELU epilogue is fully exposed (55 us of ViT-Base's fc1) where the pieces of
+        // this kernel hide most of it (29 us): option "gemm_pa16" = 1 (default) sends GELU epilogues here (fc1 313 -> 291 us in a
+        // same-process A/B), 2 every 16-bit output (qkv: 221 -> 207 on one kind of box, 197 -> 208 on the other: not the default), 0 neither.
         const int ncu = mi355::resident_slots(1);
         const long tiles = (N & 255) ? (long)(M / 256) * (N / 128) : (long)cdiv(M, 128) * (N / 256);
         if (2 * tiles >= ncu) {
