@@ -101,6 +101,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_pa16"     16-bit outputs with a long reduction (K >= 576) on the two-accumulator kernel: 1 (default) = those with a GELU epilogue
  *                   (its pieces hide most of the GELU that the persistent 256 x 256 kernel exposes), 2 = all, 0 = none.  Shorter
  *                   reductions (K = 256 .. 512) always take it ("gemm_pa" = 1).  Bit-identical results either way.
+ *   "gemm_pa_block" 1 (default) = the two-accumulator kernel walks wide outputs (>= 8 column tiles) in blocks of 8 row x 4 column tiles, so
+ *                   that the 32 workgroups of an XCD share 1.5 MB of X rows + 1.5 MB of W instead of all of W; 0 = column tile fastest.
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.

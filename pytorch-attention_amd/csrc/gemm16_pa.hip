@@ -66,6 +66,12 @@ struct KtUnroll<N, N> {
 };
 
 struct PaPlan {
+    int blk_rows;  // tile order: 0 = column tile fastest over the whole matrix; > 0 = blocks of blk_rows row tiles x blk_cols column tiles
+    int blk_cols;  // (column fastest inside a block, blocks column-block fastest inside a band of blk_rows row tiles) for row tiles < blk_lim
+    int blk_lim;   // = the row tiles covered by whole bands; the rest of the matrix keeps the plain order
+    unsigned long long magic_n, magic_band;   // ceil(2^40 / tiles_n), ceil(2^40 / (blk_rows * tiles_n)): tile ids are wave-uniform, so the
+                   // quotients are two scalar multiplies instead of the VALU reciprocal sequence of an integer division (its temporaries
+                   // spill in a kernel that sits at 256 registers); exact for tile < 2^22, divisor < 2^12 (launcher)
     int tiles_n;
     int full;      // whole rounds: every workgroup walks `full` tiles ...
     int left;      // ... and workgroups 0 .. left-1 one more
@@ -167,6 +173,22 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // The lane part of a source address is the same for every tile (M % 128 == 0, N % 256 == 0: no clamps): row (wr*64 + wc*16 +
     // lrow) of the tile's A rows / slot row wave*16 + lrow of its B columns, swizzled chunk csw; the second DMA of a pair is 8 rows
     // further = a different scalar base.  The cursor itself is scalar state.
+    // tile id -> (row tile, column tile).  The 32 workgroups of an XCD hold 32 CONSECUTIVE tile ids at any moment (entry_tile): with the
+    // plain column-fastest order and a wide output (ViT fc1: 12 column tiles) that is 2.7 row panels x ALL of W -- 4.7 MB, more than
+    // the XCD's 4 MB L2, so W streams from the Infinity Cache once per panel group.  Blocked, the 32 tiles are blk_rows row panels x
+    // blk_cols column tiles (8 x 4: 1.5 MB of X rows + 1.5 MB of W).
+    auto decode = [&](int tile, int& tm, int& tn) {
+        if (pl.blk_rows && tile < pl.blk_lim * tiles_n) {       // blocks are 8 x 4 (launcher): shifts and masks inside a band
+            const int band = 8 * tiles_n;
+            const int b = (int)(((unsigned long long)(unsigned)tile * pl.magic_band) >> 40), r = tile - b * band;
+            const int cb = r >> 5, rr = r & 31;
+            tm = b * 8 + (rr >> 2);
+            tn = cb * 4 + (rr & 3);
+        } else {
+            tm = (int)(((unsigned long long)(unsigned)tile * pl.magic_n) >> 40);
+            tn = tile - tm * tiles_n;
+        }
+    };
     struct Cursor { const T* ta; const T* tb; int kt; int ent; };
     const int rb0 = wave * 16 + lrow;
     const unsigned la = (unsigned)((wr * 64 + wc * 16 + lrow) * sld_a + csw) * 2u;
@@ -175,8 +197,10 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         const int tile = entry_tile(e);
         // pl.tiles_n = tiles along the fast axis of the tile order = the OUTPUT COLUMN axis in both orientations (the row panel of X
         // that the column tiles of a row share is then used by neighbouring workgroups at the same time)
-        c.ta = A + (long)((SWAP ? tile % tiles_n : tile / tiles_n) * 128) * sld_a;
-        c.tb = B + (long)((SWAP ? tile / tiles_n : tile % tiles_n) * 256) * sld_b;
+        int tm, tn;
+        decode(tile, tm, tn);
+        c.ta = A + (long)((SWAP ? tn : tm) * 128) * sld_a;
+        c.tb = B + (long)((SWAP ? tm : tn) * 256) * sld_b;
         c.kt = 0;
         c.ent = e;
     };
@@ -540,8 +564,10 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
         }
         for (; kt < nk; ++kt) ktile(IC<-1>{}, IC<0>{}, cur, prv);
         const int tl = entry_tile(ent);
-        pm0 = (tl / tiles_n) * (SWAP ? 256 : 128);
-        pn0 = (tl % tiles_n) * (SWAP ? 128 : 256);
+        int tm, tn;
+        decode(tl, tm, tn);
+        pm0 = tm * (SWAP ? 256 : 128);
+        pn0 = tn * (SWAP ? 128 : 256);
         ++ent;
     };
     // ---- serial drain (last tile of the workgroup): the same pieces back to back, nothing else in flight ----------------------------
@@ -620,7 +646,15 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
     if (swap ? ((g.N & 127) || (g.M & 255) || g.lnc_a || abl) : (g.M & 127) != 0) return MI355_EUNSUPPORTED;
     PaPlan pl{};
     pl.tiles_n = swap ? g.N / 128 : g.N / 256;
-    const long ntiles = (long)(swap ? g.M / 256 : g.M / 128) * pl.tiles_n;
+    const int tiles_m = swap ? g.M / 256 : g.M / 128;
+    const long ntiles = (long)tiles_m * pl.tiles_n;
+    // blocked tile order for wide outputs (>= 8 column tiles, a multiple of 4): 8 row tiles x 4 column tiles per block
+    if (opt_gemm_pa_block() && pl.tiles_n >= 8 && (pl.tiles_n & 3) == 0 && tiles_m >= 8) {
+        pl.blk_rows = 8; pl.blk_cols = 4; pl.blk_lim = (tiles_m / 8) * 8;
+    }
+    if (ntiles >= (1L << 22) || pl.tiles_n >= 512) return MI355_EUNSUPPORTED;           // range of the magic-number quotients
+    pl.magic_n = ((1ULL << 40) + pl.tiles_n - 1) / pl.tiles_n;
+    pl.magic_band = ((1ULL << 40) + 8ULL * pl.tiles_n - 1) / (8ULL * pl.tiles_n);
     if (ntiles > (1L << 30)) return MI355_EUNSUPPORTED;
     const int ncu = resident_slots(1);
     const int grid = ntiles < ncu ? (int)ntiles : ncu;
