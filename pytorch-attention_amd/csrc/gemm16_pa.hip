@@ -1,4 +1,4 @@
-// gemm16_pa.hip -- persistent 128 x 256 x 64 GEMM on the 16-bit engine with TWO accumulator sets: the epilogue of output tile i
+// gemm16_pa.hip -- persistent 128 x 256 x 64 (or, operands swapped, 256 x 128 x 64) GEMM on the 16-bit engine with TWO accumulator sets: the epilogue of output tile i
 // (bias / GELU / residual, stores) is cut into pieces that ride in the MFMA intervals of tile i + 1's main loop, so the matrix pipe
 // never waits for an epilogue (gemm16_p8.hip exposes 5-20 us per tile: the GELU of fc1, the fp32 + residual round trips of proj / fc2).
 //
@@ -33,13 +33,15 @@
 //                          DMAs retire in order, so an HBM-latency load in front of a DMA makes the next K-tile's counted wait an
 //                          HBM-latency wait (measured: 1.8 us per K-tile with the loads in phase 0); behind them it has 1.75 K-tiles
 //     K-tiles 8, 9: F(6), C(7), F(7)
-//   16-bit output, piece p = (row tile i = p / 2, column pair jp = p % 2), unit = row tile (16 rows x 64 columns x 2 B = the slab):
-//     K-tile p    phase 0: p == 0: the 4 bias loads of the tile; C1(p-1) second column tile of the previous piece -> slab; F(i-1) when
-//                          p is even (2 stores)
-//                 phase 1: p == 0: wait for the bias; C0(p) first column tile -> slab
-//     K-tile 8    phase 0: C1(7); F(3)
-//   so a tile needs nk >= 10 K-tiles (K >= 640); the last tile of a workgroup drains serially.  bias == null / resid == null are
-//   descriptors with zero records (the loads return 0): no branch inside an MFMA interval, the counts stay static.
+//   16-bit output: 16 convert pieces c = (row tile c / 4, column tile c % 4) + one flush (two row-line stores) behind each row tile's
+//   last piece; barrier interval v (v = 2 E: phase 0 of K-tile E, v = 2 E + 1: phase 1) converts pieces (v - 1) * CPI .. v * CPI - 1;
+//   interval 0 issues the tile's 4 bias loads, interval 1 waits for them.  CPI = 1 (one piece per interval) fills K-tiles 0 .. 8,
+//   CPI = 2 K-tiles 0 .. 4, CPI = 3 K-tiles 0 .. 3: reductions down to K = 256 get the overlapped epilogue (round 4).
+//   So an fp32 tile needs nk >= 10 K-tiles (K >= 640), a 16-bit tile nk >= 4; the last tile of a workgroup drains serially.
+//   bias == null / resid == null are descriptors with zero records (the loads return 0): no branch inside an MFMA interval, the
+//   counts stay static (constexpr functions of the piece schedule).
+// Round 4 template flags: SWAP (256 x 128 orientation for widths like N = 384), CPI (above), LNC (the LayerNorm fold's emitting
+//   epilogue: ln_fold.hip); tile order: blocks of 8 row x 4 column tiles for wide outputs (PaPlan.blk_*).
 #include <type_traits>
 #include "gemm16.h"
 #include "bufops.h"

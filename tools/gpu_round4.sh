@@ -11,7 +11,7 @@ mkdir -p gpurun_out/r4
 export PYTHONDONTWRITEBYTECODE=1
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r4
-timeout 900 python bench.py > $O/bench_all.json 2> $O/bench_all.err
+( time timeout 900 python bench.py > $O/bench_all.json 2> $O/bench_all.err ) 2> $O/bench_all.time
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_all -o all -- python $R/bench.py --no-cpu --no-strict --steps 3 --warmup 1 > $O/prof_all.log 2>&1
 python $R/tools/rocpd_stats.py $O/prof_all/all_results.db > $O/all_kernel_stats.txt 2>&1
