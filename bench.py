@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-attention_amd"))
 sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA
 
@@ -420,6 +421,7 @@ def main(argv=None):
                      "kernel": dominant["name"] if dominant else dom["block"], "ms": dom["ms"], "dominant_kernel": dominant},
     }
 
+    sys.stderr.write("[bench] GPU part done %.1f s after start\n" % (time.perf_counter() - T_START))
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(blocks, args)
     print(json.dumps(out))
@@ -513,41 +515,44 @@ def cpu_baseline(blocks, args):
     # attention, 16-32 the transformer blocks: with 128 threads ViT-Base ran 6x slower than with 32), so it is probed PER BLOCK:
     # one pass per candidate count on the block's sample, then median of 3 at the best one.
     cands = sorted({min(threads, n) for n in (32, 64, 128, 256)})
-    per_image, reps, detail, used = 0.0, 3, [], 0
+    per_image, reps, detail, used = 0.0, 2, [], 0
     for b in blocks:
+        t_blk = time.perf_counter()
         ns = min(args.cpu_sample or b.get("cpu_n", 64), b["x"].shape[0])
         xs = b["x"][:ns].cpu()
-        # thread count: probed on the first 8 images of the sample (one warm-up at the first count, then one pass per candidate), so
+        # thread count: probed on the first 4 images of the sample (one warm-up at the first count, then one pass per candidate), so
         # that the slow candidates -- 256 threads on the transformer blocks -- cost seconds, not minutes; the timed passes then run
         # the whole sample at the winner
-        xp = xs[:min(8, ns)]
+        xp = xs[:min(4, ns)]
         torch.set_num_threads(cands[0])
         b["cpu"](xp)
         best_t, best_n = None, cands[0]
-        for nthr in cands:
-            torch.set_num_threads(nthr)
+        for nthr in cands:                                     # ascending; a count 1.5x slower than the best ends the probe (on the
+            torch.set_num_threads(nthr)                        # transformer blocks 128 / 256 threads are 6-20x slower than 32: minutes per pass)
             t1 = time.perf_counter()
             b["cpu"](xp)
             dt = time.perf_counter() - t1
             if best_t is None or dt < best_t:
                 best_t, best_n = dt, nthr
+            elif dt > 1.5 * best_t:
+                break
         torch.set_num_threads(best_n)
         used = max(used, best_n)
-        b["cpu"](xs)                                           # warm-up at the sample size
         ts = []
-        for _ in range(reps):
+        for _ in range(reps):                                  # the first pass doubles as the warm-up at the sample size: best of `reps`
             t1 = time.perf_counter()
             b["cpu"](xs)
             ts.append(time.perf_counter() - t1)
         ts.sort()
-        per_image += ts[len(ts) // 2] / ns
-        detail.append({"block": b["name"], "images": ns, "threads": best_n, "images_per_s": round(ns / ts[len(ts) // 2], 1),
+        sys.stderr.write("[bench] cpu leg %-42s probe+passes %.1f s (threads %d)\n" % (b["name"], time.perf_counter() - t_blk, best_n))
+        per_image += ts[0] / ns
+        detail.append({"block": b["name"], "images": ns, "threads": best_n, "images_per_s": round(ns / ts[0], 1),
                        "note": b.get("cpu_note", "oracle restatement (same math as the reference forward, not its exact operator sequence)")})
     return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
             "host_cores": cores, "host_threads": threads, "host_cpu": model, "blocks": detail,
             "sample": "oracle (torch-CPU restatement of the reference forward; the reference checkout does not exist on the GPU box) "
-                      "on the first n images of the same batch per block (n listed per block: 64), median of %d after 1 warm-up, torch "
-                      "threads probed per block over {32, 64, 128, 256} on the first 8 images (capped at the host's hardware threads; listed per block; `cores` = the largest count used), host has "
+                      "on the first n images of the same batch per block (n listed per block: 64), best of %d passes, torch "
+                      "threads probed per block over {32, 64, 128, 256} in ascending order on the first 4 images (the probe ends at the first count 1.5x slower than the best) (capped at the host's hardware threads; listed per block; `cores` = the largest count used), host has "
                       "%d cores / %d hardware threads"
                       % (reps, cores, threads)}
 
