@@ -628,7 +628,7 @@ def weight16_scaled(weight, bias, gamma, precision=None):
 
     def build():
         g = gamma.detach().reshape(-1)
-        w16 = cast16((weight.detach() * g[:, None]).contiguous(), p)
+        w16 = (weight.detach() * g[:, None]).to(dtype16(p)).contiguous()      # round-to-nearest-even, like mi355_cast16_fwd
         return w16, (None if bias is None else (bias.detach() * g).contiguous())
 
     return _derived_get(anchors, ("w16scaled", p), tag, build)
