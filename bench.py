@@ -439,10 +439,10 @@ def dominant_kernel_tally(block, run_block, args, ms_block):
     import mi355attn
     reps = max(2, min(5, args.steps))
 
-    def body():
-        with torch.no_grad():
+    def body():                                               # the block's forward WITHOUT the end-of-forward gather: only rank 0 runs this
+        with torch.no_grad():                                 # tally, and a collective entered by one rank alone would never return
             for _ in range(reps):
-                run_block(block)
+                block["module"](block["x"], *block.get("fwd_args", ()))
         torch.cuda.synchronize()
 
     rows = mi355attn.kernel_trace(body)
