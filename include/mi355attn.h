@@ -103,6 +103,12 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   reductions (K = 256 .. 512) always take it ("gemm_pa" = 1).  Bit-identical results either way.
  *   "gemm_pa_block" 1 (default) = the two-accumulator kernel walks wide outputs (>= 8 column tiles) in blocks of 8 row x 4 column tiles, so
  *                   that the 32 workgroups of an XCD share 1.5 MB of X rows + 1.5 MB of W instead of all of W; 0 = column tile fastest.
+ *   "gemm_pa_tail"  fp32 outputs on the two-accumulator kernel with K >= 1024 whose last round of tiles would be at most this many percent
+ *                   full (default 10; 0 = off): the kernel runs whole rounds only and the left-over rows go to a small-tile kernel
+ *                   spread over all CUs (a second launch on the same stream; same K order, bit-identical results).
+ *   "lpi_patch"     1 (default) = mi355_lpi_fwd / mi355_ln_lpi_fwd at 14 x 14 tokens with C % 32 == 0 run the patch kernel (a lane owns a
+ *                   2 x 2 token patch of one channel quad, taps in scalar registers, fused multiply-adds); 0 = the general kernel
+ *                   (separately rounded products and sums: the two agree to ~1e-7 relative, not bit for bit).
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.

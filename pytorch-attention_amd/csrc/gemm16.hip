@@ -117,6 +117,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const G16Args g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+    } else if constexpr (STAGES >= 3) {
+        // Ring of STAGES K-tiles for a LONE small workgroup per CU (the left-over rows of the two-accumulator kernel, see
+        // linear16_dispatch): STAGES - 1 K-tiles of LDS-DMA stay in flight, counted s_waitcnt, ONE raw barrier per K-step.  The
+        // barrier of step kt says every wave's share of K-tile kt has landed AND every wave has issued the MFMAs of step kt - 1 (its
+        // fragment reads of that slot have returned), so the slot of K-tile kt - 1 is refilled right behind it.
+        constexpr int AHEAD = STAGES - 1, STEADY = (IA + IB) * (STAGES - 2);
+        static_assert(STEADY <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s)
+            if (s < nk) issue(s, s * BK);
+        int slot = 0, fill = AHEAD;                             // slot = kt % STAGES, fill = (kt + AHEAD) % STAGES
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+            else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + AHEAD < nk) issue(fill, (kt + AHEAD) * BK);
+            compute(slot);
+            slot = slot + 1 == STAGES ? 0 : slot + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
     } else {                               // single buffer, two barriers per K-step: half the LDS, twice the resident workgroups --
         for (int kt = 0; kt < nk; ++kt) {  // load/compute overlap comes from the other workgroups on the CU
             issue(0, kt * BK);
@@ -524,6 +544,36 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         const int ncu = mi355::resident_slots(1);
         const long tiles = (N & 255) ? (long)(M / 256) * (N / 128) : (long)cdiv(M, 128) * (N / 256);
         if (2 * tiles >= ncu) {
+            // A last round that is nearly empty costs a whole tile time on a persistent kernel (the Mixer's fc2: 784 tiles = 3.06
+            // rounds, XCiT's fc2: 588 = 2.30).  With a long reduction that is tens of microseconds, so the two-accumulator kernel
+            // gets the rows of its whole rounds and the rest goes, as a second launch, to ring-pipelined small tiles that cover all
+            // CUs (option "gemm_pa_tail").  Both kernels add a row's K-tiles in the same order: bit-identical to the unsplit launch.
+            const int bmt = (N & 255) ? 256 : 128, tn = (N & 255) ? N / 128 : N / 256;
+            const long left = tiles % ncu, pct = mi355::opt_gemm_pa_tail();
+            if (pct > 0 && tiles > ncu && left > 0 && left * 100 <= pct * ncu && K >= 1024 && M % bmt == 0 && !g.resid_period && !g.lnc_a) {
+                const int rows1 = (int)((tiles - left) / tn) * bmt, rows2 = M - rows1;
+                G16Args g1 = g, g2 = g;
+                g1.M = rows1;
+                g2.M = rows2;
+                g2.A = static_cast<const char*>(g.A) + (size_t)rows1 * g.lda * 2;
+                g2.C = static_cast<char*>(g.C) + (size_t)rows1 * g.ldc * 4;
+                if (g.resid) g2.resid = g.resid + (size_t)rows1 * g.ldc;
+                const int rc = mi355::gemm16_pa(g1, out16, precision, st);
+                if (rc == MI355_OK) {
+                    MI355_LAUNCH_CHECK();
+                    // 32 x 64 tiles, four waves, a ring of ten K-tiles (120 KB): 1 024 x 512 left-over outputs = one workgroup per CU.  The
+                    // small tile stages 12 KB per 0.26 MFLOP through an LDS-DMA path that tops out near 27 B/clk/CU, so
+                    // it pays for FEW left-over tiles only (round 4: Mixer fc2, 16 of 784 tiles, 143 -> 135 us and 490 -> 475 us for the
+                    // block; XCiT fc2, 76 of 588, 92 -> 102 us with 64 x 128 tiles: hence the 10 % default).
+                    const int grid = cdiv(rows2, 32) * cdiv(N, 64);
+                    MI355_TRACE(st, "gemm16_kernel<tail 32x64> M=%d N=%d K=%d", rows2, N, K);
+                    if (precision == MI355_PREC_FP16) gemm16_kernel<_Float16, false, 32, 64, 1, 4, false, 10><<<grid, 256, 0, st>>>(g2);
+                    else                              gemm16_kernel<__bf16, false, 32, 64, 1, 4, false, 10><<<grid, 256, 0, st>>>(g2);
+                    MI355_LAUNCH_CHECK();
+                    return MI355_OK;
+                }
+                if (rc != MI355_EUNSUPPORTED) return rc;
+            }
             const int rc = mi355::gemm16_pa(g, out16, precision, st);
             if (rc == MI355_OK) {
                 MI355_LAUNCH_CHECK();

@@ -375,6 +375,171 @@ __global__ __launch_bounds__(256, 4) void lpi_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same block for even token grids of at most 64 2 x 2 patches (XCiT at 224 px: 14 x 14), bound by LDS reads in the form
+// above (nine 16-byte reads per token, stencil and channel quad; taps in 36 + 36 vector registers, 9 spilled at the 128-register budget).
+//   * LDS holds the zero-haloed tile CHANNEL-QUAD-major in four planes (row parity x column parity of the padded grid), so that the 64
+//     lanes of a wave, lane = one 2 x 2 patch, read any element of their 4 x 4 neighbourhoods as consecutive 16-byte chunks: 16 reads
+//     for four outputs instead of 36, no bank conflict by construction (plane pitch odd, quad pitch = 2 mod 16 chunks for the
+//     coalesced load / store phases, whose lanes are 8 quads x 8 tokens);
+//   * a wave works on ONE channel quad at a time, so the 36 taps, bias, BatchNorm and LayerScale factors are wave-uniform: scalar
+//     loads through a constant-address-space view of the weights (a plain global load after a barrier is not scalarised by hipcc),
+//     pinned to their phase by an opaque zero in the index (hoisted to the kernel's top they cost > 100 live SGPRs, spilled into
+//     VGPR lanes, which then spill to scratch);
+//   * fused multiply-adds in the stencils (the form above rounds product and sum separately: -ffp-contract=off);
+//   * load and store phases unchanged: 8 lanes = one 128-byte line of x / y.
+// tools/lpi_probe.hip (B = 256, 14 x 14 x 384, inputs rotated through 616 MB): 73.6 -> 44.6 us, 33 us of it LDS + VALU.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) float* lpi_cptr;
+constexpr int lpi_quad_pitch(int pls) { int c = 4 * pls; while (c % 16 != 2) ++c; return c; }
+
+template <int H, int W, bool LN>
+__global__ __launch_bounds__(256, 4) void lpi_patch_kernel(const float* __restrict__ x, const float* w1, const float* b1, const float* bn_w,
+                                                           const float* bn_b, const float* bn_m, const float* bn_v, float bn_eps,
+                                                           const float* w2, const float* b2, const float* gamma, const float* resid,
+                                                           float* __restrict__ y, int C, int groups, const float* __restrict__ stats,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b) {
+    constexpr int N = H * W, PR = H / 2 + 1, PP = W / 2 + 1, PLS = (PR * PP) | 1, CQS = lpi_quad_pitch(PLS), NJ = (N + 31) / 32;
+    static_assert(H % 2 == 0 && W % 2 == 0 && (H / 2) * PP <= 64 && (PP & (PP - 1)) == 0, "one 2 x 2 patch per lane, PP lanes per patch row");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f4* s = reinterpret_cast<f4*>(smem);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cq = t & 7, tl = t >> 3;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * LPI_CG;
+    auto adr_of = [&](int n) {                                       // token n of channel quad cq in the planes
+        const int yy = n / W, xx = n - yy * W, R = yy + 1, Cc = xx + 1;
+        return cq * CQS + ((R & 1) * 2 + (Cc & 1)) * PLS + (R >> 1) * PP + (Cc >> 1);
+    };
+    auto mine = [&](int j) { return 32 * j + 31 < N || tl + 32 * j < N; };      // full iterations are decided at compile time
+    // ---- phase 1: coalesced loads, LayerNorm applied on the way into LDS (the expression of layernorm_kernel: same bits) ----
+    {
+        const float* xb = x + ((long)b * N) * C + c0 + cq * 4;
+        f4 v0[NJ];
+        float2 st[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = tl + 32 * j;
+            v0[j] = f4{0.f, 0.f, 0.f, 0.f};
+            st[j] = float2{0.f, 1.f};
+            if (mine(j)) {
+                v0[j] = *reinterpret_cast<const f4*>(xb + (long)n * C);
+                if constexpr (LN) st[j] = *reinterpret_cast<const float2*>(stats + ((long)b * N + n) * 2);
+            }
+        }
+        // zero halo of every quad while the loads fly: 2 (W + 2) + 2 H cells x 8 quads; every interior cell is written below
+        constexpr int HC = 2 * (W + 2) + 2 * H;
+#pragma unroll
+        for (int i = 0; i < (8 * HC + 255) / 256; ++i) {
+            const int q = t + 256 * i;
+            if (q < 8 * HC) {
+                const int zq = q / HC, h = q - zq * HC;
+                int R, Cc;
+                if (h < W + 2) { R = 0; Cc = h; }
+                else if (h < 2 * (W + 2)) { R = H + 1; Cc = h - (W + 2); }
+                else { const int k = h - 2 * (W + 2); R = 1 + (k >> 1); Cc = (k & 1) ? W + 1 : 0; }
+                s[zq * CQS + ((R & 1) * 2 + (Cc & 1)) * PLS + (R >> 1) * PP + (Cc >> 1)] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 lw = f4{1.f, 1.f, 1.f, 1.f}, lb = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LN) { lw = *reinterpret_cast<const f4*>(ln_w + c0 + cq * 4); lb = *reinterpret_cast<const f4*>(ln_b + c0 + cq * 4); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (mine(j)) {
+                if constexpr (LN) s[adr_of(tl + 32 * j)] = (v0[j] - st[j].x) * st[j].y * lw + lb;
+                else              s[adr_of(tl + 32 * j)] = v0[j];
+            }
+    }
+    const int py = lane / PP, px = lane & (PP - 1);
+    const bool active = px < W / 2 && py < H / 2;
+    auto quad4 = [&](lpi_cptr p, int cb) { return f4{p[cb], p[cb + 1], p[cb + 2], p[cb + 3]}; };
+    auto stencil = [&](const float* wt_, const float* bs_, int q, f4* out) {
+        lpi_cptr wt = (lpi_cptr)wt_, bs = (lpi_cptr)bs_;
+        int pin = 0;
+        asm volatile("" : "+s"(pin));                                 // the scalar loads below stay in this phase
+        const int cb = c0 + q * 4 + pin;
+        const f4* base = s + q * CQS + py * PP + px;
+        const f4 bias = quad4(bs, cb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                // one row of the 4 x 4 neighbourhood at a time: 16 operand registers
+            f4 in[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) in[cc] = base[((r & 1) * 2 + (cc & 1)) * PLS + (r >> 1) * PP + (cc >> 1)];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int dy = r - a;                                 // taps in the order dy, dx of the form above
+                if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int i9 = dy * 3 + dx;
+                    const f4 k = f4{wt[(cb + 0) * 9 + i9], wt[(cb + 1) * 9 + i9], wt[(cb + 2) * 9 + i9], wt[(cb + 3) * 9 + i9]};
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        f4& o = out[a * 2 + bb];
+                        const f4 v = in[bb + dx];
+                        o = f4{__builtin_fmaf(k.x, v.x, o.x), __builtin_fmaf(k.y, v.y, o.y), __builtin_fmaf(k.z, v.z, o.z), __builtin_fmaf(k.w, v.w, o.w)};
+                    }
+                }
+            }
+        }
+    };
+    auto put = [&](int q, const f4* out) {                            // the patch's four tokens back into the planes
+        f4* base = s + q * CQS + py * PP + px;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) base[(((a + 1) & 1) * 2 + ((bb + 1) & 1)) * PLS + ((a + 1) >> 1) * PP + ((bb + 1) >> 1)] = out[a * 2 + bb];
+    };
+    f4 res[2][4];
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave * 2 + i;
+            stencil(w1, b1, q, res[i]);
+            int pin = 0;
+            asm volatile("" : "+s"(pin));
+            const int cb = c0 + q * 4 + pin;
+            const f4 mean = quad4((lpi_cptr)bn_m, cb), var = quad4((lpi_cptr)bn_v, cb), bw = quad4((lpi_cptr)bn_w, cb), bb = quad4((lpi_cptr)bn_b, cb);
+            const f4 rstd = f4{1.0f / sqrtf(var.x + bn_eps), 1.0f / sqrtf(var.y + bn_eps), 1.0f / sqrtf(var.z + bn_eps), 1.0f / sqrtf(var.w + bn_eps)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[i][e] = (gelu_fast4(res[i][e]) - mean) * rstd * bw + bb;
+        }
+    }
+    __syncthreads();                      // every neighbourhood of the input tile has been read
+    if (active) { put(wave * 2, res[0]); put(wave * 2 + 1, res[1]); }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave * 2 + i;
+            stencil(w2, b2, q, res[i]);
+            if (gamma) {
+                int pin = 0;
+                asm volatile("" : "+s"(pin));
+                const f4 gm = quad4((lpi_cptr)gamma, c0 + q * 4 + pin);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[i][e] = res[i][e] * gm;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) { put(wave * 2, res[0]); put(wave * 2 + 1, res[1]); }
+    __syncthreads();
+    // ---- phase 4: residual + coalesced store ----
+    float* yp = y + ((long)b * N) * C + c0 + cq * 4;
+    f4 rr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        rr[j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (resid && mine(j)) rr[j] = *reinterpret_cast<const f4*>(resid + ((long)b * N + tl + 32 * j) * C + c0 + cq * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (mine(j)) *reinterpret_cast<f4*>(yp + (long)(tl + 32 * j) * C) = s[adr_of(tl + 32 * j)] + rr[j];
+}
+
 // (mean, rstd) of every token row: the statistics of layernorm_kernel (two-pass, biased variance, eps inside the sqrt), one wave per
 // row; what the LayerNorm-fused LPI above normalises with.  Reads x once, writes 8 bytes per row.
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, long rows, int cols, float eps) {
@@ -467,6 +632,18 @@ static int lpi_launch(const float* x, const float* w1, const float* b1, const fl
                       const float* bn_var, float bn_eps, const float* w2, const float* b2, const float* gamma, const float* resid,
                       float* y, int B, int H, int W, int C, const float* stats, const float* ln_w, const float* ln_b, hipStream_t st) {
     if (H * W > 32 * LPI_TMAX) return mi355::fail(MI355_EUNSUPPORTED, "mi355_lpi_fwd: %dx%d token grid exceeds the LDS tile (<= 256 tokens)", H, W);
+    if (H == 14 && W == 14 && (C % LPI_CG) == 0 && mi355::opt_lpi_patch() && aligned16(x) && aligned16(y) && (!resid || aligned16(resid)) &&
+        (!stats || (aligned16(ln_w) && aligned16(ln_b)))) {
+        // 2 x 2 patches per lane, channel-quad-major planes (see lpi_patch_kernel)
+        constexpr int PLS = (8 * 8) | 1, CQS = lpi_quad_pitch(PLS);
+        const size_t smem = (size_t)8 * CQS * 16;
+        const int groups = C / LPI_CG;
+        MI355_TRACE(st, "lpi_patch_kernel%s B=%d %dx%d C=%d", stats ? "<ln>" : "", B, H, W, C);
+        if (stats) lpi_patch_kernel<14, 14, true><<<B * groups, 256, smem, st>>>(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, C, groups, stats, ln_w, ln_b);
+        else       lpi_patch_kernel<14, 14, false><<<B * groups, 256, smem, st>>>(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, C, groups, nullptr, nullptr, nullptr);
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     const size_t smem = (size_t)(H + 2) * (W + 2) * LPI_CG * sizeof(float);
     const int groups = cdiv(C, LPI_CG);
     MI355_TRACE(st, "lpi_kernel%s B=%d %dx%d C=%d", stats ? "<ln>" : "", B, H, W, C);

@@ -177,3 +177,137 @@ def test_range_guard_sees_a_saturation_next_to_an_input_inf():
     F.cast16(x, 1)
     with pytest.raises(mi355attn.Mi355RangeError):
         mi355attn.range_status(wait=True)
+
+
+# ---- left-over rows of the two-accumulator GEMM on ring-pipelined small tiles (option "gemm_pa_tail"; gemm16.hip) -------------------
+TAIL_SHAPES = [  # (M, N, K, tail kernel expected)
+    (128 * 392, 512, 2048, "32x64"),      # MixerLayer fc2 at B = 256: 784 tiles = 3.06 rounds -> 49 152 rows + 1 024 rows (the default's case)
+    (256 * 196, 384, 1536, "32x64"),      # XCiT-S fc2: 588 swapped tiles = 2.30 rounds -> 43 520 rows + 6 656 rows (1 248 ring workgroups, five per CU in turn)
+    (128 * 264, 256, 1024, "32x64"),      # one column tile, eight left-over tiles, the shortest reduction that splits
+    (128 * 160, 512, 1088, "32x64"),      # 320 tiles: one round + 64 (4 096 rows); 17 K-tiles (more than the ring holds)
+]
+
+
+@pytest.mark.parametrize("prec,dt", [(1, torch.float16), (2, torch.bfloat16)])
+@pytest.mark.parametrize("M,N,K,which", TAIL_SHAPES)
+def test_left_over_rows_on_the_ring_kernel_are_bit_identical(M, N, K, which, prec, dt):
+    import mi355attn
+    from mi355attn import functional as F
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("round arithmetic of the shapes above assumes 256 CUs")
+    torch.manual_seed(M + N + K)
+    x16 = torch.randn(M, K, device="cuda").to(dt)
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).to(dt)
+    b = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda")
+    old = mi355attn.get_option("gemm_pa_tail")
+    try:
+        for kw in (dict(bias=b, resid=resid), dict(bias=None, resid=resid), dict(bias=b, resid=resid, act=F.ACT_GELU)):
+            mi355attn.set_option("gemm_pa_tail", 0)
+            y_off = F.linear16(x16, w16, precision=prec, **kw)
+            mi355attn.set_option("gemm_pa_tail", 30)
+            tags = []
+            y_on = [None]
+
+            def run():
+                y_on[0] = F.linear16(x16, w16, precision=prec, **kw)
+            tags = [t for t, *_ in mi355attn.kernel_trace(run)]
+            assert any(f"tail {which}" in t for t in tags), f"the ring kernel did not run: {tags}"
+            y_on2 = F.linear16(x16, w16, precision=prec, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y_on[0], y_on2), "run-to-run difference"
+            assert torch.equal(y_off, y_on[0]), f"split launch differs from the single launch with {sorted(kw)}"
+        mi355attn.set_option("gemm_variant", 7)
+        y7 = F.linear16(x16, w16, b, resid=resid, precision=prec)
+        mi355attn.set_option("gemm_variant", 0)
+        assert torch.equal(y7, F.linear16(x16, w16, b, resid=resid, precision=prec)), "differs from the round-1 tile kernel"
+        # the last rows (the ring kernel's) against an fp64 product of the same 16-bit operands
+        rows = slice(M - 96, M)
+        ref = (x16[rows].double() @ w16.double().t() + b.double() + resid[rows].double()).float()
+        assert_parity(F.linear16(x16, w16, b, resid=resid, precision=prec)[rows], ref, 2e-5, "fp64 product, last rows")
+    finally:
+        mi355attn.set_option("gemm_variant", 0)
+        mi355attn.set_option("gemm_pa_tail", old)
+
+
+def test_left_over_rows_split_is_recorded_under_graph_capture():
+    """Two plain launches on one stream: nothing to step aside for under capture."""
+    import mi355attn
+    from mi355attn import functional as F
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("assumes 256 CUs")
+    torch.manual_seed(1)
+    M, N, K = 128 * 392, 512, 2048
+    x16 = torch.randn(M, K, device="cuda").half()
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    resid = torch.randn(M, N, device="cuda")
+    y_eager = F.linear16(x16, w16, None, resid=resid, precision=1)
+    y_graph = torch.empty_like(y_eager)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        F.linear16(x16, w16, None, resid=resid, precision=1)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        y_graph.copy_(F.linear16(x16, w16, None, resid=resid, precision=1))
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_eager, y_graph)
+
+
+# ---- LPI on 2 x 2 patches per lane (xcit.hip lpi_patch_kernel; option "lpi_patch") ---------------------------------------------------
+@pytest.mark.parametrize("C,with_ln,with_tail", [(384, True, True), (96, False, True), (32, True, False), (64, False, False)])
+def test_lpi_patch_kernel_against_the_general_kernel_and_the_oracle(C, with_ln, with_tail):
+    """14 x 14 tokens, C % 32 == 0: the patch kernel (fused multiply-adds, taps in scalar registers) against the general kernel
+    (option off: separately rounded products) to 1e-6, against the oracle, run-to-run bit identity, and a row's independence of the
+    batch around it."""
+    import mi355attn
+    from mi355attn.modules import LPI
+    torch.manual_seed(C + 7)
+    B, H, W = 5, 14, 14
+    m = LPI(C).eval()
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.2)
+        m.bn.running_var.uniform_(0.5, 1.5)
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.normal_(0, 0.2)
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.2)
+    x = torch.randn(B, H * W, C) * 1.5 + 0.3
+    gamma = torch.rand(C) + 0.5
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m, ln = m.cuda(), ln.cuda()
+    xd, gd = x.cuda(), gamma.cuda()
+    kw = dict(gamma=gd, resid=xd) if with_tail else {}
+    if with_ln:
+        kw["ln"] = ln
+    old = mi355attn.get_option("lpi_patch")
+    try:
+        with torch.no_grad():
+            mi355attn.set_option("lpi_patch", 1)
+            tags = []
+            out = [None]
+
+            def run():
+                out[0] = m(xd, H, W, **kw)
+            tags = [t for t, *_ in mi355attn.kernel_trace(run)]
+            assert any("lpi_patch_kernel" in t for t in tags), tags
+            y1 = out[0]
+            y1b = m(xd, H, W, **kw)
+            y_one = m(xd[3:4].contiguous(), H, W, **({**kw, "resid": xd[3:4].contiguous()} if with_tail else kw))
+            mi355attn.set_option("lpi_patch", 0)
+            y0 = m(xd, H, W, **kw)
+    finally:
+        mi355attn.set_option("lpi_patch", old)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y1b), "run-to-run difference"
+    assert torch.equal(y1[3:4], y_one), "a row's bits depend on the batch"
+    assert_parity(y1.cpu(), y0.cpu(), 1e-6, "patch kernel vs general kernel")
+    u = torch.nn.functional.layer_norm(x, (C,), ln.weight.cpu(), ln.bias.cpu(), ln.eps) if with_ln else x
+    ref = O.lpi_forward(u, sd, H, W)
+    if with_tail:
+        ref = x + gamma * ref
+    assert_parity(y1.cpu(), ref, 2e-5, "patch kernel vs oracle")
