@@ -441,6 +441,9 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
             if (V >= 1 && c < 16) {
                 epi_c16(prv[c >> 2][c & 3], bias_of(c & 3), c & 3);
                 if ((c & 3) == 3) epi_f16(c >> 2);
+                // three GELU pieces scheduled into one another keep three sets of polynomial temporaries alive: at the 256-register
+                // budget that spilled an accumulator quad to scratch once per tile (a scratch reload drains the DMA queue)
+                if constexpr (GELU && CPI >= 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };

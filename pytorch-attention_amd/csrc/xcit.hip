@@ -550,7 +550,19 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     for (long row = wave0; row < rows; row += nwaves) {
         const float* xr = x + row * cols;
         float s = 0.f, q = 0.f;
-        if (vec) {
+        if (vec && cols <= 512) {                                       // the row fits two float4 per lane: read once (same sums, same order)
+            const int n4 = cols >> 2;
+            const bool h0 = lane < n4, h1 = lane + 64 < n4;
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            const f4 v0 = h0 ? reinterpret_cast<const f4*>(xr)[lane] : z, v1 = h1 ? reinterpret_cast<const f4*>(xr)[lane + 64] : z;
+            if (h0) s += (v0.x + v0.y) + (v0.z + v0.w);
+            if (h1) s += (v1.x + v1.y) + (v1.z + v1.w);
+            const float mean = wave_sum(s) * inv;
+            if (h0) { const f4 d = v0 - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+            if (h1) { const f4 d = v1 - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+            const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+            if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = r; }
+        } else if (vec) {
             const int n4 = cols >> 2;
             for (int i = lane; i < n4; i += 64) { const f4 v = reinterpret_cast<const f4*>(xr)[i]; s += (v.x + v.y) + (v.z + v.w); }
             const float mean = wave_sum(s) * inv;

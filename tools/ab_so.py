@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Same-process A/B of two builds of libmi355attn.so on one op (box-to-box variance on the pool is 10-20 %, so cross-run comparisons of
-small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|stripe1|stripe2|pmlp1|pmlp2|fc1|qkv|proj|fc2 [baseline.so]`.
-The baseline library defaults to tools/bin/libmi355attn_r2.so (built from the round-2 head in a scratch worktree)."""
+small changes are meaningless): `python tools/ab_so.py sdpa16|se|cbam|eca|lpi|lnlpi|lnt|stripe1|stripe2|pmlp1|pmlp2|fc1|qkv|proj|fc2 [baseline.so]`.
+The baseline library defaults to tools/bin/libmi355attn_base.so (a copy of an earlier build)."""
 import ctypes
 import os
 import sys
@@ -13,7 +13,7 @@ import mi355attn  # noqa: E402
 
 vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 op = sys.argv[1] if len(sys.argv) > 1 else "sdpa16"
-base = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tools", "bin", "libmi355attn_r2.so")
+base = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tools", "bin", "libmi355attn_base.so")
 libs = {"base": ctypes.CDLL(base), "new": ctypes.CDLL(mi355attn.LIB_PATH)}
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
@@ -88,6 +88,34 @@ elif op == "lpi":
         fns[k] = (lambda lib=lib, k=k: lib.mi355_lpi_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), bw.data_ptr(), bb.data_ptr(), bm.data_ptr(), bv.data_ptr(),
                                                           1e-5, w2.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(), outs[k].data_ptr(), B, H, W, C,
                                                           wss[k].data_ptr(), 1 << 20, st))
+elif op == "lnlpi":
+    # LayerNorm statistics + LPI (mi355_ln_lpi_fwd) at the XCABlock shape of the bench step
+    B, H, W, C = 256, 14, 14, 384
+    x = torch.randn(B, H * W, C, device=dev)
+    w1, w2 = torch.randn(C, 1, 3, 3, device=dev) / 3, torch.randn(C, 1, 3, 3, device=dev) / 3
+    b1, b2, bw, bb, bm, lw, lb = (torch.randn(C, device=dev) * 0.1 for _ in range(7))
+    bv = torch.rand(C, device=dev) + 0.5
+    gm = torch.rand(C, device=dev)
+    outs, fns, wss = {}, {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty_like(x)
+        lib.mi355_ln_lpi_fwd.restype = ci
+        lib.mi355_ln_lpi_fwd.argtypes = [vp] * 3 + [cf] + [vp] * 6 + [cf] + [vp] * 5 + [ci] * 4 + [vp, sz, vp]
+        wss[k] = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_ln_lpi_fwd(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, w1.data_ptr(), b1.data_ptr(), bw.data_ptr(), bb.data_ptr(),
+                                                             bm.data_ptr(), bv.data_ptr(), 1e-5, w2.data_ptr(), b2.data_ptr(), gm.data_ptr(), x.data_ptr(),
+                                                             outs[k].data_ptr(), B, H, W, C, wss[k].data_ptr(), 1 << 20, st))
+elif op == "lnt":
+    # the Mixer's transposed 16-bit LayerNorm (mi355_layernorm16_t_fwd) at B = 256, 196 tokens, 512 channels
+    B, N, C, NP = 256, 196, 512, 224
+    x = torch.randn(B, N, C, device=dev)
+    lw, lb = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    outs, fns = {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.zeros(B, C, NP, device=dev, dtype=torch.float16)
+        lib.mi355_layernorm16_t_fwd.restype = ci
+        lib.mi355_layernorm16_t_fwd.argtypes = [vp] * 4 + [ci] * 4 + [cf, ci, vp]
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_layernorm16_t_fwd(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), outs[k].data_ptr(), B, N, C, NP, 1e-5, 1, st))
 elif op in ("stripe1", "stripe2"):
     # first half of a CSWinBlock (mi355_cswin_stripe_attn_fwd) at the stage-1 / stage-2 shapes of the bench step
     C, reso, hb, split = (64, 56, 1, 1) if op == "stripe1" else (128, 28, 2, 2)
