@@ -106,6 +106,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_pa_tail"  fp32 outputs on the two-accumulator kernel with K >= 1024 whose last round of tiles would be at most this many percent
  *                   full (default 10; 0 = off): the kernel runs whole rounds only and the left-over rows go to a small-tile kernel
  *                   spread over all CUs (a second launch on the same stream; same K order, bit-identical results).
+ *   "mixer_fused"   1 (default) = the host mirror's MixerLayer runs its token-mixing half through mi355_mixer_token_fwd where the
+ *                   geometry allows (N = 196, T % 32 == 0, C % 256 == 0); 0 = three launches (transposing LayerNorm, fc1, transposed fc2).
  *   "lpi_patch"     1 (default) = mi355_lpi_fwd / mi355_ln_lpi_fwd at 14 x 14 tokens with C % 32 == 0 run the patch kernel (a lane owns a
  *                   2 x 2 token patch of one channel quad, taps in scalar registers, fused multiply-adds); 0 = the general kernel
  *                   (separately rounded products and sums: the two agree to ~1e-7 relative, not bit for bit).
@@ -378,6 +380,17 @@ int mi355_layernorm16_t_fwd(const float* x, const float* weight, const float* bi
                             int precision, mi355_stream_t stream);
 int mi355_linear16_tr_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K,
                           int ldx, int rows_per_image, int precision, mi355_stream_t stream);
+/* The whole token-mixing half of a MixerLayer (mlp_mixer.py:47 with norm1 and Mlp.forward :27-33) as a row-statistics pass + ONE kernel:
+ *   y (B,N,C) = x + ( gelu( LayerNorm(x)^T W1^T + b1 ) W2^T + b2 )^T
+ * for N = 196 tokens, T % 32 == 0 hidden token units (T <= 512), C % 256 == 0 (C <= 1024): neither the transposed LayerNorm output nor the hidden
+ * tensor exists in HBM (mixer_fused.hip).  w1p16: (T, 224) 16-bit = fc1.weight (T, 196) zero-padded along in_features;
+ * w2s16: (T / 32, 208, 32) 16-bit slice-major = fc2.weight (196, T) with w2s[kb][n][j] = W2[n][kb * 32 + j], rows n >= 196 zero.
+ * ws: mi355_mixer_token_workspace_bytes (the per-token (mean, rstd) of the pre-pass).  y may alias x.  Other geometries:
+ * MI355_EUNSUPPORTED (compose mi355_layernorm16_t_fwd / mi355_linear16_fwd / mi355_linear16_tr_fwd above). */
+size_t mi355_mixer_token_workspace_bytes(int B, int N, int C);
+int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const void* w1p16, const float* b1,
+                          const void* w2s16, const float* b2, float* y, int B, int N, int C, int T, int precision, void* ws,
+                          size_t ws_bytes, mi355_stream_t stream);
 /* LayerNorm + Linear in one pass for narrow rows (K = 64 or 128 = the normalised width; CSWin stage 1 / 2 and XCiT-nano qkv):
  *   Y = act( ((x - mean) / sqrt(var + eps)) . W16^T + bias ),  x (M,K) fp32 with row stride ldx floats, Y fp32 or 16-bit (out16).
  * The LayerNorm affine part must be folded into W16 / bias by the caller (W' = W diag(ln_weight), b' = b + W ln_bias).  The rows are

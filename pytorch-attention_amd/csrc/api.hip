@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -45,6 +45,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"gemm_pa_block", 1, 0, 1},            // two-accumulator kernel: blocked tile order (8 row x 4 column tiles per XCD round) for wide outputs
     {"gemm_pa_tail", 10, 0, 100},          // two-accumulator kernel, K >= 1024: a last round at most this many percent full goes to the small-tile ring kernel (0 = off)
     {"lpi_patch", 1, 0, 1},                // LPI at 14 x 14 tokens, C % 32 == 0: 2 x 2 patches per lane on channel-quad-major LDS planes (xcit.hip)
+    {"mixer_fused", 1, 0, 1},              // MixerLayer token mixing (host mirror): one kernel where the geometry allows (mixer_fused.hip)
 };
 namespace {
 constexpr long OPT_UNSET = (long)0x8000000000000000ull;              // a device block entry that follows the process default

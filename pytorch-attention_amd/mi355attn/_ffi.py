@@ -68,6 +68,8 @@ SIGNATURES = {
     "mi355_layernorm16_fwd": (c_int, [c_vp] * 4 + [c_int, c_int, c_float, c_int, c_vp]),
     "mi355_ln_linear16_fwd": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_float, c_int, c_int, c_int, c_vp]),
     "mi355_layernorm16_t_fwd": (c_int, [c_vp] * 4 + [c_int] * 4 + [c_float, c_int, c_vp]),
+    "mi355_mixer_token_workspace_bytes": (c_size, [c_int] * 3),
+    "mi355_mixer_token_fwd": (c_int, [c_vp] * 3 + [c_float] + [c_vp] * 5 + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "mi355_linear16_tr_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),
     "mi355_linear16_fwd": (c_int, [c_vp] * 6 + [c_int] * 8 + [c_vp]),
     "mi355_linear16_workspace_bytes": (c_size, [c_int] * 3),

@@ -755,6 +755,46 @@ def layernorm16_t(x, weight, bias, eps=1e-5, NP=None, precision=None):
     return ut
 
 
+MIXER_TOKENS = 196      # the token count mi355_mixer_token_fwd is built for (14 x 14 patches)
+
+
+def mixer_token_ok(N, T, C, precision=None):
+    """Envelope of mi355_mixer_token_fwd: 16-bit operand mode, N = 196 tokens, T % 32 == 0 hidden token units (<= 512), C % 256 == 0
+    (<= 1024), and the option switch "mixer_fused"."""
+    return (_prec(precision) in (PREC_FP16, PREC_BF16) and N == MIXER_TOKENS and T % 32 == 0 and 0 < T <= 512 and C % 256 == 0 and 0 < C <= 1024
+            and _ffi.get_option("mixer_fused") != 0)
+
+
+def weight16_slices(w, rows, precision=None):
+    """fc2.weight (N, T) as (T / 32, rows, 32) 16-bit: w2s[kb][n][j] = w[n][kb * 32 + j], rows n >= N zero (the slice-major operand of
+    mi355_mixer_token_fwd; cached with the parameter)."""
+    def build():
+        N, T = w.shape
+        out = torch.zeros(T // 32, rows, 32, dtype=dtype16(precision), device=w.device)
+        out[:, :N, :] = w.detach().reshape(N, T // 32, 32).permute(1, 0, 2)
+        return out.contiguous()
+    tag = (w._version, w.data_ptr(), tuple(w.shape))
+    return _derived_get((w,), ("w16slices", rows, _prec(precision)), tag, build)
+
+
+def mixer_token_mlp(x, norm, fc1, fc2, precision=None):
+    """x + (gelu(LayerNorm(x)^T W1^T + b1) W2^T + b2)^T for x (B, 196, C): mlp_mixer.py:47 as a row-statistics pass + one kernel."""
+    x = require_device_f32(x, "x")
+    B, N, C = x.shape
+    T = fc1.weight.shape[0]
+    p = _prec(precision)
+    w1p = weight16_padk(fc1.weight, 224, p)
+    w2s = weight16_slices(fc2.weight, 208, p)
+    y = torch.empty_like(x)
+    n = lib().mi355_mixer_token_workspace_bytes(B, N, C)
+    ws = workspace(n, x.device)
+    check(lib().mi355_mixer_token_fwd(dptr(x), dptr(require_device_f32(norm.weight, "norm.weight")), dptr(require_device_f32(norm.bias, "norm.bias")),
+                                      float(norm.eps), dptr(w1p), dptr(require_device_f32(fc1.bias, "fc1.bias")), dptr(w2s),
+                                      dptr(require_device_f32(fc2.bias, "fc2.bias")), dptr(y), B, N, C, T, p, dptr(ws), ws.numel(),
+                                      stream_ptr(x.device)), "mi355_mixer_token_fwd")
+    return y
+
+
 def linear16_tr(xt16, w16, bias, resid, precision=None):
     """xt16 (B, C, K) 16-bit, w16 (N, K) -> fp32 (B, N, C) = resid + (xt16 @ w16^T + bias) transposed per image."""
     xt16 = _require16(xt16, "xt16", precision)

@@ -37,7 +37,10 @@ class MixerLayer(nn.Module):
         t = self.token_mlp
         p = F._prec(self.precision)
         T, N = t.fc1.weight.shape
-        if p in (F.PREC_FP16, F.PREC_BF16) and T % 64 == 0 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024:
+        if x.dim() == 3 and t.fc1.bias is not None and t.fc2.bias is not None and F.mixer_token_ok(N, T, x.shape[-1], self.precision):
+            # the whole half in one kernel: neither LN(x)^T nor the hidden tensor exists in HBM (csrc/mixer_fused.hip)
+            x = F.mixer_token_mlp(x.contiguous(), self.norm1, t.fc1, t.fc2, p)
+        elif p in (F.PREC_FP16, F.PREC_BF16) and T % 64 == 0 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024:
             # channel-major on the 16-bit GEMM engine: LN(x)^T (B,C,NP) -> gelu(. W1^T + b1) (B,C,T) -> (. W2^T + b2)^T + x
             NP = -(-N // 64) * 64
             ut = F.layernorm16_t(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, NP, p)

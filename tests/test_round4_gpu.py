@@ -311,3 +311,64 @@ def test_lpi_patch_kernel_against_the_general_kernel_and_the_oracle(C, with_ln, 
     if with_tail:
         ref = x + gamma * ref
     assert_parity(y1.cpu(), ref, 2e-5, "patch kernel vs oracle")
+
+
+# ---- MixerLayer token mixing in one kernel (csrc/mixer_fused.hip; option "mixer_fused") -----------------------------------------------
+@pytest.mark.parametrize("prec,tol", [(1, 1e-3), (2, 8e-3)])
+@pytest.mark.parametrize("B,C", [(1, 256), (5, 512), (3, 768)])
+def test_mixer_token_mixing_in_one_kernel(B, C, prec, tol):
+    """N = 196 tokens, T = C / 2 hidden token units (128 / 256 / 384): the fused half (row statistics + one kernel) against the three-launch path it replaces,
+    against the oracle of the whole layer, run-to-run bit identity, and an image's independence of its batch."""
+    import mi355attn
+    from mi355attn.modules import MixerLayer
+    torch.manual_seed(B * 1000 + C)
+    m = MixerLayer(C, 196, precision=prec).eval()
+    with torch.no_grad():
+        for ln in (m.norm1, m.norm2):
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.normal_(0, 0.2)
+        m.token_mlp.fc1.bias.normal_(0, 0.3)
+        m.token_mlp.fc2.bias.normal_(0, 0.3)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(B, 196, C) * 1.3 + 0.2
+    ref = O.mixer_layer_forward(x, sd)
+    m = m.cuda()
+    xd = x.cuda()
+    old = mi355attn.get_option("mixer_fused")
+    try:
+        with torch.no_grad():
+            mi355attn.set_option("mixer_fused", 1)
+            out = [None]
+
+            def run():
+                out[0] = m(xd)
+            tags = [t for t, *_ in mi355attn.kernel_trace(run)]
+            assert any("mixer_token_kernel" in t for t in tags), tags
+            assert not any("layernorm16_t" in t for t in tags), tags
+            y1 = out[0]
+            y1b = m(xd)
+            y_last = m(xd[B - 1:].contiguous())
+            mi355attn.set_option("mixer_fused", 0)
+            y0 = m(xd)
+    finally:
+        mi355attn.set_option("mixer_fused", old)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y1, y1b), "run-to-run difference"
+    assert torch.equal(y1[B - 1:], y_last), "an image's bits depend on the batch"
+    assert_parity(y1.cpu(), ref, tol, "fused token mixing vs oracle")
+    assert_parity(y0.cpu(), ref, tol, "three-launch token mixing vs oracle")
+    assert_parity(y1.cpu(), y0.cpu(), tol, "fused vs three launches")
+
+
+def test_mixer_token_entry_refuses_other_geometries():
+    import ctypes
+    import mi355attn
+    from mi355attn import _ffi
+    L = _ffi.lib()
+    x = torch.zeros(1, 49, 256, device="cuda")
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = lambda t_: ctypes.c_void_p(t_.data_ptr())
+    rc = L.mi355_mixer_token_fwd(p(x), p(buf), p(buf), 1e-5, p(buf), p(buf), p(buf), p(buf), p(x), 1, 49, 256, 256, 1, p(buf), 1 << 16,
+                                 _ffi.stream_ptr(None))
+    assert rc == -2, rc          # MI355_EUNSUPPORTED (include/mi355attn.h)
