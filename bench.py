@@ -21,6 +21,16 @@ bytes or FLOPs of the block / its average duration measured with 
 `roofline` is the one of the slowest block of the step.  `cpu_baseline` = the oracle (torch-CPU restatement of the reference
 forward; /root/reference does not exist on the GPU box) timed on this host's cores on a bounded sample of the same step
 (rank 0, N = 1 only).
+
+Shape of the line (round 5; the driver's record keeps scalar leaves and a ~9 KB tail, so everything that must survive is a SCALAR and the
+line stays under 8 KB): `config.ms_<key>` / `config.frac_<key>` / `config.strict_ms_<key>` for every block (keys SE, CBAM, ECA, ViTAttn,
+CSWin_s1..s4, XCABlock, XCA, DA64, DA256, Mixer, ViTBase); `config.ms_window_1..3` = THREE consecutive windows of --steps steps, each
+between barrier + synchronize pairs (`ms_per_step` / `value` are window 1, the contract's timed region; 2 and 3 show drift of a cold or
+power-managed box); box calibration before and after the timed region: `config.stream_copy_GBps_{before,after}`,
+`config.mfma_{16x16x32,32x32x16}_TFLOPs_{before,after}` (register-operand MFMA loops: what THIS box's matrix pipes sustain),
+`config.sclk_MHz_{counter,issue}_*` (shader clock under that load, two independent readings) and `config.smi_{idle,load}_*` (clock /
+power / temperature from sysfs or amd-smi, idle and while windows 2-3 run).  The per-block list is the LAST key; `--detail FILE` writes
+the verbose records (per-kernel tally table, CPU probe times, calibration) next to the line.
 """
 import argparse
 import json
@@ -59,6 +69,13 @@ def parse_args(argv=None):
                     help="end-of-forward all-gather of the ViT logits: 'capi' = mi355_allgather_f32 (RCCL behind the C ABI), 'torch' = "
                          "torch.distributed all_gather_into_tensor, 'auto' (default) = capi when its start-up self-test passes on every "
                          "rank, else torch -- the choice is reported in config.gather")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for N > 1: 'nccl' (= RCCL over xGMI, one GPU per rank: the default and what a multi-GPU node "
+                         "runs) or 'gloo' (host-side barrier / max-reduce / gather; ranks may SHARE a GPU, rank r uses GPU r mod visible: lets "
+                         "the whole N > 1 path -- self-launch, barrier-bracketed timing, ranks_seen, end-of-forward gather -- run end to end "
+                         "with the real kernels on a one-GPU box)")
+    ap.add_argument("--no-calib", action="store_true", help="skip the box calibration (MFMA / copy yardsticks, telemetry)")
+    ap.add_argument("--detail", default=None, help="also write the line + the verbose per-block / per-kernel / CPU-leg records to this JSON file")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + barrier + max-reduce of an empty step on the gloo backend, no GPU work: what the CPU tests "
                          "use to check that --gpus N really runs N ranks")
@@ -150,26 +167,19 @@ def load_pmc_traffic():
 def workload_c2(B, dev):
     import torch
     from mi355attn.modules import CBAM, ECALayer, SELayer
-    import oracle as O
+    from oracle import aten_seq as A
     C, H, W = 256, 56, 56
     torch.manual_seed(4321)
     x = torch.randn(B, C, H, W, device=dev)
     nbytes = 2 * B * C * H * W * 4                      # read x once + write y once
     se, cb, ec = _seeded(lambda: SELayer(C)), _seeded(lambda: CBAM(C)), _seeded(lambda: ECALayer(C))
 
-    def cpu_se(xs, m=se):
-        return O.se_forward(xs, m.fc[0].weight.cpu(), m.fc[2].weight.cpu())
-
-    def cpu_cb(xs, m=cb):
-        return O.cbam_forward(xs, m.ca.fc[0].weight.cpu(), m.ca.fc[2].weight.cpu(), m.sa.conv.weight.cpu())
-
-    def cpu_ec(xs, m=ec):
-        return O.eca_forward(xs, m.conv.weight.cpu())
-
+    sds = [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in (se, cb, ec)]
+    note = "ATen-operator-sequence restatement of the reference forward (oracle/aten_seq.py)"
     blocks = [
-        dict(name="SELayer(256)", module=se.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_se, cpu_n=64),
-        dict(name="CBAM(256)", module=cb.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_cb, cpu_n=64),
-        dict(name="ECALayer(256)", module=ec.to(dev), x=x, bound="hbm", work=nbytes, cpu=cpu_ec, cpu_n=64),
+        dict(name="SELayer(256)", key="SE", module=se.to(dev), x=x, bound="hbm", work=nbytes, cpu=lambda xs: A.se_aten(xs, sds[0]), cpu_n=64, cpu_note=note),
+        dict(name="CBAM(256)", key="CBAM", module=cb.to(dev), x=x, bound="hbm", work=nbytes, cpu=lambda xs: A.cbam_aten(xs, sds[1]), cpu_n=64, cpu_note=note),
+        dict(name="ECALayer(256)", key="ECA", module=ec.to(dev), x=x, bound="hbm", work=nbytes, cpu=lambda xs: A.eca_aten(xs, sds[2]), cpu_n=64, cpu_note=note),
     ]
     return dict(name="SELayer+CBAM+ECALayer fwd, x=(%d,256,56,56) fp32 per GPU (BASELINE configs[1])" % B,
                 blocks=blocks, dtype="f32")
@@ -181,9 +191,7 @@ def workload_all(B, dev):
     parts = [workload_c2(B, dev), W.workload_c3(B, dev), W.workload_c4(B, dev), W.workload_da(B, dev), W.workload_mixer(B, dev),
              W.workload_c5(B, dev)]
     blocks = [b for p in parts for b in p["blocks"]]
-    return dict(name="north-star step: SELayer+CBAM+ECALayer (C2) + ViT Attention (C3) + CSWinBlock s1-s4 + XCABlock/XCA (C4) + "
-                     "DoubleAttention x2 + MixerLayer (class-surface rows without a BASELINE config) + ViT-Base/16 full forward with "
-                     "logits all-gather (C5), B=%d per GPU (BASELINE configs[1..4])" % B,
+    return dict(name="north-star step: C2 SE+CBAM+ECA, C3 ViT-Attn, C4 CSWin s1-4 + XCABlock + XCA, DA x2, Mixer, C5 ViT-Base fwd; B=%d/GPU" % B,
                 blocks=blocks, dtype="f32/f16")
 
 
@@ -227,6 +235,31 @@ def launch_check(args, rank, world):
         dist.destroy_process_group()
 
 
+def yardsticks(dev, src):
+    """Box calibration: float4 streaming copy of the C2 footprint + the register-operand MFMA loops (both instruction shapes),
+    each ~40 ms.  Flat scalars."""
+    import torch
+    from mi355attn import StreamTimer
+    from mi355attn import functional as F
+    out = {}
+    if src is not None and src.numel() * 4 % 16 == 0 and src.numel() * 4 >= (1 << 26):
+        dst = torch.empty_like(src)
+        F.stream_copy(src, dst)
+        torch.cuda.synchronize()
+        tm = StreamTimer(dev)
+        tm.start()
+        for _ in range(10):
+            F.stream_copy(src, dst)
+        cms = tm.stop_ms() / 10
+        out["stream_copy_GBps"] = round(2 * src.numel() * 4 / (cms * 1e-3) / 1e9, 1)
+        del dst
+    y0 = F.mfma_yardstick(dev, 0)
+    y1 = F.mfma_yardstick(dev, 1)
+    out.update({"mfma_16x16x32_TFLOPs": y0["TFLOPs"], "mfma_32x32x16_TFLOPs": y1["TFLOPs"], "sclk_MHz_counter": y1["sclk_MHz_counter"],
+                "sclk_MHz_issue": y1.get("sclk_MHz_issue")})
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -242,18 +275,25 @@ def main(argv=None):
         return launch_check(args, rank, world)
 
     import torch
+    import bench_telemetry as tele
     _extra_workloads()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
-    if torch.cuda.device_count() < world:
-        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    shared_gpu = args.dist_backend == "gloo"                 # ranks may share a GPU (host-side collectives): N > visible GPUs is allowed
+    if ndev < world and not shared_gpu:
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible (use --dist-backend gloo to let ranks share a GPU)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mi355attn
     from mi355attn import StreamTimer
@@ -270,7 +310,9 @@ def main(argv=None):
         mi355attn.set_default_precision(args.precision)
 
     comm, gather_kind, comm_ok = None, "none (single rank)", False
-    if dist is not None:
+    if dist is not None and shared_gpu:
+        gather_kind = "gloo all_gather staged through the host (--dist-backend gloo)"
+    elif dist is not None:
         gather_kind = "torch.distributed all_gather_into_tensor (RCCL)"
         if args.gather in ("auto", "capi"):
             comm, why = make_comm(dist, dev, rank, world)
@@ -280,7 +322,7 @@ def main(argv=None):
             elif args.gather == "capi":
                 raise SystemExit("--gather capi: " + why)
             else:
-                gather_kind += " [C-ABI communicator self-test failed: %s]" % why
+                gather_kind += " [C-ABI communicator self-test failed: %s]" % why[:60]
 
     wl = WORKLOADS[args.workload](args.batch, dev)
     wname, blocks = wl["name"], wl["blocks"]
@@ -292,6 +334,8 @@ def main(argv=None):
         wname += " [only: %s]" % args.only
         if not blocks:
             raise SystemExit("--only matched no block")
+    for b in blocks:
+        b.setdefault("key", "".join(c for c in b["name"].split("(")[0] if c.isalnum()))
 
     def run_block(b):
         y = b["module"](b["x"], *b.get("fwd_args", ()))
@@ -304,25 +348,55 @@ def main(argv=None):
         with torch.no_grad():
             return [run_block(b) for b in blocks]
 
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def window():
+        """K steps bracketed by barrier + synchronize on both sides; seconds on this rank."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return time.perf_counter() - t0
+
+    # ---- box calibration BEFORE the timed region (rank 0 measures, every rank waits): yardsticks + telemetry -------------------------
+    card = None
+    try:
+        card = tele.find_card(getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
+    except Exception:                                        # noqa: BLE001  (telemetry is best effort)
+        card = tele.find_card()
+    calib = {}
+    want_calib = rank == 0 and not args.only and not args.no_calib
+    if want_calib:
+        calib["idle"] = tele.snapshot(card)
+        src = blocks[0]["x"].reshape(-1) if blocks[0]["x"].dtype == torch.float32 else None
+        calib["before"] = yardsticks(dev, src)
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    local_elapsed = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    # THE timed region of the contract: W warm-up steps, then exactly K steps between barrier + synchronize pairs, max over ranks
+    elapsed = local_elapsed = window()
+    # two more windows of K steps right behind it (same bracket): drift of a cold / power-managed box shows as a trend across the three
+    sampler = tele.LoadSampler(card) if want_calib else None
+    if sampler is not None:
+        sampler.start()
+    extra = [window() for _ in range(0 if args.only else 2)]
+    if sampler is not None:
+        calib["load"] = sampler.stop()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
+    extra = [max_over_ranks(e) for e in extra]
 
     # per-block durations with HIP events on the launch stream (un-timed extra passes)
     pmc, pmc_note = load_pmc_traffic()
@@ -345,12 +419,10 @@ def main(argv=None):
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = b["work"] / (ms * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
-        rec = dict(block=b["name"], ms=round(ms, 4), images_per_s=round(args.batch / (ms * 1e-3), 1),
-                   bound=b["bound"], achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
-                   traffic=pmc.get(b["name"]))
+        rec = dict(block=b["name"], key=b["key"], ms=round(ms, 4), bound=b["bound"], achieved=round(ach, 1), unit=unit,
+                   frac=round(ach / peak, 4), traffic=pmc.get(b["name"]))
         if b.get("alt_work"):                                 # mixed blocks: the FLOP rate next to the HBM figure
-            rec["alt_achieved_TFLOPs"] = round(b["alt_work"] / (ms * 1e-3) / 1e12, 2)
-            rec["alt_frac_mfma"] = round(b["alt_work"] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+            rec["alt_TFLOPs"] = round(b["alt_work"] / (ms * 1e-3) / 1e12, 1)
         per_block.append(rec)
     # the fp32-class cost of the MFMA blocks (precision 0: bf16 hi/lo split, three MFMAs per product): a few un-timed passes per block
     if mi355attn.default_precision() != 0 and not args.no_strict and not args.only:
@@ -363,29 +435,13 @@ def main(argv=None):
             mi355attn.set_default_precision(1 if args.precision is None else args.precision)
     dominant = None
 
-    # achievable-bandwidth yardstick: float4 streaming copy of the same footprint
-    copy_gbs = None
-    if rank == 0:
-        from mi355attn import functional as F
-        src = blocks[0]["x"].reshape(-1)
-        if src.numel() * 4 % 16 == 0 and src.numel() * 4 >= (1 << 26):
-            dst = torch.empty_like(src)
-            F.stream_copy(src, dst)
-            torch.cuda.synchronize()
-            tm = StreamTimer(dev)
-            tm.start()
-            for _ in range(10):
-                F.stream_copy(src, dst)
-            cms = tm.stop_ms() / 10
-            copy_gbs = round(2 * src.numel() * 4 / (cms * 1e-3) / 1e9, 1)
-            del dst
-
-    rank_ms, ranks_seen = [round(local_elapsed / args.steps * 1e3, 4)], [rank]
+    rank_ms, ranks_seen, rank_devs = [round(local_elapsed / args.steps * 1e3, 4)], [rank], [dev_index]
     if dist is not None:
         ms_all = [None] * world
         dist.all_gather_object(ms_all, (rank, round(local_elapsed / args.steps * 1e3, 4), torch.cuda.current_device()))
         ranks_seen = sorted(r for r, _, _ in ms_all)
         rank_ms = [m for _, m, _ in sorted(ms_all)]
+        rank_devs = [d for _, _, d in sorted(ms_all)]
     if comm is not None:
         comm.close()
     if rank != 0:
@@ -396,35 +452,73 @@ def main(argv=None):
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
     dom = max(per_block, key=lambda r: r["ms"])
-    if rank == 0 and not args.only:                            # --only runs feed the PMC passes: block kernels only
+    if not args.only:                                          # --only runs feed the PMC passes: block kernels only
         dominant = dominant_kernel_tally(blocks[per_block.index(dom)], run_block, args, dom["ms"])
+    if want_calib:
+        calib["after"] = yardsticks(dev, blocks[0]["x"].reshape(-1) if blocks[0]["x"].dtype == torch.float32 else None)
+
+    # ---- the line: scalars first (the driver's record keeps scalar leaves), the per-block list LAST -------------------------------------
+    cfg = {"workload": wname, "batch_per_gpu": args.batch, "parallelism": "batch-shard x%d" % world,
+           "precision": {0: "strict(bf16x3)", 1: "fp16-mfma", 2: "bf16-mfma"}[mi355attn.default_precision()],
+           "dist_backend": "none" if world == 1 else args.dist_backend, "gather": gather_kind,
+           "rccl_self_test": ("passed on every rank" if comm_ok else ("not run (single rank)" if world == 1 else
+                              ("not run (gloo backend)" if shared_gpu else "FAILED or skipped: see gather"))),
+           "ranks_seen": len(ranks_seen), "ms_window_1": round(ms_per_step, 4)}
+    for i, e in enumerate(extra):
+        cfg["ms_window_%d" % (i + 2)] = round(e / args.steps * 1e3, 4)
+    for rec in per_block:                                      # every block as SCALAR keys: ms / fraction of its roofline / fp32-class ms
+        cfg["ms_" + rec["key"]] = rec["ms"]
+        cfg["frac_" + rec["key"]] = rec["frac"]
+        if "strict_ms" in rec:
+            cfg["strict_ms_" + rec["key"]] = rec["strict_ms"]
+    for phase in ("before", "after"):
+        for k, v in calib.get(phase, {}).items():
+            cfg["%s_%s" % (k, phase)] = v
+    for phase in ("idle", "load"):
+        for k, v in calib.get(phase, {}).items():
+            cfg["smi_%s_%s" % (phase, k)] = v
+    cfg["traffic_source"] = pmc_note[:110]
+    roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_PEAK_TFLOPS,
+            "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"], "block": dom["block"],
+            "kernel": dominant["name"] if dominant else dom["block"], "ms": dom["ms"]}
+    if dominant:                                               # the dominant kernel's own figures, flat; its per-tag table goes to --detail
+        for k in ("launches_per_forward", "avg_us", "us_per_forward", "share_of_block", "traced_us_per_forward", "achieved", "frac"):
+            if k in dominant:
+                roof["kernel_" + k] = dominant[k]
     out = {
-        "metric": "forward images/sec through one step (+ ms/block), B=%d per GPU, 224x224-derived shapes; CPU leg = oracle port "
-                  "of the reference forward on this host" % args.batch,
+        "metric": "forward images/sec through one step (+ ms/block), B=%d per GPU, 224x224-derived shapes" % args.batch,
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": wl.get("dtype", "f32") if wl.get("dtype", "f32") in ("f32", "f32/f16")
         else {0: "bf16x3", 1: "f16", 2: "bf16"}[mi355attn.default_precision()],
         "data": "synthetic (torch.randn seed 4321; module-default init seed 1234)",
-        "config": {"workload": wname, "batch_per_gpu": args.batch, "parallelism": "batch-shard x%d" % world,
-                   "chunk_images": mi355attn.get_option("chunk_images"), "nt": mi355attn.get_option("nt"),
-                   "reverse": mi355attn.get_option("reverse"),
-                   "precision": {0: "strict(bf16x3)", 1: "fp16-mfma", 2: "bf16-mfma"}[mi355attn.default_precision()],
-                   "gather": gather_kind, "ranks_seen": ranks_seen, "ms_per_step_by_rank": rank_ms,
-                   "rccl_self_test": ("passed on every rank" if comm_ok else ("not run (single rank)" if world == 1 else "FAILED or skipped: see gather")),
-                   "blocks": per_block, "stream_copy_GBps": copy_gbs, "traffic_source": pmc_note},
+        "config": cfg,
         # `roofline` grades the slowest BLOCK of the step (a block is many launches: `block` names it, achieved / frac are the block's);
-        # `kernel` names the one kernel that takes the largest share of that block and `dominant_kernel` carries its own figures, both
-        # from an in-process HIP-event tally of the block's own launches
-        "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                     "frac": dom["frac"], "traffic": dom["traffic"], "block": dom["block"],
-                     "kernel": dominant["name"] if dominant else dom["block"], "ms": dom["ms"], "dominant_kernel": dominant},
+        # `kernel` names the one kernel that takes the largest share of that block, its own figures are the kernel_* keys: all from an
+        # in-process HIP-event tally of the block's own launches
+        "roofline": roof,
     }
+    detail = {"ms_per_step_by_rank": rank_ms, "ranks": ranks_seen, "rank_devices": rank_devs, "ms_windows": [round(ms_per_step, 4)] +
+              [round(e / args.steps * 1e3, 4) for e in extra], "calibration": calib, "dominant_kernel": dominant, "blocks": per_block}
 
     sys.stderr.write("[bench] GPU part done %.1f s after start\n" % (time.perf_counter() - T_START))
     if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(blocks, args)
-    print(json.dumps(out))
+        cpu, cpu_detail = cpu_baseline(blocks, args)
+        out["cpu_baseline"] = cpu
+        detail["cpu_blocks"] = cpu_detail
+    out["ms_per_step_by_rank"] = rank_ms
+    out["ms_windows"] = detail["ms_windows"]
+    out["blocks"] = [{k: v for k, v in r.items() if k != "bound"} for r in per_block]
+    line = json.dumps(out, separators=(",", ":"))
+    if args.detail:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, "w") as f:
+                json.dump({"line": out, "detail": detail}, f, indent=1)
+        except OSError as e:
+            sys.stderr.write("[bench] --detail %s not written: %s\n" % (args.detail, e))
+    sys.stderr.write("[bench] JSON line: %d bytes\n" % len(line))
+    print(line)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -477,7 +571,7 @@ def dominant_kernel_tally(block, run_block, args, ms_block):
         out.update({"achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)})
     for r in table:
         r.pop("flop", None)
-    out["kernels"] = table[:12]
+    out["kernels"] = table[:16]
     return out
 
 
@@ -507,54 +601,66 @@ def make_comm(dist, dev, rank, world):
 
 
 def cpu_baseline(blocks, args):
-    """The oracle on this host's cores, per block on a bounded sample (`cpu_n` images of the same batch), median of 3 after one
-    warm-up.  value = images/s through the same step = 1 / sum_b (t_b / n_b)."""
+    """The reference's CPU path beside the GPU numbers: per block, the ATen-operator-sequence restatement of the reference forward
+    (oracle/aten_seq.py, oracle/cswin.py *_aten: /root/reference does not exist on the GPU box, hence kind "port") on this host's cores,
+    on the first n images of the same batch.  The torch thread count is probed PER BLOCK over {8, 16, 32, 64, 128} (capped at the
+    host's hardware threads) ON THE TIMED SAMPLE -- one pass per count, every count tried unless the block has already used its time
+    budget -- then best of 2 more passes at the fastest count.  value = images/s through the same step = 1 / sum_b (t_b / n_b).
+    Returns (flat record for the line, verbose per-block list for --detail)."""
     import torch
     cores, threads, model = host_cpu_info()
-    # The torch thread count that is fastest differs per block on a big dual-socket host (all 128 cores suit the streaming channel
-    # attention, 16-32 the transformer blocks: with 128 threads ViT-Base ran 6x slower than with 32), so it is probed PER BLOCK:
-    # one pass per candidate count on the block's sample, then median of 3 at the best one.
-    cands = sorted({min(threads, n) for n in (32, 64, 128, 256)})
-    per_image, reps, detail, used = 0.0, 2, [], 0
-    for b in blocks:
-        t_blk = time.perf_counter()
-        ns = min(args.cpu_sample or b.get("cpu_n", 64), b["x"].shape[0])
-        xs = b["x"][:ns].cpu()
-        # thread count: probed on the first 4 images of the sample (one warm-up at the first count, then one pass per candidate), so
-        # that the slow candidates -- 256 threads on the transformer blocks -- cost seconds, not minutes; the timed passes then run
-        # the whole sample at the winner
-        xp = xs[:min(4, ns)]
-        torch.set_num_threads(cands[0])
-        b["cpu"](xp)
-        best_t, best_n = None, cands[0]
-        for nthr in cands:                                     # ascending; a count 1.5x slower than the best ends the probe (on the
-            torch.set_num_threads(nthr)                        # transformer blocks 128 / 256 threads are 6-20x slower than 32: minutes per pass)
-            t1 = time.perf_counter()
-            b["cpu"](xp)
-            dt = time.perf_counter() - t1
-            if best_t is None or dt < best_t:
-                best_t, best_n = dt, nthr
-            elif dt > 1.5 * best_t:
-                break
-        torch.set_num_threads(best_n)
-        used = max(used, best_n)
-        ts = []
-        for _ in range(reps):                                  # the first pass doubles as the warm-up at the sample size: best of `reps`
-            t1 = time.perf_counter()
-            b["cpu"](xs)
-            ts.append(time.perf_counter() - t1)
-        ts.sort()
-        sys.stderr.write("[bench] cpu leg %-42s probe+passes %.1f s (threads %d)\n" % (b["name"], time.perf_counter() - t_blk, best_n))
-        per_image += ts[0] / ns
-        detail.append({"block": b["name"], "images": ns, "threads": best_n, "images_per_s": round(ns / ts[0], 1),
-                       "note": b.get("cpu_note", "oracle restatement (same math as the reference forward, not its exact operator sequence)")})
-    return {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
-            "host_cores": cores, "host_threads": threads, "host_cpu": model, "blocks": detail,
-            "sample": "oracle (torch-CPU restatement of the reference forward; the reference checkout does not exist on the GPU box) "
-                      "on the first n images of the same batch per block (n listed per block: 64), best of %d passes, torch "
-                      "threads probed per block over {32, 64, 128, 256} in ascending order on the first 4 images (the probe ends at the first count 1.5x slower than the best) (capped at the host's hardware threads; listed per block; `cores` = the largest count used), host has "
-                      "%d cores / %d hardware threads"
-                      % (reps, cores, threads)}
+    cands = sorted({min(threads, n) for n in (8, 16, 32, 64, 128)})
+    budget_s = float(os.environ.get("MI355_CPU_BLOCK_BUDGET_S", "10"))
+    per_image, detail, used, flat = 0.0, [], 0, {}
+    with torch.no_grad():
+        for b in blocks:
+            t_blk = time.perf_counter()
+            ns = min(args.cpu_sample or b.get("cpu_n", 32), b["x"].shape[0])
+            xs = b["x"][:ns].cpu()
+            torch.set_num_threads(cands[min(2, len(cands) - 1)])
+            b["cpu"](xs[:max(1, ns // 8)])                     # first touch of the weights / code paths, small
+            probe = {}
+            for nthr in cands:
+                if probe and time.perf_counter() - t_blk > budget_s:
+                    break                                      # budget used: the remaining (larger) counts are not tried, said in `probe`
+                torch.set_num_threads(nthr)
+                t1 = time.perf_counter()
+                b["cpu"](xs)
+                probe[nthr] = time.perf_counter() - t1
+            best_n = min(probe, key=probe.get)
+            torch.set_num_threads(best_n)
+            used = max(used, best_n)
+            ts = [probe[best_n]]
+            for _ in range(2):
+                if time.perf_counter() - t_blk > 2 * budget_s:
+                    break
+                t1 = time.perf_counter()
+                b["cpu"](xs)
+                ts.append(time.perf_counter() - t1)
+            t = min(ts)
+            per_image += t / ns
+            flop = b.get("alt_work") or (b["work"] if b["bound"] == "mfma" else None)
+            rec = {"block": b["name"], "key": b["key"], "images": ns, "threads": best_n, "images_per_s": round(ns / t, 1),
+                   "probe_s": {str(k): round(v, 3) for k, v in probe.items()},
+                   "note": b.get("cpu_note", "oracle restatement (same math as the reference forward, not its exact operator sequence)")}
+            flat["img_s_" + b["key"]] = rec["images_per_s"]
+            flat["thr_" + b["key"]] = best_n
+            if flop:                                            # achieved host rate, so that a reader can see the baseline is sane
+                rec["GFLOPs"] = round(flop / b["x"].shape[0] * ns / t / 1e9, 1)
+                flat["GFLOPs_" + b["key"]] = rec["GFLOPs"]
+            else:
+                rec["GBps"] = round(b["work"] / b["x"].shape[0] * ns / t / 1e9, 1)
+                flat["GBps_" + b["key"]] = rec["GBps"]
+            detail.append(rec)
+            sys.stderr.write("[bench] cpu leg %-42s %.1f s (threads %d of probe %s)\n" % (b["name"], time.perf_counter() - t_blk, best_n,
+                                                                                         sorted(probe)))
+    out = {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
+           "host_cores": cores, "host_threads": threads, "host_cpu": model,
+           "sample": "first n images of the same batch per block (n = 64 C2 / 32 others), best of <= 3 passes, threads probed per block"}
+    out.update(flat)
+    out["legend"] = ("img_s_* / thr_* / GFLOPs_* (GBps_* for the HBM-bound blocks) per block key; ATen-operator-sequence restatements of the "
+                     "reference forward (oracle/aten_seq.py); threads probed over {8,16,32,64,128} on the timed sample; cores = largest count used")
+    return out, detail
 
 
 if __name__ == "__main__":

@@ -7,6 +7,9 @@ bf16/fp16 MFMA peak regardless of the precision mode in use).
 import torch
 
 import oracle as O
+from oracle import aten_seq as A
+
+ATEN_NOTE = "ATen-operator-sequence restatement of the reference forward (oracle/aten_seq.py: the same fused layer_norm / linear / gelu / softmax / batched matmul calls in the same order)"
 
 
 def _seeded(ctor, seed=1234):
@@ -24,8 +27,8 @@ def workload_c3(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 197, 768, device=dev)
     sd = _sd(m)
-    blocks = [dict(name="ViT Attention(768,h12)", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=64,
-                   cpu=lambda xs: O.vit_attention_forward(xs, sd, 12))]
+    blocks = [dict(name="ViT Attention(768,h12)", key="ViTAttn", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=32,
+                   cpu=lambda xs: A.vit_attention_aten(xs, sd, 12), cpu_note=ATEN_NOTE)]
     return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, dtype="f16")
 
 
@@ -44,7 +47,7 @@ def workload_c4(B, dev):
         m = _seeded(lambda: CSWinBlock(*args, **kw))
         torch.manual_seed(4321)
         x = torch.randn(B, *shp, device=dev)
-        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=64,
+        blocks.append(dict(name=name, key="CSWin_" + name.split()[1], module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=32,
                            cpu_note="ATen-sequence restatement (strided window views, bmm, softmax, grouped conv2d, fused layer_norm / linear / "
                                     "gelu): the operator sequence of cswin.py:101-127,176-197; within 0.9-1.4x of the real reference on the "
                                     "build container's CPU"))
@@ -53,10 +56,10 @@ def workload_c4(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 196, 384, device=dev)
     sdb, sda = _sd(xb), _sd(xa)
-    blocks.append(dict(name="XCABlock(384,h8)", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B, cpu_n=64,
-                       cpu=lambda xs: O.xca_block_forward(xs, sdb, 8, 14, 14)))
-    blocks.append(dict(name="XCA(384,h8)", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B, cpu_n=64,
-                       cpu=lambda xs: O.xca_forward(xs, sda, 8)))
+    blocks.append(dict(name="XCABlock(384,h8)", key="XCABlock", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B,
+                       cpu_n=32, cpu=lambda xs: A.xca_block_aten(xs, sdb, 8, 14, 14), cpu_note=ATEN_NOTE))
+    blocks.append(dict(name="XCA(384,h8)", key="XCA", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B,
+                       cpu_n=32, cpu=lambda xs: A.xca_aten(xs, sda, 8), cpu_note=ATEN_NOTE))
     return dict(name="CSWin-T blocks s1-s4 + XCiT-S XCABlock/XCA fwd, B=%d (BASELINE configs[3])" % B, blocks=blocks,
                 dtype="f16")
 
@@ -69,8 +72,8 @@ def workload_c5(B, dev):
     sd = _sd(m)
 
     # gather=True: bench.py all-gathers this block's logits (mi355attn.dist.gather_batch: one RCCL all-gather over xGMI, 1 MB per rank)
-    blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
-                   cpu=lambda xs: O.vit_forward(xs, sd, 12, 12), cpu_n=64, gather=True)]
+    blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", key="ViTBase", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
+                   cpu=lambda xs: A.vit_aten(xs, sd, 12, 12), cpu_n=32, gather=True, cpu_note=ATEN_NOTE)]
     return dict(name="ViT-Base full fwd, %d images per GPU, logits all-gathered (BASELINE configs[4])" % B, blocks=blocks,
                 gather=True, dtype="f16")
 
@@ -81,8 +84,8 @@ def workload_mixer(B, dev):
     torch.manual_seed(4321)
     x = torch.randn(B, 196, 512, device=dev)
     sd = _sd(m)
-    blocks = [dict(name="MixerLayer(512,196)", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B, cpu_n=64,
-                   cpu=lambda xs: O.mixer_layer_forward(xs, sd))]
+    blocks = [dict(name="MixerLayer(512,196)", key="Mixer", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B, cpu_n=32,
+                   cpu=lambda xs: A.mixer_layer_aten(xs, sd), cpu_note=ATEN_NOTE)]
     return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, dtype="f16")
 
 
@@ -97,13 +100,11 @@ def workload_da(B, dev):
         if not flop:
             n = hw * hw
             flop = 2.0 * n * ((cm + 2 * cn) * C + cm * cn * 2 + C * cm)
-        keys = ("convA.weight", "convA.bias", "convB.weight", "convB.bias", "convV.weight", "convV.bias", "proj.weight",
-                "proj.bias")
         # DoubleAttention is a mixed block -- graded on the HBM roofline (algorithmic bytes = read x + write y), FLOP rate
         # reported next to it (alt_*)
-        blocks.append(dict(name="DoubleAttention(%d,%d,%d)@%dx%d" % (C, cm, cn, hw, hw), module=m.to(dev), x=x, bound="hbm",
-                           work=2.0 * C * hw * hw * 4 * B, alt_work=flop * B, cpu_n=64,
-                           cpu=(lambda sd_: (lambda xs: O.double_attention_forward(xs, *[sd_[k] for k in keys])))(sd)))
+        blocks.append(dict(name="DoubleAttention(%d,%d,%d)@%dx%d" % (C, cm, cn, hw, hw), key="DA%d" % C, module=m.to(dev), x=x, bound="hbm",
+                           work=2.0 * C * hw * hw * 4 * B, alt_work=flop * B, cpu_n=32 if C > 64 else 64,
+                           cpu=(lambda sd_: (lambda xs: A.double_attention_aten(xs, sd_)))(sd), cpu_note=ATEN_NOTE))
     return dict(name="DoubleAttention fwd, B=%d" % B, blocks=blocks, dtype="f16")
 
 
@@ -113,8 +114,8 @@ def _full_model(ctor, title, flop_per_image, cpu_fn, B, dev):
     x = torch.randn(B, 3, 224, 224, device=dev)
     sd = _sd(m)
 
-    blocks = [dict(name=title, module=m.to(dev), x=x, bound="mfma", work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd), cpu_n=64,
-                   gather=True)]
+    blocks = [dict(name=title, key="".join(c for c in title.split("(")[0] if c.isalnum()), module=m.to(dev), x=x, bound="mfma",
+                   work=flop_per_image * B, cpu=lambda xs: cpu_fn(xs, sd), cpu_n=32, gather=True)]
     return dict(name="%s full fwd, %d images per GPU, logits all-gathered" % (title, B), blocks=blocks, gather=True, dtype="f16")
 
 
@@ -168,7 +169,7 @@ def workload_zoo(B, dev):
             cpu = (lambda s: (lambda xs: O.lct_forward(xs, s["w"], s["b"], 16)))(sd)
         else:
             cpu = (lambda s: (lambda xs: O.gct_forward(xs, s["alpha"], s["gamma"], s["beta"])))(sd)
-        blocks.append(dict(name=name, module=m.to(dev), x=x, bound="hbm", work=nbytes * B, cpu=cpu))
+        blocks.append(dict(name=name, key=name.split("(")[0], module=m.to(dev), x=x, bound="hbm", work=nbytes * B, cpu=cpu))
     return dict(name="SimAM+SRM+GaussianGCT+LCT+GCT fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, dtype="f32")
 
 
@@ -199,7 +200,7 @@ def workload_zoo2(B, dev):
         m.eval()
         sd = _sd(m)
         cpu = (lambda f, s: (lambda xs: f(xs, s)))(orc, sd)
-        blocks.append(dict(name=name, module=m.to(dev), x=x, bound=bound, work=work * B, cpu=cpu))
+        blocks.append(dict(name=name, key=name.split("(")[0], module=m.to(dev), x=x, bound=bound, work=work * B, cpu=cpu))
     return dict(name="GC+CoordAtt+Triplet+BAM+SK+CAM fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, dtype="f32")
 
 

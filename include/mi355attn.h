@@ -108,6 +108,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   spread over all CUs (a second launch on the same stream; same K order, bit-identical results).
  *   "mixer_fused"   1 (default) = the host mirror's MixerLayer runs its token-mixing half through mi355_mixer_token_fwd where the
  *                   geometry allows (N = 196, T % 32 == 0, C % 256 == 0); 0 = three launches (transposing LayerNorm, fc1, transposed fc2).
+ *   "mixer_early"   mi355_mixer_token_fwd: 1 = the kernel issues the residual loads of its epilogue in two batches ahead of their stores (two
+ *                   exposed round trips instead of thirteen; bit-identical results); 0 (default) = a token tile's loads right before its stores.
  *   "lpi_patch"     1 (default) = mi355_lpi_fwd / mi355_ln_lpi_fwd at 14 x 14 tokens with C % 32 == 0 run the patch kernel (a lane owns a
  *                   2 x 2 token patch of one channel quad, taps in scalar registers, fused multiply-adds); 0 = the general kernel
  *                   (separately rounded products and sums: the two agree to ~1e-7 relative, not bit for bit).
@@ -122,8 +124,10 @@ long        mi355_get_option(const char* key);                      /* what a la
  * the attention cores, LayerNorm / cast / im2col passes, the XCiT kernels) on the calling thread's current device is bracketed by a
  * pair of HIP events on its launch stream.  mi355_trace_end waits for those launches and writes one line per kernel tag,
  *   "count\ttotal_us\tmin_us\tmax_us\ttag\n"   (largest total first; the tag = kernel name + the shape parameters that tell its
- * launches apart), NUL-terminated, truncated to report_bytes; it returns the size of the full report.  One trace at a time per
- * process; launches under hipGraph stream capture are not recorded.  What bench.py fills roofline.dominant_kernel from. */
+ * launches apart), NUL-terminated, truncated to report_bytes; it returns the size of the full report (without the NUL).  A report that did
+ * not fit -- or report == NULL -- is kept: size a buffer from the return value (+ 1) and call again; it is dropped once handed out whole
+ * or at the next mi355_trace_begin.  One trace at a time per process; launches under hipGraph stream capture are not recorded.  What
+ * bench.py fills roofline.dominant_kernel from. */
 int         mi355_trace_begin(void);
 long        mi355_trace_end(char* report, size_t report_bytes);
 /* Drop what the library remembers about workspaces inside [ws, ws + ws_bytes) ("ws_persistent"): call before freeing or
@@ -615,6 +619,13 @@ int mi355_bicubic_rows_fwd(const float* table, float* out, int n0h, int n0w, int
 int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t stream);
 /* read-only float4 sweep of `bytes` (sum-reduced, result discarded; `sink` is a 4-byte device scratch). */
 int mi355_stream_read(const void* src, size_t bytes, float* sink, mi355_stream_t stream);
+/* Box calibration for bench.py (SURVEY.md 8d "a measured MFMA microbench"): a register-operand MFMA loop, two 4-wave workgroups per CU,
+ * every wave `iters` x 8 independent v_mfma_f32_16x16x32_f16 (shape 0: a 32 x 64 wave tile, the engine's instruction) or `iters` x 4
+ * v_mfma_f32_32x32x16_f16 (shape 1: a 64 x 64 wave tile), operands random in [-1, 1) -- nothing but the matrix pipe, i.e. what THIS box
+ * sustains under dense MFMA load.  report (device, 3 x 8 bytes, written by workgroup 0): {shader-clock ticks, ticks of the constant 100 MHz
+ * counter} over the first wave's loop and the number of workgroups launched.  MFMA instructions of the launch = workgroups x 4 x iters x
+ * (8 | 4) at 16 384 | 32 768 FLOP each; the caller times the launch (mi355_event_time_*).  sink: 4 bytes of device scratch. */
+int mi355_mfma_yardstick(int shape, int iters, float* sink, unsigned long long* report, mi355_stream_t stream);
 /* HIP-event stopwatch ON `stream` (torch.cuda.Event only sees torch's current stream): begin records an event and
  * returns an opaque handle; end records the closing event, waits for it and returns elapsed milliseconds. */
 int mi355_event_time_begin(mi355_stream_t stream, void** handle);

@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -46,6 +46,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"gemm_pa_tail", 10, 0, 100},          // two-accumulator kernel, K >= 1024: a last round at most this many percent full goes to the small-tile ring kernel (0 = off)
     {"lpi_patch", 1, 0, 1},                // LPI at 14 x 14 tokens, C % 32 == 0: 2 x 2 patches per lane on channel-quad-major LDS planes (xcit.hip)
     {"mixer_fused", 1, 0, 1},              // MixerLayer token mixing (host mirror): one kernel where the geometry allows (mixer_fused.hip)
+    {"mixer_early", 0, 0, 1},              // mixer_token_kernel: all residual loads of the epilogue before its first store (A/B switch)
 };
 namespace {
 constexpr long OPT_UNSET = (long)0x8000000000000000ull;              // a device block entry that follows the process default
@@ -93,6 +94,7 @@ long opt_gemm_pa16() { return opt(O_GEMM_PA16); }
 long opt_gemm_pa_block() { return opt(O_GEMM_PA_BLOCK); }
 long opt_gemm_pa_tail() { return opt(O_GEMM_PA_TAIL); }
 long opt_lpi_patch() { return opt(O_LPI_PATCH); }
+long opt_mixer_early() { return opt(O_MIXER_EARLY); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the
@@ -192,7 +194,7 @@ int range_pending(const char* who) {
     if (!code) return MI355_OK;
     static const char* const names[] = {"?", "mi355_cast16_fwd", "mi355_layernorm16_fwd", "a 16-bit-output GEMM epilogue (mi355_linear16_fwd family)",
                                         "a fused block kernel (mi355_mlp_fused_fwd / mi355_proj_mlp_fused_fwd / mi355_cswin_stripe_attn_fwd / "
-                                        "mi355_ln_linear16_fwd / mi355_layernorm16_t_fwd)",
+                                        "mi355_ln_linear16_fwd / mi355_layernorm16_t_fwd / mi355_mixer_token_fwd)",
                                         "the LayerNorm-folding GEMM epilogue (mi355_linear16_lnc_fwd / mi355_ln_center16_fwd)"};
     return fail(MI355_ERANGE, "%s: an EARLIER launch of %s converted a finite value of magnitude >= 65520 to fp16: that tensor holds inf "
                 "where the fp32 reference is finite.  Run the module in precision 0 (strict) or 2 (bf16)", who, names[code < 6 ? code : 0]);
@@ -231,6 +233,8 @@ struct TraceRec { std::string tag; hipEvent_t a, b; };
 std::atomic<int> g_trace_dev{-1};             // device ordinal with an open trace, -1 = none
 std::mutex g_trace_mu;
 std::vector<TraceRec> g_trace;
+std::string g_trace_report;                   // finished report of the last closed trace, kept until it has been handed out whole
+bool g_trace_report_pending = false;
 }  // namespace
 bool trace_on() { return g_trace_dev.load(std::memory_order_relaxed) >= 0; }
 TraceScope::TraceScope(hipStream_t st_, const char* fmt, ...) : idx(-1), st(st_) {
@@ -259,44 +263,57 @@ int trace_begin() {
     std::lock_guard<std::mutex> lk(g_trace_mu);
     for (auto& r : g_trace) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_trace.clear();
+    g_trace_report.clear();
+    g_trace_report_pending = false;
     g_trace_dev.store(cur_dev(), std::memory_order_relaxed);
     return MI355_OK;
 }
 // closes the trace, waits for the recorded launches and writes one line per tag: "count\ttotal_us\tmin_us\tmax_us\ttag\n", largest
-// total first; returns the number of bytes the full report needs (like snprintf)
+// total first; returns the number of bytes the full report needs (like snprintf).  A report that did not fit (or buf == NULL) is KEPT:
+// the caller sizes a buffer from the return value and calls again; it is dropped once it has been handed out whole, or by the next
+// mi355_trace_begin.
 long trace_end(char* buf, size_t n) {
     g_trace_dev.store(-1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(g_trace_mu);
-    struct Acc { long cnt; double tot, mn, mx; };
-    std::map<std::string, Acc> acc;
-    for (auto& r : g_trace) {
-        float ms = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            auto it = acc.find(r.tag);
-            const double us = ms * 1e3;
-            if (it == acc.end()) acc[r.tag] = Acc{1, us, us, us};
-            else { it->second.cnt++; it->second.tot += us; if (us < it->second.mn) it->second.mn = us; if (us > it->second.mx) it->second.mx = us; }
-        } else {
-            (void)hipGetLastError();
+    if (!g_trace.empty() || !g_trace_report_pending) {
+        struct Acc { long cnt; double tot, mn, mx; };
+        std::map<std::string, Acc> acc;
+        for (auto& r : g_trace) {
+            float ms = 0.f;
+            if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                auto it = acc.find(r.tag);
+                const double us = ms * 1e3;
+                if (it == acc.end()) acc[r.tag] = Acc{1, us, us, us};
+                else { it->second.cnt++; it->second.tot += us; if (us < it->second.mn) it->second.mn = us; if (us > it->second.mx) it->second.mx = us; }
+            } else {
+                (void)hipGetLastError();
+            }
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_trace.clear();
+        std::vector<std::pair<std::string, Acc>> rows(acc.begin(), acc.end());
+        std::sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.second.tot > y.second.tot; });
+        g_trace_report.clear();
+        char line[256];
+        for (auto& kv : rows) {
+            snprintf(line, sizeof(line), "%ld\t%.1f\t%.1f\t%.1f\t%s\n", kv.second.cnt, kv.second.tot, kv.second.mn, kv.second.mx, kv.first.c_str());
+            g_trace_report += line;
+        }
+        g_trace_report_pending = true;
     }
-    g_trace.clear();
-    std::vector<std::pair<std::string, Acc>> rows(acc.begin(), acc.end());
-    std::sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.second.tot > y.second.tot; });
-    std::string out;
-    char line[256];
-    for (auto& kv : rows) {
-        snprintf(line, sizeof(line), "%ld\t%.1f\t%.1f\t%.1f\t%s\n", kv.second.cnt, kv.second.tot, kv.second.mn, kv.second.mx, kv.first.c_str());
-        out += line;
-    }
+    const std::string& out = g_trace_report;
+    const long need = (long)out.size();
     if (buf && n) {
         const size_t m = out.size() < n - 1 ? out.size() : n - 1;
         std::memcpy(buf, out.data(), m);
         buf[m] = 0;
+        if (m == out.size()) {                       // handed out whole: nothing to keep
+            g_trace_report.clear();
+            g_trace_report_pending = false;
+        }
     }
-    return (long)out.size();
+    return need;
 }
 
 int resident_slots(int per_cu) {

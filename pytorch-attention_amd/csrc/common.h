@@ -30,6 +30,7 @@ long  opt_gemm_pa16();
 long  opt_gemm_pa_block();
 long  opt_gemm_pa_tail();
 long  opt_lpi_patch();
+long  opt_mixer_early();
 void  ws_forget(const void* region);
 bool  ws_known(const void* region, unsigned long long key, hipStream_t st);   // api.hip: was this workspace zeroed for this shape? (device-resident launch tags)
 hipError_t ws_zero_async(void* p, size_t bytes, hipStream_t st);   // zero an exchange area with a kernel (capture-safe ordering)

@@ -491,6 +491,9 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
     if ((g.K % g16::BK) || (g.N & 7) || (out16 && g.resid)) return MI355_EUNSUPPORTED;
     if (g.resid_period && (g.resid_period < 128 || out16 || !g.resid)) return MI355_EUNSUPPORTED;   // 16-bit out + residual: rounding point differs
     if ((long)cdiv(g.M, 256) * cdiv(g.N, 256) > (1L << 30)) return MI355_EUNSUPPORTED;
+    // LayerNorm fold, consumer side: its argument checks belong up here, before the trace scope opens (a refused call must not leave an
+    // event pair under a kernel tag)
+    if (g.rowtau && (!out16 || !g.colsum || g.gamma || !aligned16(g.colsum) || (reinterpret_cast<uintptr_t>(g.rowtau) & 7u))) return MI355_EUNSUPPORTED;
     P8Plan pl{};
     int grid;
     size_t pb, ab;
@@ -516,8 +519,7 @@ int gemm16_p8(const g16::G16Args& g, int out16, int precision, void* ws, size_t 
     }
     MI355_TRACE(st, "gemm16_p8_kernel<%s,%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
                 g.rowtau ? ",fold" : "", g.M, g.N, g.K, g.act == MI355_ACT_GELU ? " gelu" : "");
-    if (g.rowtau) {                                            // LayerNorm fold, consumer side
-        if (!out16 || !g.colsum || g.gamma || !aligned16(g.colsum) || (reinterpret_cast<uintptr_t>(g.rowtau) & 7u)) return MI355_EUNSUPPORTED;
+    if (g.rowtau) {                                            // LayerNorm fold, consumer side (arguments checked above)
         if (precision == MI355_PREC_FP16) gemm16_p8_kernel<_Float16, true, true><<<grid, 512, 0, st>>>(g, pl);
         else                              gemm16_p8_kernel<__bf16, true, true><<<grid, 512, 0, st>>>(g, pl);
         return MI355_OK;

@@ -666,11 +666,18 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
     pl.full = (int)(ntiles / grid);
     pl.left = (int)(ntiles - (long)pl.full * grid);
     const bool gelu = g.act == MI355_ACT_GELU;
-    MI355_TRACE(st, "gemm16_pa_kernel<%s,%s%s%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
-                g.lnc_a ? ",emit" : "", swap ? ",256x128" : "", cpi == 1 ? "" : (cpi == 2 ? ",2 pieces" : ",3 pieces"), g.M, g.N, g.K, gelu ? " gelu" : "");
+    // every rejection comes BEFORE the trace scope opens: a refused call must not leave an event pair under a kernel tag (the dispatcher
+    // falls through to another kernel and the tally would show a phantom launch of near-zero duration)
     if (g.lnc_a) {                                              // emitting variant (LayerNorm fold, producer side)
         if (out16 || !g.lnc_stats || !g.lnc_c || abl || (g.N & 31) || g.lnc_lda != g.ldc) return MI355_EUNSUPPORTED;
         if ((long)g.M * g.lnc_lda * 2 >= (1L << 31) || (long)(g.N / 32) * g.M * 8 >= (1L << 31)) return MI355_EUNSUPPORTED;
+    }
+#ifndef MI355_PA_ABLATION
+    if (abl) return MI355_EUNSUPPORTED;
+#endif
+    MI355_TRACE(st, "gemm16_pa_kernel<%s,%s%s%s%s> M=%d N=%d K=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", out16 ? "out16" : "out32",
+                g.lnc_a ? ",emit" : "", swap ? ",256x128" : "", cpi == 1 ? "" : (cpi == 2 ? ",2 pieces" : ",3 pieces"), g.M, g.N, g.K, gelu ? " gelu" : "");
+    if (g.lnc_a) {
         if (precision == MI355_PREC_FP16) {
             if (gelu) gemm16_pa_kernel<_Float16, false, true, 0, true><<<grid, 512, 0, st>>>(g, pl);
             else      gemm16_pa_kernel<_Float16, false, false, 0, true><<<grid, 512, 0, st>>>(g, pl);
@@ -693,8 +700,6 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
         }
         return MI355_OK;
     }
-#else
-    if (abl) return MI355_EUNSUPPORTED;
 #endif
 #define PA_LAUNCH_C(T_, O_, G_, C_)                                                    \
     do {                                                                               \

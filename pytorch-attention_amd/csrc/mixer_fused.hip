@@ -40,6 +40,8 @@ struct MixArgs {
     const void* w2s;            // (T / 32, 208, 32) 16-bit slice-major, rows >= 196 zero
     const float* b1; const float* b2;
     int C, halves, T;           // halves = C / 256 workgroups per image; T hidden token units
+    unsigned* ovf;              // fp16 range word (common.h rg_report): the 16-bit LN(x) and gelu(H) operands are tracked like the
+                                // stand-alone producers they replace (layernorm16_t, the 16-bit GEMM epilogue); null = unguarded
 };
 
 // (mean, rstd) per token row: one wave per row, the row in registers (C <= 1024), biased variance, eps inside the sqrt -- the
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
-template <int PREC>
+// EARLY: the residual loads of phase 3 are issued in two batches of 14 / 12 ahead of their stores (two exposed round trips instead of
+// thirteen: hipcc pairs every token tile's loads with an s_waitcnt vmcnt(0) in front of its stores); the operand registers of phase 2
+// are dead by then.  All 26 at once needs 256 registers and spills in the fp16 instantiation.
+template <int PREC, bool EARLY>
 __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     const int C = a.C;
     if (t < a.T) s_b1[t] = a.b1[t];
     if (t < MX_NP) s_b2[t] = t < MX_N ? a.b2[t] : 0.f;
+    float rgmax = 0.f;                                              // fp16 range guard: largest finite magnitude this lane converts
 
     // ---- phase 1: LayerNorm of the wave's 32-channel slab, parked channel-major (two tokens per word) ----------------------------------
     {
@@ -115,8 +121,10 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
                 const int p = (half * 7 + i) * 8 + tk;
                 v4 ha = v4{(el)0.f, (el)0.f, (el)0.f, (el)0.f}, hc = ha;
                 if (2 * p < MX_N) {
-                    ha = M_::cvt((xa[i] - st[i].x) * st[i].y * lw + lb);
-                    hc = M_::cvt((xc[i] - st[i].z) * st[i].w * lw + lb);
+                    const f4 ua = (xa[i] - st[i].x) * st[i].y * lw + lb, uc = (xc[i] - st[i].z) * st[i].w * lw + lb;
+                    if constexpr (PREC == 1) rgmax = rg_absmax4(rg_absmax4(rgmax, ua), uc);
+                    ha = M_::cvt(ua);
+                    hc = M_::cvt(uc);
                 }
                 auto pack = [](el lo, el hi) {
                     return (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
         for (int tt = 0; tt < TT; ++tt) {
             const f4 p0 = gelu16_fast4(s[tt][0]);
             const f4 p1 = gelu16_fast4(s[tt][1]);
+            if constexpr (PREC == 1) rgmax = rg_absmax4(rg_absmax4(rgmax, p0), p1);
             const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
             pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         }
@@ -217,17 +226,41 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     }
     // ---- phase 3: lane (l15, g) holds channels cw + tt*16 + g*4 + [0,4) of token nt*16 + l15: + b2 + x, 16-byte stores -----------------
     const long base = (long)b * MX_N * C + cw + g * 4;
+    if constexpr (EARLY) {
+        constexpr int CH = 7;                                          // token tiles per batch: 14 loads in flight, then their stores
 #pragma unroll
-    for (int nt = 0; nt < MX_NT; ++nt) {
-        const int n = nt * 16 + l15;
-        if (n >= MX_N) continue;
-        const float bn = s_b2[n];
-        f4 xr[TT];
+        for (int c0 = 0; c0 < MX_NT; c0 += CH) {
+            f4 xr[TT][CH];
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) xr[tt] = *reinterpret_cast<const f4*>(a.x + base + (long)n * C + tt * 16);
+            for (int i = 0; i < CH; ++i) {
+                const int n = (c0 + i) * 16 + l15;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f4*>(a.y + base + (long)n * C + tt * 16) = (o[tt][nt] + bn) + xr[tt];
+                for (int tt = 0; tt < TT; ++tt)
+                    xr[tt][i] = (c0 + i < MX_NT && n < MX_N) ? *reinterpret_cast<const f4*>(a.x + base + (long)n * C + tt * 16) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int nt = c0 + i, n = nt * 16 + l15;
+                if (nt >= MX_NT || n >= MX_N) continue;
+                const float bn = s_b2[n];
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f4*>(a.y + base + (long)n * C + tt * 16) = (o[tt][nt] + bn) + xr[tt][i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < MX_NT; ++nt) {
+            const int n = nt * 16 + l15;
+            if (n >= MX_N) continue;
+            const float bn = s_b2[n];
+            f4 xr[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) xr[tt] = *reinterpret_cast<const f4*>(a.x + base + (long)n * C + tt * 16);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f4*>(a.y + base + (long)n * C + tt * 16) = (o[tt][nt] + bn) + xr[tt];
+        }
     }
+    if constexpr (PREC == 1) rg_report(rgmax, a.ovf, 4u);
 }
 
 }  // namespace
@@ -266,14 +299,17 @@ int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, 
     a.C = C; a.halves = C / 256; a.T = T;
     const long grid = (long)B * a.halves;
     if (grid >= (1L << 31)) return mi355::fail(MI355_EUNSUPPORTED, "mi355_mixer_token_fwd: batch too large");
-    MI355_TRACE(st, "mixer_token_kernel B=%d C=%d", B, C);
-    if (precision == MI355_PREC_FP16) {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mixer_token_kernel<1>), (int)MX_LDS)) return rc;
-        mixer_token_kernel<1><<<(int)grid, 512, MX_LDS, st>>>(a);
-    } else {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mixer_token_kernel<2>), (int)MX_LDS)) return rc;
-        mixer_token_kernel<2><<<(int)grid, 512, MX_LDS, st>>>(a);
-    }
+    a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
+    const bool early = mi355::opt_mixer_early() != 0;
+    MI355_TRACE(st, "mixer_token_kernel%s B=%d C=%d", early ? "<early>" : "", B, C);
+#define MIXER_LAUNCH(P_, E_)                                                                                                          \
+    do {                                                                                                                             \
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mixer_token_kernel<P_, E_>), (int)MX_LDS)) return rc;      \
+        mixer_token_kernel<P_, E_><<<(int)grid, 512, MX_LDS, st>>>(a);                                                               \
+    } while (0)
+    if (precision == MI355_PREC_FP16) { if (early) MIXER_LAUNCH(1, true); else MIXER_LAUNCH(1, false); }
+    else                              { if (early) MIXER_LAUNCH(2, true); else MIXER_LAUNCH(2, false); }
+#undef MIXER_LAUNCH
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }

@@ -126,6 +126,7 @@ SIGNATURES = {
     "mi355_bicubic_rows_fwd": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_float, c_float, c_vp]),
     "mi355_stream_copy": (c_int, [c_vp, c_vp, c_size, c_vp]),
     "mi355_stream_read": (c_int, [c_vp, c_size, c_vp, c_vp]),
+    "mi355_mfma_yardstick": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
 }
@@ -299,10 +300,18 @@ def kernel_trace(fn):
     try:
         fn()
     finally:
+        need = lib().mi355_trace_end(buf, len(buf))          # closes the trace also when fn() raised
+    if need < 0:
+        raise Mi355Error("mi355_trace_end failed (code %d)" % need)
+    if need >= len(buf):                                      # did not fit: the library kept the report for a second call
+        buf = ctypes.create_string_buffer(need + 1)
         lib().mi355_trace_end(buf, len(buf))
     rows = []
     for line in buf.value.decode().splitlines():
-        cnt, tot, mn, mx, tag = line.split("\t", 4)
+        parts = line.split("\t", 4)
+        if len(parts) != 5:
+            continue
+        cnt, tot, mn, mx, tag = parts
         rows.append((tag, int(cnt), float(tot), float(mn), float(mx)))
     return rows
 

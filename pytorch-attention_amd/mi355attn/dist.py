@@ -127,7 +127,13 @@ def gather_batch(y_local, global_batch=None, group=None, comm=None):
     n_local = y_local.shape[0]
     if global_batch is None or global_batch % world == 0:
         out = torch.empty((world * n_local,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-        if dist.get_backend(group) == "gloo":
+        if dist.get_backend(group) == "gloo" and y_local.is_cuda:
+            # host-side process group with device tensors (bench.py --dist-backend gloo: ranks sharing one GPU): staged through the host
+            host = y_local.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=group)
+            out.copy_(torch.cat(parts, dim=0))
+        elif dist.get_backend(group) == "gloo":
             parts = list(out.chunk(world, dim=0))
             dist.all_gather(parts, y_local, group=group)
         else:

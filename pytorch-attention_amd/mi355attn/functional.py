@@ -618,17 +618,34 @@ def weight16(param, precision=None):
     return _derived_get((param,), ("w16", p), tag, lambda: cast16(param.detach(), p))
 
 
+FP16_MIN_NORMAL = 2.0 ** -14
+
+
 def weight16_scaled(weight, bias, gamma, precision=None):
     """(W16', b') with a LayerScale folded in: y = resid + gamma * (x W^T + b) = resid + x (gamma[:, None] * W)^T + gamma * b when no
     activation sits between the product and the scale (XCiT: x + gamma1 * proj(..), x + gamma2 * fc2(..), xcit.py:290-294).  The GEMM
-    then needs no per-column scale in its epilogue and can take the two-accumulator kernel.  Cached with the parameters."""
+    then needs no per-column scale in its epilogue and can take the two-accumulator kernel.  Cached with the parameters.
+
+    Returns None when the fold would cost accuracy or range in fp16: gamma * W must stay inside the fp16 NORMAL range -- with the
+    published deep-XCiT initialisation eta = 1e-5, gamma * W ~ 2e-7 lies in the subnormals (step 6e-8: ~12 % of the weights flush to
+    zero, the branch's relative error rises from 3e-4 to 9e-2) -- so the fold is taken only if the smallest non-zero |gamma| times the
+    median |W| is at least 8 fp16 min-normals and the largest product is finite; the caller then keeps gamma in the fp32 epilogue
+    (`linear16(..., gamma=)`).  bf16 has the fp32 exponent range and always folds."""
     p = _prec(precision)
     anchors = (weight, gamma) + ((bias,) if bias is not None else ())
     tag = tuple((t._version, t.data_ptr(), tuple(t.shape)) for t in anchors)
 
     def build():
         g = gamma.detach().reshape(-1)
-        w16 = (weight.detach() * g[:, None]).to(dtype16(p)).contiguous()      # round-to-nearest-even, like mi355_cast16_fwd
+        w = weight.detach()
+        if p == PREC_FP16:
+            ga = g.abs()
+            nz = ga[ga > 0]
+            gmin = float(nz.min()) if nz.numel() else 1.0
+            wmed, wmax = float(w.abs().median()), float(w.abs().max())
+            if gmin * wmed < 8.0 * FP16_MIN_NORMAL or float(ga.max()) * wmax >= 65504.0:
+                return None
+        w16 = (w * g[:, None]).to(dtype16(p)).contiguous()      # round-to-nearest-even, like mi355_cast16_fwd
         return w16, (None if bias is None else (bias.detach() * g).contiguous())
 
     return _derived_get(anchors, ("w16scaled", p), tag, build)
@@ -833,6 +850,11 @@ class LnState:
 
     def __init__(self, a16, rowtau, cvec):
         self.a16, self.rowtau, self.cvec = a16, rowtau, cvec
+
+
+def ln_fold_enabled():
+    """Option "ln_fold" of the current device (default 0: the LayerNorm launches are faster than the fold)."""
+    return _ffi.get_option("ln_fold") == 1
 
 
 def ln_fold_ok(rows, C, N, K, precision=None):
@@ -1375,3 +1397,32 @@ def stream_copy(src, dst):
     check(lib().mi355_stream_copy(dptr(src), dptr(dst), src.numel() * src.element_size(), stream_ptr(src.device)),
           "mi355_stream_copy")
     return dst
+
+
+def mfma_yardstick(device, shape=0, target_ms=40.0):
+    """Box calibration (include/mi355attn.h mi355_mfma_yardstick): a register-operand MFMA loop on every SIMD of `device`, sized to run
+    about `target_ms`.  Returns dict(TFLOPs, ms, sclk_MHz_counter = the wave's cycle counter against the 100 MHz wall clock,
+    sclk_MHz_issue = clock implied by the instruction's documented issue interval (32 cycles per 32x32x16, shape 1 only), mfma, flop)."""
+    from ._ffi import StreamTimer
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    rep = torch.zeros(4, dtype=torch.int64, device=device)
+    per_iter, flop_per = (8, 16384) if shape == 0 else (4, 32768)
+
+    def run(iters):
+        tm = StreamTimer(device)
+        tm.start()
+        check(lib().mi355_mfma_yardstick(shape, iters, dptr(sink), dptr(rep), stream_ptr(device)), "mi355_mfma_yardstick")
+        return tm.stop_ms()
+
+    run(256)                                                 # code object load + a first look at the rate
+    ms = run(4096)
+    iters = int(min(1 << 24, max(4096, 4096 * target_ms / max(ms, 1e-3))))
+    ms = run(iters)
+    ticks, ref, groups = (int(v) for v in rep[:3].tolist())
+    mfma = groups * 4 * iters * per_iter
+    out = {"TFLOPs": round(mfma * flop_per / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 2), "mfma": mfma, "flop": mfma * flop_per,
+           "sclk_MHz_counter": round(ticks / ref * 100.0, 1) if ref else None}
+    if shape == 1 and groups:
+        per_simd = 2 * iters * per_iter                      # two waves per SIMD (two 4-wave workgroups per CU)
+        out["sclk_MHz_issue"] = round(per_simd * 32 / (ms * 1e-3) / 1e6, 1)
+    return out

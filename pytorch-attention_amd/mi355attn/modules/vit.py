@@ -29,8 +29,9 @@ def _mlp16(x, fc1, fc2, precision, second_gelu, gamma=None, resid=None):
     p = F._prec(precision)
     x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
     h16 = F.linear16(x16, F.weight16(fc1.weight, p), fc1.bias, act=F.ACT_GELU, out16=True, precision=p)
-    if gamma is not None and not second_gelu:                 # LayerScale folded into fc2 (XCiT: no activation behind fc2)
-        w16, b = F.weight16_scaled(fc2.weight, fc2.bias, gamma, p)
+    folded = F.weight16_scaled(fc2.weight, fc2.bias, gamma, p) if gamma is not None and not second_gelu else None
+    if folded is not None:                                    # LayerScale folded into fc2 (XCiT: no activation behind fc2); None =
+        w16, b = folded                                       # gamma * W would leave the fp16 normal range: gamma stays in the epilogue
         return F.linear16(h16, w16, b, resid=resid, precision=p)
     return F.linear16(h16, F.weight16(fc2.weight, p), fc2.bias, act=F.ACT_GELU if second_gelu else F.ACT_NONE, gamma=gamma,
                       resid=resid, precision=p)
@@ -129,6 +130,10 @@ class TransformerEncoder(nn.Module):
     def forward(self, x):
         if self.fold_ok(x):
             return self.forward_folded(x)[0]
+        return self.forward_plain(x)
+
+    def forward_plain(self, x):
+        """The default body: one LayerNorm launch in front of each half (the fold is opt-in: measured slower)."""
         fast = self.attn.fast_ok(x.shape[1]) and _fast(self.attn.precision, self.mlp.fc1, self.mlp.fc2)
         x = self.attn(self._norm(self.layernorm1, x, fast), resid=x)
         return self.mlp(self._norm(self.layernorm2, x, fast), resid=x)
@@ -138,7 +143,7 @@ class TransformerEncoder(nn.Module):
     def fold_ok(self, x):
         """The folded path applies: 16-bit dataflow, K/V-resident attention core, the producer kernel's shape envelope
         (rows % 128 == 0: B = 128, 256, ... at 197 tokens) and LayerNorm gains that keep gamma * W inside fp16."""
-        if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        if not F.ln_fold_enabled() or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:   # the option first: off by default
             return False
         B, N, C = x.shape
         p = F._prec(self.attn.precision)
@@ -207,12 +212,15 @@ class VisionTransformer(nn.Module):
         tok = F.patch_embed(x, self.patch_embedding.proj.weight, self.patch_embedding.proj.bias,
                             self.cls_token.reshape(-1), pos, ps, self.precision)
         blocks, state = list(self.blocks), None
+        # fold eligibility is decided ONCE per forward (the token tensor keeps its shape through the blocks): with the option off -- the
+        # default -- no per-block option reads / envelope checks / cache look-ups happen at all
+        elig = [blk.fold_ok(tok) for blk in blocks] if F.ln_fold_enabled() else None
         for i, blk in enumerate(blocks):
-            if blk.fold_ok(tok):                                  # LayerNorms folded into the GEMMs; the state travels block to block
-                nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-                tok, state = blk.forward_folded(tok, state, nxt.layernorm1.eps if nxt is not None and nxt.fold_ok(tok) else None)
+            if elig is not None and elig[i]:                      # LayerNorms folded into the GEMMs; the state travels block to block
+                nxt_ok = i + 1 < len(blocks) and elig[i + 1]
+                tok, state = blk.forward_folded(tok, state, blocks[i + 1].layernorm1.eps if nxt_ok else None)
             else:
-                tok, state = blk(tok), None
+                tok, state = blk(tok), None                       # module call (hooks intact); its own fold check is one option read
         if self.global_pool == "token":
             pooled = tok[:, 0]                                   # row-strided view, consumed in place by the GEMM
         elif self.global_pool == "avg":

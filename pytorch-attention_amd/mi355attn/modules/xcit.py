@@ -82,10 +82,12 @@ class XCA(nn.Module):
                 x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
                 qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
             ctx16 = F.xca_core(qkv, self.temperature, self.num_heads, precision=p, out16=True)
-            if gamma is not None:                             # LayerScale folded into the projection (no activation in between)
-                w16, b = F.weight16_scaled(self.proj.weight, self.proj.bias, gamma, p)
+            folded = F.weight16_scaled(self.proj.weight, self.proj.bias, gamma, p) if gamma is not None else None
+            if folded is not None:                            # LayerScale folded into the projection (no activation in between)
+                w16, b = folded
                 return F.linear16(ctx16, w16, b, resid=resid, precision=p)
-            return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, resid=resid, precision=p)
+            # no LayerScale, or gamma * W would leave the fp16 normal range (eta = 1e-5 initialisations): gamma in the fp32 epilogue
+            return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid, precision=p)
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias, precision=self.precision)
         ctx = F.xca_core(qkv, self.temperature, self.num_heads, precision=self.precision)
         return F.linear(ctx, self.proj.weight, self.proj.bias, gamma=gamma, resid=resid, precision=self.precision)

@@ -84,3 +84,26 @@ def test_lnfold_weights_and_layerscale_fold():
     want = gamma.detach() * (x @ proj.weight.detach().t() + proj.bias.detach())
     got = x @ ws.float().t() + bs
     assert rel_fro(got, want) < 8e-3
+
+
+def test_layerscale_fold_declines_outside_the_fp16_normal_range():
+    """XCiT's published deep initialisation (eta = 1e-5) puts gamma * W (~2e-7) into the fp16 subnormals; the fold must
+    decline in fp16 (gamma then stays in the GEMM's fp32 epilogue) and still be taken in bf16 (fp32 exponent range) and for O(1) gammas."""
+    from mi355attn import functional as F
+    torch.manual_seed(3)
+    proj = torch.nn.Linear(384, 384)
+    for eta, want_fold in ((1.0, True), (0.1, True), (1e-3, False), (1e-5, False)):
+        gamma = torch.nn.Parameter(eta * torch.ones(384))
+        got = F.weight16_scaled(proj.weight, proj.bias, gamma, 1)
+        assert (got is not None) == want_fold, eta
+        assert F.weight16_scaled(proj.weight, proj.bias, gamma, 2) is not None, "bf16 always folds"
+        if got is not None:                                    # the folded weights keep fp16's relative precision
+            w = (gamma.detach()[:, None] * proj.weight.detach()).double()
+            normal = w.abs() >= 2.0 ** -13                    # fp16 normal numbers: half an ulp = 2^-11 relative
+            assert float(normal.double().mean()) > 0.97, "nearly all folded weights are fp16 normals when the fold is taken"
+            assert float(((got[0].double() - w).abs() / w.abs())[normal].max()) <= 2.0 ** -11
+    big = torch.nn.Parameter(1e7 * torch.ones(384))
+    assert F.weight16_scaled(proj.weight, proj.bias, big, 1) is None, "gamma * W beyond the fp16 maximum"
+    zero = torch.nn.Parameter(torch.zeros(384))
+    ws = F.weight16_scaled(proj.weight, proj.bias, zero, 1)
+    assert ws is not None and float(ws[0].abs().max()) == 0.0, "an all-zero LayerScale folds exactly"

@@ -1,0 +1,166 @@
+"""Round-5 GPU tests (VERDICT round 4 "Next round" + the advisor's findings):
+
+  * LayerScale with the published deep-XCiT initialisation (eta = 1e-5): the branch y - x of XCABlock against fp64 (the host no longer folds
+    a gamma whose products would land in the fp16 subnormals);
+  * the fused Mixer token-mixing kernel reports a saturating 16-bit intermediate into the range word, like the launches it replaced;
+  * its "mixer_early" epilogue variant is bit-identical to the default;
+  * the in-process kernel tally: a refused launch leaves no phantom tag, a report longer than the caller's buffer is handed out whole;
+  * the MFMA yardstick of the bench line;
+  * `bench.py --gpus 2 --dist-backend gloo`: the whole N > 1 path (self-launch, barrier-bracketed windows, ranks_seen, host-staged
+    gather) end to end with the real kernels, two ranks sharing the one visible GPU.
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import oracle as O
+from conftest import ROOT, assert_parity, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def _drain_range():
+    import mi355attn
+    try:
+        mi355attn.range_status(wait=True)
+    except mi355attn.Mi355RangeError:
+        pass
+
+
+@pytest.mark.parametrize("eta", [1e-5, 1e-3, 1.0])
+def test_xcablock_small_layerscale_branch_accuracy(eta):
+    """with gamma folded into fp16 weights the proj / fc2 branch lost 9e-2 relative accuracy at eta = 1e-5 and
+    no test saw it (the branch is 1e-5 of the residual).  The branch y - x is compared with an fp64 evaluation of the reference math."""
+    from mi355attn import functional as F
+    from mi355attn.modules import XCABlock
+    torch.manual_seed(1234)
+    m = XCABlock(384, 8, qkv_bias=True, eta=eta).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(4, 196, 384)
+    ref = O.xca_block_forward(x, sd, 8, 14, 14, dtype=torch.float64)
+    m = m.cuda()
+    with torch.no_grad():
+        y = m(x.cuda(), 14, 14).cpu()
+    branch, want = (y.double() - x.double()), (ref.double() - x.double())
+    # fp32 cancellation noise of y - x: |x| * 2^-24 against a branch of size ~eta
+    floor = float(x.abs().max()) * 2.0 ** -23 / max(float(want.abs().mean()), 1e-30)
+    err = rel_fro(branch, want)
+    assert err <= 2e-3 + 4 * floor, f"eta={eta}: branch error {err:.3e} (cancellation floor {floor:.1e})"
+    folded = F.weight16_scaled(m.attn.proj.weight, m.attn.proj.bias, m.gamma1, 1) is not None
+    assert folded == (eta >= 0.1), "fold decision"
+
+
+def test_fused_mixer_kernel_reports_a_saturating_intermediate():
+    """LN(x) * w + b above 65504 inside mixer_token_kernel must raise Mi355RangeError at the next check."""
+    import mi355attn
+    from mi355attn.modules import MixerLayer
+    _drain_range()
+    torch.manual_seed(5)
+    m = MixerLayer(256, 196, precision=1).eval().cuda()
+    x = torch.randn(2, 196, 256, device="cuda")
+    with torch.no_grad():
+        tags = [t for t, *_ in mi355attn.kernel_trace(lambda: m(x))]
+        assert any("mixer_token_kernel" in t for t in tags), tags
+        mi355attn.range_status(wait=True)                          # ordinary data: nothing to report
+        m.norm1.weight.mul_(1.0e5)                                  # LN output ~1e5: finite in fp32, inf in fp16
+        raised = False
+        try:
+            m(x)                                                   # a later 16-bit launch of the same forward may already see the report
+        except mi355attn.Mi355RangeError:
+            raised = True
+    if not raised:
+        with pytest.raises(mi355attn.Mi355RangeError, match="fused block kernel"):
+            mi355attn.range_status(wait=True)
+    _drain_range()
+    m2 = MixerLayer(256, 196, precision=2).eval().cuda()           # bf16 operands have the fp32 range: nothing to report
+    m2.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        m2(x)
+    mi355attn.range_status(wait=True)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+def test_mixer_early_residual_variant_is_bit_identical(prec):
+    import mi355attn
+    from mi355attn.modules import MixerLayer
+    torch.manual_seed(11)
+    m = MixerLayer(512, 196, precision=prec).eval().cuda()
+    x = torch.randn(7, 196, 512, device="cuda")
+    old = mi355attn.get_option("mixer_early")
+    try:
+        with torch.no_grad():
+            mi355attn.set_option("mixer_early", 0)
+            y0 = m(x)
+            mi355attn.set_option("mixer_early", 1)
+            seen = []
+            def run():
+                seen.append(m(x))
+            tags = [t for t, *_ in mi355attn.kernel_trace(run)]
+    finally:
+        mi355attn.set_option("mixer_early", old)
+    assert any("mixer_token_kernel<early>" in t for t in tags), tags
+    assert torch.equal(y0, seen[0])
+
+
+def test_trace_has_no_phantom_tags_and_long_reports_survive():
+    """A launch the two-accumulator kernel refuses (K too short for its fp32 epilogue) must not leave a tag; a report longer than the
+    caller's buffer is kept by the library and handed out whole on the second call."""
+    import mi355attn
+    from mi355attn import _ffi
+    from mi355attn import functional as F
+    x16 = torch.randn(512, 384, device="cuda").half()
+    w16 = torch.randn(256, 384, device="cuda").half()
+    res = torch.randn(512, 256, device="cuda")
+
+    def run():
+        F.linear16(x16, w16, None, resid=res, precision=1)            # fp32 out + residual, K = 384 < 640: not gemm16_pa's shape
+    rows = mi355attn.kernel_trace(run)
+    assert len(rows) == 1 and rows[0][1] == 1, rows                   # exactly one kernel ran, exactly one tag with one launch
+    assert all(mn > 0.5 for _, _, _, mn, _ in rows), rows             # no near-zero phantom interval
+    # long report: many distinct tags through a 64-byte buffer
+    L = _ffi.lib()
+    assert L.mi355_trace_begin() == 0
+    for k in (64, 128, 192, 256, 320):
+        F.linear16(torch.randn(256, k, device="cuda").half(), torch.randn(64, k, device="cuda").half(), None, out16=True, precision=1)
+    torch.cuda.synchronize()
+    small = ctypes.create_string_buffer(64)
+    need = L.mi355_trace_end(small, 64)
+    assert need > 64
+    big = ctypes.create_string_buffer(need + 1)
+    assert L.mi355_trace_end(big, need + 1) == need
+    lines = big.value.decode().splitlines()
+    assert len(lines) == 5 and all(len(l.split("\t", 4)) == 5 for l in lines), lines
+    assert big.value.decode().startswith(small.value.decode())
+    assert L.mi355_trace_end(big, need + 1) == 0                      # handed out whole: dropped
+
+
+def test_mfma_yardstick_reads_a_sane_rate_and_clock():
+    from mi355attn import functional as F
+    dev = torch.device("cuda", 0)
+    y0 = F.mfma_yardstick(dev, 0, target_ms=10.0)
+    y1 = F.mfma_yardstick(dev, 1, target_ms=10.0)
+    for y in (y0, y1):
+        assert 300.0 < y["TFLOPs"] < 2600.0, y                        # between a badly throttled part and the 2.5 PF nameplate
+    assert 500.0 < y1["sclk_MHz_issue"] < 2500.0, y1
+    if y1["sclk_MHz_counter"]:
+        assert 50.0 < y1["sclk_MHz_counter"] < 3000.0, y1
+
+
+def test_bench_two_ranks_share_one_gpu_on_gloo():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "c5", "--batch", "16",
+           "--steps", "2", "--warmup", "1", "--no-cpu", "--no-strict", "--no-calib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and len(line["ms_per_step_by_rank"]) == 2
+    assert line["config"]["dist_backend"] == "gloo" and "gloo" in line["config"]["gather"]
+    assert len(line["ms_windows"]) == 3 and line["value"] > 0
+    assert line["blocks"][0]["key"] == "ViTBase"
