@@ -610,7 +610,7 @@ def cpu_baseline(blocks, args):
     import torch
     cores, threads, model = host_cpu_info()
     cands = sorted({min(threads, n) for n in (8, 16, 32, 64, 128)})
-    budget_s = float(os.environ.get("MI355_CPU_BLOCK_BUDGET_S", "10"))
+    budget_s = float(os.environ.get("MI355_CPU_BLOCK_BUDGET_S", "6"))
     per_image, detail, used, flat = 0.0, [], 0, {}
     with torch.no_grad():
         for b in blocks:

@@ -37,7 +37,7 @@ def _cards():
 def find_card(pci_bus_id=None):
     """sysfs device directory of the GPU with this PCI address ('0000:05:00.0'), else of the only / first amdgpu card, else None."""
     cards = _cards()
-    if pci_bus_id:
+    if isinstance(pci_bus_id, str) and pci_bus_id:
         want = pci_bus_id.lower()
         for dev in cards:
             if os.path.realpath(dev).lower().endswith(want):
