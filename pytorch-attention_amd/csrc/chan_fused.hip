@@ -18,6 +18,25 @@ typedef unsigned int u32;
 
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// wave_sum() of common.h without address registers: the xor-32 step is one v_permlane32_swap_b32 on two copies of the value (row 0 of
+// one meets row 1 of the other), the xor-16 .. xor-1 steps are ds_swizzle_b32 in bit-mask mode (pattern in the instruction).  Same
+// pairs in the same order as the __shfl_xor butterfly, fp32 addition is commutative: bit-identical sums.  The six ds_bpermute address
+// registers of the __shfl_xor form were loop invariants the 80-register SE kernel had to spill a row chunk for.
+template <int XOR> __device__ __forceinline__ float swz_xor(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1f));
+}
+__device__ __forceinline__ float wave_sum_sw(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    v = a + b;
+    v += swz_xor<16>(v);
+    v += swz_xor<8>(v);
+    v += swz_xor<4>(v);
+    v += swz_xor<2>(v);
+    v += swz_xor<1>(v);
+    return v;
+}
+
 // ---- ECA without any cross-workgroup exchange ------------------------------------------------------------------------------
 // The ECA gate of channel c only needs the means of channels c-pad..c+pad (eca.py:26-30, k taps, zero padding).  A workgroup
 // therefore keeps ECW = 8 channel rows in registers (one per wave) and additionally SUMS the 2*pad halo rows next to its slab
@@ -31,7 +50,7 @@ constexpr int ECW = 8;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NV, bool NTS>
-__global__ __launch_bounds__(512, 6) void eca_halo_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+__global__ __launch_bounds__(512, NV <= 13 ? 6 : 4) void eca_halo_kernel(const float* __restrict__ x, const float* __restrict__ taps,
                                                           float* __restrict__ y, int C, int k, int HW, int gpi, int total,
                                                           int per_xcd) {
     __shared__ float s_mean[ECW + 8];                        // means of channels c0-pad .. c0+ECW+pad-1
@@ -70,10 +89,10 @@ __global__ __launch_bounds__(512, 6) void eca_halo_kernel(const float* __restric
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
-    const float mean = wave_sum((s0 + s1) + (s2 + s3)) * inv;
+    const float mean = wave_sum_sw((s0 + s1) + (s2 + s3)) * inv;
     if (lane == 0) s_mean[pad + wave] = mean;
     if (wave < 2 * pad) {
-        const float hm = halo_live ? wave_sum((h0 + h1) + (h2 + h3)) * inv : 0.f;
+        const float hm = halo_live ? wave_sum_sw((h0 + h1) + (h2 + h3)) * inv : 0.f;
         if (lane == 0) s_mean[hslot] = hm;
     }
     __syncthreads();
@@ -111,30 +130,37 @@ struct SeSingleArgs {
     u32 spin;
     int gate;
     int C, Cr, HW, n4, gpi, total;
+    float inv;                  // 1.0f / HW, divided on the host (IEEE division either way: the same bits the kernel used to compute)
 };
 
-template <int NV, bool NTS, bool WLDS, int OCC>
+// EXTRA: the SE variants of the reference's CNNs (biases of the two excitation layers, hard-sigmoid gate: SeExtra).  The plain SELayer
+// instantiation carries none of their pointers, null checks and select masks -- scalar registers the 80-VGPR build cannot spare (past
+// 102 SGPRs hipcc parks uniform values in VGPRs and then spills those).
+template <int NV, bool NTS, bool WLDS, int OCC, bool EXTRA>
 __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // p[C] | h[Cr] | (WLDS: W1[Cr*C] | W2[C*Cr])
     __shared__ u32 s_tk[2];
     __shared__ u32 s_ep;
+    __shared__ u32 s_ok[2][8];                                        // per-wave "all my granules are in" votes, double-buffered by sweep parity
     float* s_p = smem;
     float* s_h = smem + a.C;
     float* s_w1 = s_h + a.Cr;
     float* s_w2 = s_w1 + a.Cr * a.C;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float inv = 1.0f / (float)a.HW;
+    const int t0 = threadIdx.x;
+    const float inv = a.inv;
     // one ticket; the last draw of the launch (number total + gridDim.x - 1) resets the ticket word and advances the epoch
     const u32 last_draw = (u32)a.total + gridDim.x - 1u;
     auto draw = [&](u32 ep) -> u32 {
         const u32 v = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
         if (v == last_draw) {
+            u32 e1;                                                    // formed HERE: a hoisted VGPR copy of epoch + 1 lived (spilled) for the whole kernel
+            asm volatile("v_mov_b32 %0, %1" : "=v"(e1) : "s"(ep + 1u));
             __hip_atomic_store(a.ticket, 0u, AGENT_RLX);
-            __hip_atomic_store(a.epoch, ep + 1u, AGENT_RLX);
+            __hip_atomic_store(a.epoch, e1, AGENT_RLX);
         }
         return v;
     };
-    if (t == 0) {
+    if (t0 == 0) {
         // read BEFORE the first draw (acquire: the fetch_add below may not be performed ahead of this load -- they are different
         // addresses, a relaxed pair has no order): the epoch cannot move until this workgroup has drawn its stop ticket
         const u32 ep = __hip_atomic_load(a.epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -143,51 +169,77 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
     }
     if (WLDS) {                                                       // both weight matrices stay in LDS for every slice
         const int nw = a.Cr * a.C;
-        for (int i = t; i < nw; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
+        for (int i = t0; i < nw; i += 512) { s_w1[i] = a.w1[i]; s_w2[i] = a.w2[i]; }
     }
     __syncthreads();
-    const u32 EP = s_ep;
+    // fresh scalar copies of C / Cr for the ticket loop: expressions like C * 4 are otherwise shared with the (divergent) weight-copy loop
+    // above, become "uniform values defined under divergent control flow" = VGPRs, and get spilled
+    int C_ = a.C, Cr_ = a.Cr;
+    asm volatile("" : "+s"(C_), "+s"(Cr_));
+    const u32 EP = __builtin_amdgcn_readfirstlane(s_ep);
     const u32 GRAN_TAG = (EP + 1u) ? EP + 1u : 1u;                    // 0 is what a zeroed granule holds
     int par = 0;
     for (;;) {
         __syncthreads();
-        const u32 tk = s_tk[par];
-        if (tk >= (u32)a.total) return;
+        // Everything a thread derives from its id is re-derived PER SLICE from an opaque copy: left alone, hipcc hoists each
+        // slice-invariant (lane offsets, LDS addresses, predicates ...) out of the ticket loop, and with the row resident in 52 of the
+        // 80 registers that three workgroups per CU allow it then spills those invariants to scratch (48 bytes per lane in round 4's
+        // <13, ., ., 3> instantiation -- the C2 bench shape).  A handful of integer instructions per slice instead.
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int lane = t & 63, wave = t >> 6;
+        const u32 tk = __builtin_amdgcn_readfirstlane(s_tk[par]);      // wave-uniform by construction: image / slab indices, the granule base
+        if (tk >= (u32)a.total) return;                                // and the row descriptors live in scalar registers
         const int b = tk / a.gpi, c0 = (tk - b * a.gpi) * ECW;
-        const u32 rw = __builtin_amdgcn_readfirstlane((u32)(b * a.C + c0 + wave));
+        const u32 rw = __builtin_amdgcn_readfirstlane((u32)(b * C_ + c0 + wave));
         const long row = (long)rw * a.HW;
         const rsrc_t rx = make_rsrc(a.x + row, (u32)a.HW * 4u), ry = make_rsrc(a.y + row, (u32)a.HW * 4u);
         const u32 voff = (u32)lane * 16u;                              // lanes beyond the row: zeros in, stores dropped (range check)
         v4f r[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (u32)j * 1024u, 0));
+        for (int j = 0; j < NV; ++j) {
+            // chunk j sits j KB behind the lane's first: steps 0 .. 3 ride in the instruction's immediate, every further 4 KB in the VGPR
+            // offset (formed behind an opaque copy: as scalar offsets they cost nine SGPRs, and past ~100 SGPRs hipcc spills scalars
+            // through VGPRs to scratch)
+            u32 vo = voff;
+            asm volatile("" : "+v"(vo));
+            r[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + (u32)(j >> 2) * 4096u + (u32)(j & 3) * 1024u, 0, 0));
+        }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
-        const float mean = wave_sum((s0 + s1) + (s2 + s3)) * inv;
-        u64* gb = a.gran + (long)b * a.C;
+        const float mean = wave_sum_sw((s0 + s1) + (s2 + s3)) * inv;
+        u64* gb = a.gran + (long)b * C_;
         if (lane == 0)
             __hip_atomic_store(gb + c0 + wave, ((u64)GRAN_TAG << 32) | (u64)__float_as_uint(mean), AGENT_RLX);
 
         // sweep the image's granules until every tag is in
         u32 spins = 0;
         bool mine_done = false;                                        // C <= 512: one granule per thread; larger C loops
+        const int ts = t;
         for (;;) {
             bool ok = true;
-            if (a.C <= 512) {
-                if (t < a.C && !mine_done) {
-                    const u64 g = __hip_atomic_load(gb + t, AGENT_RLX);
-                    if ((u32)(g >> 32) == GRAN_TAG) { s_p[t] = __uint_as_float((u32)g); mine_done = true; }
+            if (C_ <= 512) {
+                if (ts < C_ && !mine_done) {
+                    const u64 g = __hip_atomic_load(gb + (u32)ts, AGENT_RLX);     // scalar base + 32-bit lane offset
+                    if ((u32)(g >> 32) == GRAN_TAG) { s_p[ts] = __uint_as_float((u32)g); mine_done = true; }
                     else ok = false;
                 }
             } else {
-                for (int cc = t; cc < a.C; cc += 512) {
+                for (int cc = ts; cc < C_; cc += 512) {
                     const u64 g = __hip_atomic_load(gb + cc, AGENT_RLX);
                     if ((u32)(g >> 32) == GRAN_TAG) s_p[cc] = __uint_as_float((u32)g);
                     else ok = false;
                 }
             }
-            if (__syncthreads_and(ok)) break;
+            // workgroup-wide AND of `ok` in ONE barrier: a ballot per wave, the eight votes through LDS, two vote rows used alternately (a
+            // row is rewritten two sweeps later, when every wave has passed the barrier in between).  __syncthreads_and() costs three
+            // barriers per sweep and drags threadIdx.y / .z into registers.
+            const int vp = (int)(spins & 1u);
+            if ((ts & 63) == 0) s_ok[vp][ts >> 6] = __builtin_amdgcn_ballot_w64(!ok) == 0ull ? 1u : 0u;
+            __syncthreads();
+            const u32 votes = s_ok[vp][0] & s_ok[vp][1] & s_ok[vp][2] & s_ok[vp][3] & s_ok[vp][4] & s_ok[vp][5] & s_ok[vp][6] & s_ok[vp][7];
+            if (__builtin_amdgcn_readfirstlane(votes)) break;
             __builtin_amdgcn_s_sleep(2);
             if (++spins > a.spin) {
                 if (t == 0) {
@@ -203,25 +255,36 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
         // excitation: h = relu(W1 p) (16 lanes per hidden unit), g = sigmoid(W2[c,:] h) (one wave per channel)
         const float* w1 = WLDS ? s_w1 : a.w1;
         const float* w2 = WLDS ? s_w2 : a.w2;
-        const int part = t & 15, jl = t >> 4;
-        for (int j0 = 0; j0 < a.Cr; j0 += 32) {
+        const int tm = t;
+        const int part = tm & 15, jl = tm >> 4;
+        // the LDS bases of h / W1 / W2 as opaque SCALARS formed here (a hoisted VGPR copy of each was what the 80-register build spilled)
+        u32 oh = (u32)C_;
+        asm volatile("" : "+s"(oh));
+        float* s_hl = smem + oh;
+        if (WLDS) {
+            u32 o1 = (u32)(C_ + Cr_), o2 = (u32)(C_ + Cr_ + Cr_ * C_);
+            asm volatile("" : "+s"(o1), "+s"(o2));
+            w1 = smem + o1;
+            w2 = smem + o2;
+        }
+        for (int j0 = 0; j0 < Cr_; j0 += 32) {
             const int j = j0 + jl;
             float acc = 0.f;
-            if (j < a.Cr) {
-                const float* wrow = w1 + (long)j * a.C;
-                for (int cc = part; cc < a.C; cc += 16) acc += wrow[cc] * s_p[cc];
+            if (j < Cr_) {
+                const float* wrow = w1 + (long)j * C_;
+                for (int cc = part; cc < C_; cc += 16) acc += wrow[cc] * s_p[cc];
             }
             acc += __shfl_xor(acc, 8, WAVE);
             acc += __shfl_xor(acc, 4, WAVE);
             acc += __shfl_xor(acc, 2, WAVE);
             acc += __shfl_xor(acc, 1, WAVE);
-            if (part == 0 && j < a.Cr) s_h[j] = relu_nan(acc + (a.b1 ? a.b1[j] : 0.f));
+            if (part == 0 && j < Cr_) s_hl[j] = relu_nan(EXTRA ? acc + (a.b1 ? a.b1[j] : 0.f) : acc);
         }
         __syncthreads();
-        const float* w2r = w2 + (long)(c0 + wave) * a.Cr;
+        const float* w2r = w2 + (long)(c0 + wave) * Cr_;
         float z = 0.f;
-        for (int j = lane; j < a.Cr; j += 64) z += w2r[j] * s_h[j];
-        const float g = se_gate(wave_sum(z) + (a.b2 ? a.b2[c0 + wave] : 0.f), a.gate);
+        for (int j = lane; j < Cr_; j += 64) z += w2r[j] * s_hl[j];
+        const float g = EXTRA ? se_gate(wave_sum_sw(z) + (a.b2 ? a.b2[c0 + wave] : 0.f), a.gate) : sigmoidf_(wave_sum_sw(z));
         u32 ob = voff;                                                // row step in the VGPR offset of the stores: cbam_single.hip
         asm volatile("" : "+v"(ob));
 #pragma unroll
@@ -232,6 +295,31 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
         }
         par ^= 1;
     }
+}
+
+// launch dispatch over the template parameters; the three-workgroups-per-CU build exists only up to 13 float4 per lane (occ is 2 beyond)
+template <int NV, bool EXTRA>
+static void se_launch(int occ, bool nts, bool wlds, int grid, size_t smem, hipStream_t st, const SeSingleArgs& a) {
+    if constexpr (NV <= 13) {
+        if (occ == 3) {
+            if (wlds) se_single_kernel<NV, true, true, 3, EXTRA><<<grid, 512, smem, st>>>(a);
+            else      se_single_kernel<NV, true, false, 3, EXTRA><<<grid, 512, smem, st>>>(a);
+            return;
+        }
+    }
+    if (nts && wlds) se_single_kernel<NV, true, true, 2, EXTRA><<<grid, 512, smem, st>>>(a);
+    else if (nts)    se_single_kernel<NV, true, false, 2, EXTRA><<<grid, 512, smem, st>>>(a);
+    else if (wlds)   se_single_kernel<NV, false, true, 2, EXTRA><<<grid, 512, smem, st>>>(a);
+    else             se_single_kernel<NV, false, false, 2, EXTRA><<<grid, 512, smem, st>>>(a);
+}
+template <bool EXTRA>
+static void se_launch_nv(int nv, int occ, bool nts, bool wlds, int grid, size_t smem, hipStream_t st, const SeSingleArgs& a) {
+    if (nv <= 1) se_launch<1, EXTRA>(occ, nts, wlds, grid, smem, st, a);
+    else if (nv <= 2) se_launch<2, EXTRA>(occ, nts, wlds, grid, smem, st, a);
+    else if (nv <= 4) se_launch<4, EXTRA>(occ, nts, wlds, grid, smem, st, a);
+    else if (nv <= 8) se_launch<8, EXTRA>(occ, nts, wlds, grid, smem, st, a);
+    else if (nv <= 13) se_launch<13, EXTRA>(occ, nts, wlds, grid, smem, st, a);
+    else se_launch<16, EXTRA>(occ, nts, wlds, grid, smem, st, a);
 }
 
 }  // namespace
@@ -295,11 +383,15 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
     a.herr = sync_err_word_on(st); a.spin = spin_limit();
     if (int rc = sync_pending("se_single")) return rc;
     a.C = C; a.Cr = Cr; a.HW = H * W; a.n4 = a.HW / 4; a.gpi = C / ECW;
+    a.inv = 1.0f / (float)a.HW;
     const long total_l = (long)B * a.gpi;
     if (total_l > (1L << 30)) return fail(MI355_EUNSUPPORTED, "se_single: too many slices");
     a.total = (int)total_l;
     const bool wlds = (size_t)2 * C * Cr * sizeof(float) <= 48 * 1024;   // both weight matrices resident in LDS
-    const int occ = (opt_se_occ() == 3 && (!wlds || (size_t)(C + Cr + 2 * C * Cr) * 4 <= 50 * 1024)) ? 3 : 2;
+    const int nv = (a.n4 + 63) / 64;
+    // three workgroups per CU (<= 80 VGPRs) only while the row leaves room beside it: 13 float4 per lane (56 x 56) is the limit,
+    // 16 (64 x 64) would spill 100+ bytes per lane and runs two per CU at 112 registers instead
+    const int occ = (opt_se_occ() == 3 && nv <= 13 && (!wlds || (size_t)(C + Cr + 2 * C * Cr) * 4 <= 50 * 1024)) ? 3 : 2;
     long grid = (long)resident_slots(occ);                // 512-thread workgroups per CU: 2 (<= 128 VGPRs) or 3 (<= 80)
     if (a.gpi > grid) return fail(MI355_EUNSUPPORTED, "se_single: an image needs %d resident workgroups, the device holds %ld", a.gpi, grid);
     if (grid > a.total) grid = a.total;
@@ -310,25 +402,10 @@ int se_single(const float* x, const float* w1, const float* w2, float* y, int B,
         if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: zeroing -> %s", hipGetErrorString(e)); }
     }
     const size_t smem = (size_t)(C + Cr + (wlds ? 2 * C * Cr : 0)) * sizeof(float);
-    const int nv = (a.n4 + 63) / 64;
     const bool nts = (opt_nt() & 2) != 0;
-#define GO(NV_)                                                                                     \
-    do {                                                                                            \
-        if (occ == 3) {                                                                             \
-            if (wlds) se_single_kernel<NV_, true, true, 3><<<(int)grid, 512, smem, st>>>(a);        \
-            else      se_single_kernel<NV_, true, false, 3><<<(int)grid, 512, smem, st>>>(a);       \
-        } else if (nts && wlds)  se_single_kernel<NV_, true, true, 2><<<(int)grid, 512, smem, st>>>(a);   \
-        else if (nts)     se_single_kernel<NV_, true, false, 2><<<(int)grid, 512, smem, st>>>(a);   \
-        else if (wlds)    se_single_kernel<NV_, false, true, 2><<<(int)grid, 512, smem, st>>>(a);   \
-        else              se_single_kernel<NV_, false, false, 2><<<(int)grid, 512, smem, st>>>(a);  \
-    } while (0)
-    if (nv <= 1) GO(1);
-    else if (nv <= 2) GO(2);
-    else if (nv <= 4) GO(4);
-    else if (nv <= 8) GO(8);
-    else if (nv <= 13) GO(13);
-    else GO(16);
-#undef GO
+    const bool extra = ex.b1 || ex.b2 || ex.gate;
+    if (extra) se_launch_nv<true>(nv, occ, nts, wlds, (int)grid, smem, st, a);
+    else       se_launch_nv<false>(nv, occ, nts, wlds, (int)grid, smem, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) { ws_forget(state); return fail(MI355_EHIP, "se_single: launch -> %s", hipGetErrorString(e)); }
     return MI355_OK;

@@ -31,6 +31,10 @@ long  opt_gemm_pa_block();
 long  opt_gemm_pa_tail();
 long  opt_lpi_patch();
 long  opt_mixer_early();
+long  opt_gemm_small();
+// one-wave 32 x 32 tiles for small outputs (gemm_small.hip): MI355_EUNSUPPORTED when the shape is the engine's
+int   gemm_small_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int precision,
+                    hipStream_t st);
 void  ws_forget(const void* region);
 bool  ws_known(const void* region, unsigned long long key, hipStream_t st);   // api.hip: was this workspace zeroed for this shape? (device-resident launch tags)
 hipError_t ws_zero_async(void* p, size_t bytes, hipStream_t st);   // zero an exchange area with a kernel (capture-safe ordering)

@@ -112,3 +112,20 @@ def test_options_are_per_device_with_process_defaults(built_lib):
     assert lib.mi355_set_option(b"spin_limit", 0) == 0 and lib.mi355_set_option(b"spin_limit", 5) == -1
     assert lib.mi355_set_option(b"spin_limit", 1 << 22) == 0
     assert lib.mi355_set_option(b"no_such_key", 1) == -1 and lib.mi355_get_option(b"no_such_key") == -1
+
+
+def test_c2_kernels_have_no_scratch(built_lib):
+    """the single-read SE / ECA / CBAM kernels of the C2 bench shape (56 x 56: 13 float4 per lane, full bands)
+    must not spill -- read from the AMDGPU metadata of the shipped library (tools/kernel_resources.py), no GPU needed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    rows = kernel_resources.kernels(built_lib)
+    assert len(rows) > 300
+    c2 = [r for r in rows if ("se_single_kernel<13," in r["demangled"] or "eca_halo_kernel<" in r["demangled"]
+                              or ("cbam_single_kernel<" in r["demangled"] and r["demangled"].split("(")[0].rstrip(">").endswith("true")))]
+    assert len(c2) >= 10, [r["demangled"] for r in c2][:5]
+    bad = [(r["demangled"], r["scratch"]) for r in c2 if r["scratch"]]
+    assert not bad, bad
+    se3 = [r for r in rows if "se_single_kernel<13, true, true, 3, false>" in r["demangled"]]        # the bench instantiation: three workgroups per CU
+    assert se3 and se3[0]["vgpr"] <= 80 and se3[0]["scratch"] == 0, se3

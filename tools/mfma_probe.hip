@@ -1,0 +1,158 @@
+// mfma_probe.hip -- what the two 16-bit MFMA shapes sustain on THIS box, alone and next to the LDS fragment traffic of a GEMM main loop
+// ("an A/B of v_mfma_f32_32x32x16_f16 in the main loop ... commit the table whatever it says").
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_probe.hip -o tools/bin/mfma_probe && tools/bin/mfma_probe
+//
+// Every variant: grid = CUs x (waves per SIMD / 1), 256-thread workgroups (one wave per SIMD each), `iters` iterations of a fixed body,
+// accumulators updated IN PLACE by inline assembly (no compiler-chosen register rotation), operands random in [-1, 1).
+//   shape 16: v_mfma_f32_16x16x32_f16, body = 8 A x 4 B fragments = 32 MFMAs on 32 accumulator quads (the engine's 128 x 64 wave tile, K = 32)
+//   shape 32: v_mfma_f32_32x32x16_f16, body = 2 K-halves x (4 A x 2 B) = 16 MFMAs on 8 accumulator x 16 registers (the same tile, K = 32)
+//   lds 0 / 1: without / with the 12 ds_read_b128 fragment reads (8 A + 4 B for shape 16; 2 x (4 A + 2 B) for shape 32) of that K = 32 step
+//              issued inside the body from a conflict-free LDS image, consumed by the MFMAs of the NEXT iteration (double-buffered registers)
+// Output per variant: TFLOP/s, shader clock (cycle counter against the 100 MHz counter), shader cycles per MFMA and SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ h8 frag(unsigned seed) {
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        seed = seed * 1664525u + 1013904223u;
+        v[e] = (_Float16)((float)((seed >> 9) & 1023u) * (1.0f / 512.0f) - 1.0f);
+    }
+    return v;
+}
+
+template <int SHAPE, int LDS>
+__global__ __launch_bounds__(256) void probe(int iters, float* sink, unsigned long long* rep) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[4 * 12 * 64 * 8];          // per wave: 12 fragments x 64 lanes x 16 bytes
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Float16* mine = img + wave * 12 * 64 * 8;
+    for (int f = 0; f < 12; ++f) *reinterpret_cast<h8*>(mine + (f * 64 + lane) * 8) = frag(lane * 2654435761u + f * 97u + blockIdx.x);
+    __syncthreads();
+    h8 a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const h8*>(mine + (i * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const h8*>(mine + ((8 + i) * 64 + lane) * 8);
+    unsigned long long c0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    float out = 0.f;
+    if constexpr (SHAPE == 16) {
+        f4 acc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+            h8 na[8], nb[4];
+            if (LDS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) na[i] = *reinterpret_cast<const volatile h8*>(mine + (i * 64 + lane) * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nb[i] = *reinterpret_cast<const volatile h8*>(mine + ((8 + i) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i * 4 + j]) : "v"(a[i]), "v"(b[j]));
+            if (LDS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = na[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = nb[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) out += acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+    } else {
+        f16v acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            h8 na[8], nb[4];
+            if (LDS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) na[i] = *reinterpret_cast<const volatile h8*>(mine + (i * 64 + lane) * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nb[i] = *reinterpret_cast<const volatile h8*>(mine + ((8 + i) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)                       // two K = 16 halves: A fragments kh*4 .. kh*4+3, B fragments kh*2, kh*2+1
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i * 2 + j]) : "v"(a[kh * 4 + i]), "v"(b[kh * 2 + j]));
+            if (LDS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = na[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = nb[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out += acc[j][e];
+    }
+    if (stamp) { rep[0] = __builtin_readcyclecounter() - c0; rep[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    if (out == 12345.678f) sink[0] = out;
+}
+
+template <int SHAPE, int LDS>
+static void run(int wps, int ncu, float* sink, unsigned long long* rep) {
+    const int grid = ncu * wps;                                  // 256-thread workgroups: one wave per SIMD each
+    const int mf = SHAPE == 16 ? 32 : 16;
+    const double flop_per = SHAPE == 16 ? 16384.0 : 32768.0;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int iters = 2000;
+    float ms = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        CK(hipEventRecord(e0));
+        probe<SHAPE, LDS><<<grid, 256>>>(iters, sink, rep);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 0) iters = (int)(iters * 30.0 / (ms > 0.01f ? ms : 0.01f));       // ~30 ms
+        if (iters > (1 << 22)) iters = 1 << 22;
+    }
+    unsigned long long h[2];
+    CK(hipMemcpy(h, rep, sizeof(h), hipMemcpyDeviceToHost));
+    const double mfma = (double)grid * 4 * iters * mf;
+    const double tf = mfma * flop_per / (ms * 1e-3) / 1e12;
+    const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    const double per_simd = (double)wps * iters * mf;          // MFMAs one SIMD issues
+    const double cyc = (double)h[0] / per_simd;
+    printf("| %dx%dx%d | %s | %d | %8.1f | %7.0f | %6.2f | %6.1f |\n", SHAPE, SHAPE, SHAPE == 16 ? 32 : 16, LDS ? "12 ds_read_b128 / K32" : "none", wps, tf, mhz,
+           cyc, ms);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
+int main() {
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    const int ncu = p.multiProcessorCount;
+    float* sink; unsigned long long* rep;
+    CK(hipMalloc(&sink, 64)); CK(hipMalloc(&rep, 64));
+    printf("device: %s, %d CUs\n", p.gcnArchName, ncu);
+    printf("| MFMA | LDS traffic in the body | waves / SIMD | TFLOP/s | sclk MHz | shader cycles per MFMA and SIMD | ms |\n|---|---|---|---|---|---|---|\n");
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+        run<16, 0>(1, ncu, sink, rep); run<16, 0>(2, ncu, sink, rep);
+        run<32, 0>(1, ncu, sink, rep); run<32, 0>(2, ncu, sink, rep);
+        run<16, 1>(1, ncu, sink, rep); run<16, 1>(2, ncu, sink, rep);
+        run<32, 1>(1, ncu, sink, rep); run<32, 1>(2, ncu, sink, rep);
+    }
+    return 0;
+}
