@@ -364,11 +364,7 @@ def main(argv=None):
         return time.perf_counter() - t0
 
     # ---- box calibration BEFORE the timed region (rank 0 measures, every rank waits): yardsticks + telemetry -------------------------
-    card = None
-    try:
-        card = tele.find_card(getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
-    except Exception:                                        # noqa: BLE001  (telemetry is best effort)
-        card = tele.find_card()
+    card = tele.find_card(tele.pci_address(dev_index))       # the sysfs directory of THIS GPU (a host may list eight cards)
     calib = {}
     want_calib = rank == 0 and not args.only and not args.no_calib
     if want_calib:
@@ -638,9 +634,19 @@ def cpu_baseline(blocks, args):
                 b["cpu"](xs)
                 ts.append(time.perf_counter() - t1)
             t = min(ts)
+            chunk = ns
+            if t > 0.3 and ns >= 16 and time.perf_counter() - t_blk < 2 * budget_s:
+                # a throughput baseline may pick its batch size: the same sample in sub-batches of 8 (the intermediates of a full model at
+                # 32 images -- 77 MB per MLP hidden tensor -- fall out of the host's caches; at 8 they stay)
+                t1 = time.perf_counter()
+                for c0 in range(0, ns, 8):
+                    b["cpu"](xs[c0:c0 + 8])
+                tc = time.perf_counter() - t1
+                if tc < t:
+                    t, chunk = tc, 8
             per_image += t / ns
             flop = b.get("alt_work") or (b["work"] if b["bound"] == "mfma" else None)
-            rec = {"block": b["name"], "key": b["key"], "images": ns, "threads": best_n, "images_per_s": round(ns / t, 1),
+            rec = {"block": b["name"], "key": b["key"], "images": ns, "sub_batch": chunk, "threads": best_n, "images_per_s": round(ns / t, 1),
                    "probe_s": {str(k): round(v, 3) for k, v in probe.items()},
                    "note": b.get("cpu_note", "oracle restatement (same math as the reference forward, not its exact operator sequence)")}
             flat["img_s_" + b["key"]] = rec["images_per_s"]
@@ -656,7 +662,7 @@ def cpu_baseline(blocks, args):
                                                                                          sorted(probe)))
     out = {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
            "host_cores": cores, "host_threads": threads, "host_cpu": model,
-           "sample": "first n images of the same batch per block (n = 64 C2 / 32 others), best of <= 3 passes, threads probed per block"}
+           "sample": "first n images of the same batch per block (n = 64 C2 / 32 others), best of <= 3 passes (+ sub-batches of 8)"}
     out.update(flat)
     out["legend"] = ("img_s_* / thr_* / GFLOPs_* (GBps_* for the HBM-bound blocks) per block key; ATen-operator-sequence restatements of the "
                      "reference forward (oracle/aten_seq.py); threads probed over {8,16,32,64,128} on the timed sample; cores = largest count used")

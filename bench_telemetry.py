@@ -34,6 +34,34 @@ def _cards():
     return out
 
 
+def pci_address(device_index):
+    """'0000:72:00.0' of HIP device `device_index` in this process (hipDeviceGetPCIBusId of the runtime torch has loaded; falls back to
+    the integer fields of torch's device properties), or None."""
+    import ctypes
+    try:
+        # the copy of the HIP runtime ALREADY mapped into this process (torch's): opening it by its path returns that very handle,
+        # opening it by bare name could map a second runtime from /opt/rocm
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        if path:
+            hip = ctypes.CDLL(path)
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0 and buf.value:
+                return buf.value.decode().lower()
+    except (OSError, AttributeError):
+        pass
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:                                        # noqa: BLE001  (telemetry is best effort)
+        return None
+
+
 def find_card(pci_bus_id=None):
     """sysfs device directory of the GPU with this PCI address ('0000:05:00.0'), else of the only / first amdgpu card, else None."""
     cards = _cards()

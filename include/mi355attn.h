@@ -108,8 +108,8 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   spread over all CUs (a second launch on the same stream; same K order, bit-identical results).
  *   "mixer_fused"   1 (default) = the host mirror's MixerLayer runs its token-mixing half through mi355_mixer_token_fwd where the
  *                   geometry allows (N = 196, T % 32 == 0, C % 256 == 0); 0 = three launches (transposing LayerNorm, fc1, transposed fc2).
- *   "gemm_small"    1 (default) = mi355_linear_fwd without activation / LayerScale / residual whose output is less than a quarter round of
- *                   the engine's 128 x 128 tiles (a classifier head: 256 x 1000) runs on one-wave 32 x 32 tiles spread over every CU
+ *   "gemm_small"    1 (default) = mi355_linear_fwd without activation / LayerScale / residual whose output is less than an eighth of a round of
+ *                   the engine's 128 x 128 tiles (a classifier head: 256 x 1000) runs on one-wave 16 x 32 tiles spread over every CU
  *                   (gemm_small.hip; same K order, bit-identical results); 0 = always the 128 x 128 engine.
  *   "mixer_early"   mi355_mixer_token_fwd: 1 = the kernel issues the residual loads of its epilogue in two batches ahead of their stores (two
  *                   exposed round trips instead of thirteen; bit-identical results); 0 (default) = a token tile's loads right before its stores.

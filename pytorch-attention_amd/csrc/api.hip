@@ -47,7 +47,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"lpi_patch", 1, 0, 1},                // LPI at 14 x 14 tokens, C % 32 == 0: 2 x 2 patches per lane on channel-quad-major LDS planes (xcit.hip)
     {"mixer_fused", 1, 0, 1},              // MixerLayer token mixing (host mirror): one kernel where the geometry allows (mixer_fused.hip)
     {"mixer_early", 0, 0, 1},              // mixer_token_kernel: all residual loads of the epilogue before its first store (A/B switch)
-    {"gemm_small", 1, 0, 1},               // mi355_linear_fwd: outputs under a quarter round of 128 x 128 tiles on one-wave 32 x 32 tiles (gemm_small.hip)
+    {"gemm_small", 1, 0, 1},               // mi355_linear_fwd: outputs under an eighth of a round of 128 x 128 tiles on one-wave 16 x 32 tiles (gemm_small.hip)
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {

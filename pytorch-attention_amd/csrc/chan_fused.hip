@@ -236,7 +236,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void se_single_kernel(const SeSingleA
             // row is rewritten two sweeps later, when every wave has passed the barrier in between).  __syncthreads_and() costs three
             // barriers per sweep and drags threadIdx.y / .z into registers.
             const int vp = (int)(spins & 1u);
-            if ((ts & 63) == 0) s_ok[vp][ts >> 6] = __builtin_amdgcn_ballot_w64(!ok) == 0ull ? 1u : 0u;
+            const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;      // evaluated by the WHOLE wave (not under the lane-0 branch below)
+            if ((ts & 63) == 0) s_ok[vp][ts >> 6] = wave_ok ? 1u : 0u;
             __syncthreads();
             const u32 votes = s_ok[vp][0] & s_ok[vp][1] & s_ok[vp][2] & s_ok[vp][3] & s_ok[vp][4] & s_ok[vp][5] & s_ok[vp][6] & s_ok[vp][7];
             if (__builtin_amdgcn_readfirstlane(votes)) break;

@@ -25,6 +25,6 @@ import json, sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-attention_amd")); sys.path.insert(0, os.getcwd())
 import torch, bench
 dev = torch.device("cuda", 0)
-src = torch.randn(256 * 256 * 56 * 56 // 4, device=dev)
+src = torch.randn(256 * 256 * 56 * 56, device=dev)           # the C2 footprint (822 MB), as in bench.py
 print(json.dumps(bench.yardsticks(dev, src)))
 PY
