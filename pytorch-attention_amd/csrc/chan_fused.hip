@@ -18,25 +18,6 @@ typedef unsigned int u32;
 
 #define AGENT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// wave_sum() of common.h without address registers: the xor-32 step is one v_permlane32_swap_b32 on two copies of the value (row 0 of
-// one meets row 1 of the other), the xor-16 .. xor-1 steps are ds_swizzle_b32 in bit-mask mode (pattern in the instruction).  Same
-// pairs in the same order as the __shfl_xor butterfly, fp32 addition is commutative: bit-identical sums.  The six ds_bpermute address
-// registers of the __shfl_xor form were loop invariants the 80-register SE kernel had to spill a row chunk for.
-template <int XOR> __device__ __forceinline__ float swz_xor(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1f));
-}
-__device__ __forceinline__ float wave_sum_sw(float v) {
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    v = a + b;
-    v += swz_xor<16>(v);
-    v += swz_xor<8>(v);
-    v += swz_xor<4>(v);
-    v += swz_xor<2>(v);
-    v += swz_xor<1>(v);
-    return v;
-}
-
 // ---- ECA without any cross-workgroup exchange ------------------------------------------------------------------------------
 // The ECA gate of channel c only needs the means of channels c-pad..c+pad (eca.py:26-30, k taps, zero padding).  A workgroup
 // therefore keeps ECW = 8 channel rows in registers (one per wave) and additionally SUMS the 2*pad halo rows next to its slab

@@ -72,7 +72,9 @@ __device__ __forceinline__ float gate_of(const StatArgs& a, int c, float mean, f
 //   GCTG: red0 = mean_c, red1 = mean_c(v^2) - mean_c^2;   GCT2: red0 = mean_c((v + eps) alpha^2);   GCT1: red0 = mean_c |v alpha|
 template <int MODE, int NT>
 __device__ __forceinline__ void image_reduce(const StatArgs& a, const float* s_p, float* s_red, float& red0, float& red1) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));                                       // formed here, not hoisted out of the caller's slice loop
+    const int lane = t & 63, wave = t >> 6;
     float u = 0.f, w = 0.f;
     for (int c = t; c < a.C; c += NT) {
         const float v = s_p[c];
@@ -80,8 +82,8 @@ __device__ __forceinline__ void image_reduce(const StatArgs& a, const float* s_p
         if (MODE == M_GCT2) { const float e = sqrtf(v + a.f0) * a.p0[c]; u += e * e; }
         if (MODE == M_GCT1) { u += fabsf(v * a.p0[c]); }
     }
-    u = wave_sum(u);
-    w = wave_sum(w);
+    u = wave_sum_sw(u);
+    w = wave_sum_sw(w);
     if (lane == 0) { s_red[wave] = u; s_red[16 + wave] = w; }
     __syncthreads();
     float su = 0.f, sw = 0.f;
@@ -93,21 +95,24 @@ __device__ __forceinline__ void image_reduce(const StatArgs& a, const float* s_p
 
 // LCT: mean / variance of the published means over the group of channel c (cpg channels), by one wave
 __device__ __forceinline__ void group_reduce(const float* s_p, int c, int cpg, float& red0, float& red1) {
-    const int lane = threadIdx.x & 63, g0 = (c / cpg) * cpg;
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, g0 = (c / cpg) * cpg;
     float u = 0.f, w = 0.f;
     for (int i = lane; i < cpg; i += 64) { const float v = s_p[g0 + i]; u += v; w += v * v; }
-    u = wave_sum(u);
-    w = wave_sum(w);
+    u = wave_sum_sw(u);
+    w = wave_sum_sw(w);
     red0 = u / (float)cpg;
     red1 = w / (float)cpg - red0 * red0;
 }
 
 template <int MODE, int NV, bool NTS>
-__global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_kernel(const StatArgs a) {
+__global__ __launch_bounds__(512, (MODE == M_SIMAM ? (NV > 13 ? 2 : 4) : (NV > 13 ? 4 : 6))) void stat_single_kernel(const StatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_p[];       // exchange modes: the image's C published values
     __shared__ float s_red[32];
     __shared__ u32 s_tk[2];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ u32 s_ok[2][8];                                        // per-wave votes of the granule sweep, double-buffered by sweep parity
+    const int t0 = threadIdx.x;
     constexpr bool XCH = MODE >= M_GCTG;
     // Launch state lives in the workspace, exactly as in se_single_kernel (chan_fused.hip): the tag of a launch is `epoch + 1`, a launch
     // draws total + gridDim.x tickets (one per slice, one stop ticket per workgroup) and the workgroup that draws the last one sets the
@@ -118,14 +123,16 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
     auto draw = [&](u32 ep) -> u32 {
         const u32 v = __hip_atomic_fetch_add(a.ticket, 1u, AGENT_RLX);
         if (v == last_draw) {
+            u32 e1;                                                    // formed here: a hoisted VGPR copy of epoch + 1 would live for the whole kernel
+            asm volatile("v_mov_b32 %0, %1" : "=v"(e1) : "s"(ep + 1u));
             __hip_atomic_store(a.ticket, 0u, AGENT_RLX);
-            __hip_atomic_store(a.epoch, ep + 1u, AGENT_RLX);
+            __hip_atomic_store(a.epoch, e1, AGENT_RLX);
         }
         return v;
     };
     u32 EP = 0u, TAG = 1u;
     if (XCH) {
-        if (t == 0) {
+        if (t0 == 0) {
             // acquire: the draw below must not be performed before this load (the epoch cannot move until this workgroup has drawn
             // its stop ticket, but only if the load really comes first)
             const u32 ep = __hip_atomic_load(a.epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -133,16 +140,21 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
             s_tk[0] = draw(ep);
         }
         __syncthreads();
-        EP = s_ep;
+        EP = __builtin_amdgcn_readfirstlane(s_ep);
         TAG = (EP + 1u) ? EP + 1u : 1u;                               // 0 is what a zeroed granule holds
     }
     int par = 0;
     u32 slice = blockIdx.x;
     for (;;) {
+        // thread-id arithmetic is re-derived per slice from an opaque copy (see se_single_kernel, chan_fused.hip: hoisted slice invariants
+        // are what the 80-register builds of this family spilled); the ticket is wave-uniform by construction
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int lane = t & 63, wave = t >> 6;
         u32 tk;
         if (XCH) {
             __syncthreads();
-            tk = s_tk[par];
+            tk = __builtin_amdgcn_readfirstlane(s_tk[par]);
         } else {
             tk = slice;                                               // no waiting between workgroups: a plain grid-stride walk
             slice += gridDim.x;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
 #pragma unroll
             for (int j = 0; j < NV; ++j) { s0 += r[j].x; s1 += r[j].y; s2 += r[j].z; s3 += r[j].w; }
         }
-        const float tot = wave_sum((s0 + s1) + (s2 + s3));
+        const float tot = wave_sum_sw((s0 + s1) + (s2 + s3));
         const float mean = tot / (float)a.HW;
         float cvs = 0.f;                                              // sum_hw (x - mean)^2  (SIMAM, SRM)
         if (MODE == M_SIMAM || MODE == M_SRM) {
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
                 const v4f d = r[j] - mean;
                 q0 += d.x * d.x; q1 += d.y * d.y; q2 += d.z * d.z; q3 += d.w * d.w;
             }
-            cvs = wave_sum((q0 + q1) + (q2 + q3));
+            cvs = wave_sum_sw((q0 + q1) + (q2 + q3));
         }
         const float own = (MODE == M_GCT2 || MODE == M_GCT1) ? tot : mean;
         float red0 = 0.f, red1 = 0.f;
@@ -203,7 +215,12 @@ __global__ __launch_bounds__(512, (MODE == M_SIMAM ? 4 : 6)) void stat_single_ke
                     if ((u32)(g >> 32) == TAG) s_p[cc] = __uint_as_float((u32)g);
                     else ok = false;
                 }
-                if (__syncthreads_and(ok)) break;
+                const int vp = (int)(spins & 1u);                     // one-barrier AND of `ok` (chan_fused.hip se_single_kernel)
+                const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                if (lane == 0) s_ok[vp][wave] = wave_ok ? 1u : 0u;
+                __syncthreads();
+                const u32 votes = s_ok[vp][0] & s_ok[vp][1] & s_ok[vp][2] & s_ok[vp][3] & s_ok[vp][4] & s_ok[vp][5] & s_ok[vp][6] & s_ok[vp][7];
+                if (__builtin_amdgcn_readfirstlane(votes)) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > a.spin) { timeout = true; break; }
             }
@@ -314,7 +331,10 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
         const long total_l = (long)B * a.gpi;
         if (total_l > (1L << 30)) return mi355::fail(MI355_EUNSUPPORTED, "channel-statistics gate: too many slices");
         a.total = (int)total_l;
-        long grid = (long)mi355::resident_slots(MODE == M_SIMAM ? 2 : 3);        // three workgroups per CU (<= 80 VGPRs); SimAM's per-element gate needs 120
+        const int nv = (a.n4 + 63) / 64;
+        // workgroups per CU = what the kernel's launch bounds allow: three (<= 80 VGPRs) up to 13 float4 per lane, two beyond; SimAM's
+        // per-element gate needs 120 registers (two per CU), 141 at 16 float4 per lane (one per CU)
+        long grid = (long)mi355::resident_slots(MODE == M_SIMAM ? (nv > 13 ? 1 : 2) : (nv > 13 ? 2 : 3));
         if (grid > a.total) grid = a.total;
         if (XCH) {
             if (ws_bytes < mi355::zoo_workspace_bytes(B, C)) return mi355::fail(MI355_EINVAL, "channel-statistics gate: workspace too small");
@@ -333,7 +353,6 @@ int run(StatArgs a, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
             }
         }
         const size_t smem = XCH ? (size_t)C * 4 : 0;
-        const int nv = (a.n4 + 63) / 64;
         const bool nts = (mi355::opt_nt() & 2) != 0;
 #define GO(NV_)                                                                                        \
         do {                                                                                           \

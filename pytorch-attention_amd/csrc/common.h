@@ -32,6 +32,7 @@ long  opt_gemm_pa_tail();
 long  opt_lpi_patch();
 long  opt_mixer_early();
 long  opt_gemm_small();
+long  opt_mlp_tt4();
 // one-wave 32 x 32 tiles for small outputs (gemm_small.hip): MI355_EUNSUPPORTED when the shape is the engine's
 int   gemm_small_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int precision,
                     hipStream_t st);
@@ -151,6 +152,25 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
     return v;
 }
+// wave_sum() of common.h without address registers: the xor-32 step is one v_permlane32_swap_b32 on two copies of the value (row 0 of
+// one meets row 1 of the other), the xor-16 .. xor-1 steps are ds_swizzle_b32 in bit-mask mode (pattern in the instruction).  Same
+// pairs in the same order as the __shfl_xor butterfly, fp32 addition is commutative: bit-identical sums.  The six ds_bpermute address
+// registers of the __shfl_xor form were loop invariants the 80-register SE kernel had to spill a row chunk for.
+template <int XOR> __device__ __forceinline__ float swz_xor(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1f));
+}
+__device__ __forceinline__ float wave_sum_sw(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    v = a + b;
+    v += swz_xor<16>(v);
+    v += swz_xor<8>(v);
+    v += swz_xor<4>(v);
+    v += swz_xor<2>(v);
+    v += swz_xor<1>(v);
+    return v;
+}
+
 // Logical workgroup id of a 1-D grid such that each XCD works on one CONTIGUOUS range of logical ids (the hardware deals consecutive
 // blockIdx.x to the 8 XCDs round-robin): neighbours in the logical order -- heads of one image, query blocks of one head -- then share
 // an L2.  Bijective for any grid size.

@@ -30,13 +30,16 @@ struct MlpArgs {
     const void* ctx; const void* wp; const float* bp;      // ctx (M, C) 16-bit, wp (C, C) 16-bit, bp (C) fp32
 };
 
-template <int PREC, int C, int HD, bool PROJ = false>
-__global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
+// NWV waves per workgroup (one workgroup per CU), TT 16-token tiles per wave and step.  <16, 2>: 128 registers per lane, four waves per
+// SIMD (the default).  <8, 4> (option "mlp_tt4"): 256 registers, two waves per SIMD, every weight fragment read from LDS feeds FOUR
+// MFMAs instead of two -- the lever VERDICT rounds 2-4 name for CSWin stages 1-2; measured in round 5.
+template <int PREC, int C, int HD, bool PROJ = false, int NWV = 16, int TT = 2>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void mlp_fused_kernel(const MlpArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
     using v4 = typename M_::v4;
     using el = typename M_::e;
-    constexpr int NWV = 16, TT = 2;                 // waves per workgroup, 16-token tiles per wave and step
+    constexpr int NTH = NWV * 64;                   // threads per workgroup
     constexpr int P1 = C + 8;                       // W1 row pitch (elements): rows = hidden units, k = channels
     constexpr int P2 = HD + 4;                      // W2 row pitch: rows = output channels, k = hidden units
     constexpr int SP = C + 4;                       // slab pitch (floats)
@@ -53,18 +56,18 @@ __global__ __launch_bounds__(1024, 4) void mlp_fused_kernel(const MlpArgs a) {
     {
         const el* w1 = static_cast<const el*>(a.w1);
         const el* w2 = static_cast<const el*>(a.w2);
-        for (int i = t; i < HD * (C / 8); i += 1024) {
+        for (int i = t; i < HD * (C / 8); i += NTH) {
             const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
             *reinterpret_cast<v8*>(s_w1 + r * P1 + c8) = *reinterpret_cast<const v8*>(w1 + (long)r * C + c8);
         }
-        for (int i = t; i < C * (HD / 4); i += 1024) {
+        for (int i = t; i < C * (HD / 4); i += NTH) {
             const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             *reinterpret_cast<v4*>(s_w2 + r * P2 + c4) = *reinterpret_cast<const v4*>(w2 + (long)r * HD + c4);
         }
-        for (int i = t; i < HD; i += 1024) s_b1[i] = a.b1[i];
+        for (int i = t; i < HD; i += NTH) s_b1[i] = a.b1[i];
         if constexpr (PROJ) {
             const el* wp = static_cast<const el*>(a.wp);
-            for (int i = t; i < C * (C / 8); i += 1024) {
+            for (int i = t; i < C * (C / 8); i += NTH) {
                 const int r = i / (C / 8), c8 = (i % (C / 8)) * 8;
                 *reinterpret_cast<v8*>(s_wp + r * P1 + c8) = *reinterpret_cast<const v8*>(wp + (long)r * C + c8);
             }
@@ -443,18 +446,24 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    const long nchunk = (M + 31) / 32;
-    long grid = (nchunk + 15) / 16;
-    if (grid > ncu) grid = ncu;
     constexpr size_t smem = mlp_smem<64, 256>();
     static_assert(smem <= 160 * 1024, "LDS budget");
-    if (precision == MI355_PREC_FP16) {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256>), (int)smem)) return rc;
-        mlp_fused_kernel<1, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
-    } else {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256>), (int)smem)) return rc;
-        mlp_fused_kernel<2, 64, 256><<<(int)grid, 1024, smem, st>>>(a);
-    }
+    const bool tt4 = mi355::opt_mlp_tt4() != 0;
+    const long nchunk = (M + (tt4 ? 63 : 31)) / (tt4 ? 64 : 32);
+    long grid = (nchunk + (tt4 ? 7 : 15)) / (tt4 ? 8 : 16);
+    if (grid > ncu) grid = ncu;
+#define MLP64(P_, PR_)                                                                                                                     \
+    do {                                                                                                                                  \
+        if (tt4) {                                                                                                                        \
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<P_, 64, 256, PR_, 8, 4>), (int)smem)) return rc;   \
+            mlp_fused_kernel<P_, 64, 256, PR_, 8, 4><<<(int)grid, 512, smem, st>>>(a);                                                    \
+        } else {                                                                                                                          \
+            if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<P_, 64, 256, PR_>), (int)smem)) return rc; \
+            mlp_fused_kernel<P_, 64, 256, PR_><<<(int)grid, 1024, smem, st>>>(a);                                                         \
+        }                                                                                                                                 \
+    } while (0)
+    if (precision == MI355_PREC_FP16) MLP64(1, false);
+    else MLP64(2, false);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
@@ -488,18 +497,15 @@ extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    const long nchunk = (M + 31) / 32;
-    long grid = (nchunk + 15) / 16;
-    if (grid > ncu) grid = ncu;
     constexpr size_t smem = mlp_smem<64, 256>(true);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    if (precision == MI355_PREC_FP16) {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<1, 64, 256, true>), (int)smem)) return rc;
-        mlp_fused_kernel<1, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
-    } else {
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel<2, 64, 256, true>), (int)smem)) return rc;
-        mlp_fused_kernel<2, 64, 256, true><<<(int)grid, 1024, smem, st>>>(a);
-    }
+    const bool tt4 = mi355::opt_mlp_tt4() != 0;
+    const long nchunk = (M + (tt4 ? 63 : 31)) / (tt4 ? 64 : 32);
+    long grid = (nchunk + (tt4 ? 7 : 15)) / (tt4 ? 8 : 16);
+    if (grid > ncu) grid = ncu;
+    if (precision == MI355_PREC_FP16) MLP64(1, true);
+    else MLP64(2, true);
+#undef MLP64
     MI355_LAUNCH_CHECK();
     return MI355_OK;
 }
