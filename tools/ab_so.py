@@ -153,6 +153,17 @@ elif op in ("pmlp1", "pmlp2"):
         lib.mi355_proj_mlp_fused_fwd.argtypes = [vp] * 10 + [ctypes.c_long, ci, ci, ci, cf, ci, vp]
         fns[k] = (lambda lib=lib, k=k: lib.mi355_proj_mlp_fused_fwd(x.data_ptr(), ctx.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                                                     w2.data_ptr(), b2.data_ptr(), None, outs[k].data_ptr(), M, C, HD, 1, 1e-5, 1, st))
+elif op.startswith("ln") and op[2:].isdigit():
+    # 16-bit LayerNorm (mi355_layernorm16_fwd) on 50 176 rows (256 x 196 tokens) of the given width: ln256 (CSWin s3), ln384 (XCiT), ln512 (Mixer), ln768
+    rows, cols = 256 * (197 if op == "ln768" else 196), int(op[2:])
+    x = torch.randn(rows, cols, device=dev)
+    lw, lb = torch.rand(cols, device=dev) + 0.5, torch.randn(cols, device=dev) * 0.1
+    outs, fns = {}, {}
+    for k, lib in libs.items():
+        outs[k] = torch.empty(rows, cols, device=dev, dtype=torch.float16)
+        lib.mi355_layernorm16_fwd.restype = ci
+        lib.mi355_layernorm16_fwd.argtypes = [vp] * 4 + [ci, ci, cf, ci, vp]
+        fns[k] = (lambda lib=lib, k=k: lib.mi355_layernorm16_fwd(x.data_ptr(), lw.data_ptr(), lb.data_ptr(), outs[k].data_ptr(), rows, cols, 1e-5, 1, st))
 elif op in ("fc1", "qkv", "proj", "fc2"):
     # the four GEMMs of a ViT-Base layer at B = 256 (mi355_linear16_ws_fwd): fc1 = bias + GELU, 16-bit out; fc2 / proj = fp32 + residual
     M = 256 * 197
