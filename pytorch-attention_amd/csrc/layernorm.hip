@@ -11,16 +11,10 @@
 namespace {
 using v4f = float __attribute__((ext_vector_type(4)));
 
-// sum over the LPR lanes of a row group: the xor butterfly of __shfl_xor (LPR / 2, ..., 1) on the swizzle / permlane units (common.h
-// wave_sum_sw: same pairs in the same order -> the same bits, no ds_bpermute address registers, no LDS crossbar round trip per step)
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-    if constexpr (LPR == 64) return wave_sum_sw(v);
-    if constexpr (LPR >= 32) v += swz_xor<16>(v);
-    v += swz_xor<8>(v);
-    v += swz_xor<4>(v);
-    v += swz_xor<2>(v);
-    v += swz_xor<1>(v);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
 
@@ -34,60 +28,49 @@ __device__ __forceinline__ void store4(OT* p, v4f v) {
     }
 }
 
-// RU rows per lane group are in flight together (their loads are issued before the first reduction): a narrow row is one or two float4
-// per lane, and one row per wave at a time kept only ~32 KB per CU in flight -- below what the HBM latency needs (the C = 256 LayerNorm of
-// CSWin stage 3 ran at 3.7 TB/s where the four-float4 ViT rows reach 5.6).  The arithmetic per row is unchanged.
-template <int LPR, int NV, int RU, typename OT>
+template <int LPR, int NV, typename OT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, OT* __restrict__ y, long rows, int cols,
                                                        float eps, unsigned* ovf) {
     float rgmax = 0.f;                                  // fp16 range guard (common.h): a large LayerNorm gain can saturate the operand
-    constexpr int RPW = 64 / LPR;                       // rows per wave and step
+    constexpr int RPW = 64 / LPR;                       // rows per wave
     const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const int n4 = cols >> 2;
     const float inv = 1.0f / (float)cols;
-    for (long r0 = wave0 * (RPW * RU); r0 < rows; r0 += nwaves * (RPW * RU)) {
-        v4f v[RU][NV];
+    for (long r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+        const long row = r0 + rsel;
+        const bool rok = row < rows;
+        const v4f* xr = reinterpret_cast<const v4f*>(x + (rok ? row : 0) * cols);
+        v4f v[NV];
+        float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const long row = r0 + u * RPW + rsel;
-            const bool rok = row < rows;
-            const v4f* xr = reinterpret_cast<const v4f*>(x + (rok ? row : 0) * cols);
+        for (int j = 0; j < NV; ++j) {
+            const int i = sub + LPR * j;
+            v[j] = (rok && i < n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = group_sum<LPR>(s) * inv;
+        float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = sub + LPR * j;
-                v[u][j] = (rok && i < n4) ? xr[i] : v4f{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NV; ++j) {
+            const int i = sub + LPR * j;
+            if (i < n4) {
+                const v4f d = v[j] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
+        const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) * inv + eps);
+        if (!rok) continue;
+        OT* yr = y + row * cols;
 #pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const long row = r0 + u * RPW + rsel;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) s += (v[u][j].x + v[u][j].y) + (v[u][j].z + v[u][j].w);
-            const float mean = group_sum<LPR>(s) * inv;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = sub + LPR * j;
-                if (i < n4) {
-                    const v4f d = v[u][j] - mean;
-                    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-                }
-            }
-            const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) * inv + eps);
-            if (row >= rows) continue;
-            OT* yr = y + row * cols;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = sub + LPR * j;
-                if (i < n4) {
-                    const v4f ww = reinterpret_cast<const v4f*>(w)[i], bb = reinterpret_cast<const v4f*>(b)[i];
-                    const v4f o = (v[u][j] - mean) * rstd * ww + bb;
-                    if constexpr (std::is_same<OT, _Float16>::value) rgmax = rg_absmax4(rgmax, o);
-                    store4<OT>(yr + 4 * i, o);
-                }
+        for (int j = 0; j < NV; ++j) {
+            const int i = sub + LPR * j;
+            if (i < n4) {
+                const v4f ww = reinterpret_cast<const v4f*>(w)[i], bb = reinterpret_cast<const v4f*>(b)[i];
+                const v4f o = (v[j] - mean) * rstd * ww + bb;
+                if constexpr (std::is_same<OT, _Float16>::value) rgmax = rg_absmax4(rgmax, o);
+                store4<OT>(yr + 4 * i, o);
             }
         }
     }
@@ -124,18 +107,18 @@ int launch_ln(const float* x, const float* weight, const float* bias, OT* y, int
     unsigned* ovf = std::is_same<OT, _Float16>::value ? mi355::range_word(st) : nullptr;
     MI355_TRACE(st, "layernorm_kernel<%s> rows=%d cols=%d", std::is_same<OT, float>::value ? "out32" : "out16", rows, cols);
     const bool vec = (cols % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) && aligned16(bias);
-#define LN(LPR_, NV_, RU_)                                                                                          \
+#define LN(LPR_, NV_)                                                                                                \
     do {                                                                                                             \
-        const long waves = ((long)rows + (64 / LPR_) * RU_ - 1) / ((64 / LPR_) * RU_);                              \
+        const long waves = ((long)rows + (64 / LPR_) - 1) / (64 / LPR_);                                            \
         const int grid = (int)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);                                    \
-        layernorm_kernel<LPR_, NV_, RU_, OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps, ovf);           \
+        layernorm_kernel<LPR_, NV_, OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps, ovf);                \
     } while (0)
-    if (vec && cols <= 64)        LN(16, 1, 4);
-    else if (vec && cols <= 128)  LN(32, 1, 4);
-    else if (vec && cols <= 256)  LN(64, 1, 4);
-    else if (vec && cols <= 512)  LN(64, 2, 2);
-    else if (vec && cols <= 1024) LN(64, 4, 1);
-    else if (vec && cols <= 2048) LN(64, 8, 1);
+    if (vec && cols <= 64)        LN(16, 1);
+    else if (vec && cols <= 128)  LN(32, 1);
+    else if (vec && cols <= 256)  LN(64, 1);
+    else if (vec && cols <= 512)  LN(64, 2);
+    else if (vec && cols <= 1024) LN(64, 4);
+    else if (vec && cols <= 2048) LN(64, 8);
     else {
         const int grid = cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192;
         layernorm_generic_kernel<OT><<<grid, 256, 0, st>>>(x, weight, bias, y, rows, cols, eps, ovf);

@@ -48,37 +48,28 @@ struct MixArgs {
 // statistics of layernorm_kernel.
 template <int NV>
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, long rows, int C, float eps) {
-    constexpr int RU = NV <= 2 ? 4 / NV : 1;                    // rows in flight per wave: four float4 per lane outstanding (layernorm.hip)
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const int n4 = C >> 2;
     const float inv = 1.0f / (float)C;
-    for (long r0 = wave0 * RU; r0 < rows; r0 += nwaves * RU) {
-        f4 v[RU][NV];
+    for (long row = wave0; row < rows; row += nwaves) {
+        const f4* xr = reinterpret_cast<const f4*>(x + row * C);
+        f4 v[NV];
+        float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const long row = r0 + u < rows ? r0 + u : rows - 1;
-            const f4* xr = reinterpret_cast<const f4*>(x + row * C);
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int i = lane + 64 * k;
-                v[u][k] = i < n4 ? xr[i] : f4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + 64 * k;
+            v[k] = i < n4 ? xr[i] : f4{0.f, 0.f, 0.f, 0.f};
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
 #pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) s += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
-            const float mean = wave_sum_sw(s) * inv;
-            float q = 0.f;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (lane + 64 * k < n4) { const f4 d = v[u][k] - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-            }
-            const float r = 1.0f / sqrtf(wave_sum_sw(q) * inv + eps);
-            if (lane == 0 && r0 + u < rows) { stats[(r0 + u) * 2] = mean; stats[(r0 + u) * 2 + 1] = r; }
+        for (int k = 0; k < NV; ++k) {
+            if (lane + 64 * k < n4) { const f4 d = v[k] - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
         }
+        const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
+        if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = r; }
     }
 }
 
@@ -295,7 +286,7 @@ int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* stats = static_cast<float*>(ws);
     const long rows = (long)B * N;
-    const int sgrid = (int)(cdiv(rows, 8) < 8192 ? cdiv(rows, 8) : 8192);
+    const int sgrid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
     {
         MI355_TRACE(st, "row_stats_kernel rows=%ld cols=%d", rows, C);
         if (C <= 256) row_stats_kernel<1><<<sgrid, 256, 0, st>>>(x, stats, rows, C, ln_eps);

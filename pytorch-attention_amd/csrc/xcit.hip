@@ -551,32 +551,17 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
         const float* xr = x + row * cols;
         float s = 0.f, q = 0.f;
         if (vec && cols <= 512) {                                       // the row fits two float4 per lane: read once (same sums, same order)
-            // TWO rows per wave and step (rows `row` and `row + nwaves`), their loads issued together: one narrow row at a time left too
-            // few bytes in flight per CU (layernorm.hip)
             const int n4 = cols >> 2;
             const bool h0 = lane < n4, h1 = lane + 64 < n4;
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-            const long row2 = row + nwaves;
-            const bool two = row2 < rows;
-            const float* xr2 = x + (two ? row2 : row) * cols;
             const f4 v0 = h0 ? reinterpret_cast<const f4*>(xr)[lane] : z, v1 = h1 ? reinterpret_cast<const f4*>(xr)[lane + 64] : z;
-            const f4 u0 = h0 ? reinterpret_cast<const f4*>(xr2)[lane] : z, u1 = h1 ? reinterpret_cast<const f4*>(xr2)[lane + 64] : z;
             if (h0) s += (v0.x + v0.y) + (v0.z + v0.w);
             if (h1) s += (v1.x + v1.y) + (v1.z + v1.w);
-            const float mean = wave_sum_sw(s) * inv;
+            const float mean = wave_sum(s) * inv;
             if (h0) { const f4 d = v0 - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
             if (h1) { const f4 d = v1 - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-            const float r = 1.0f / sqrtf(wave_sum_sw(q) * inv + eps);
+            const float r = 1.0f / sqrtf(wave_sum(q) * inv + eps);
             if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = r; }
-            float s2 = 0.f, q2 = 0.f;
-            if (h0) s2 += (u0.x + u0.y) + (u0.z + u0.w);
-            if (h1) s2 += (u1.x + u1.y) + (u1.z + u1.w);
-            const float mean2 = wave_sum_sw(s2) * inv;
-            if (h0) { const f4 d = u0 - mean2; q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-            if (h1) { const f4 d = u1 - mean2; q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-            const float r2 = 1.0f / sqrtf(wave_sum_sw(q2) * inv + eps);
-            if (lane == 0 && two) { stats[row2 * 2] = mean2; stats[row2 * 2 + 1] = r2; }
-            row += nwaves;                                              // the loop's own step skips the second row
         } else if (vec) {
             const int n4 = cols >> 2;
             for (int i = lane; i < n4; i += 64) { const f4 v = reinterpret_cast<const f4*>(xr)[i]; s += (v.x + v.y) + (v.z + v.w); }
