@@ -29,7 +29,7 @@ constexpr int MX_PU = MX_NK + 8;                 // pitch of the parked operand 
 constexpr int MX_P2 = 32 + 4;                    // pitch of the W2 slice rows
 constexpr int MX_W1S = 32 * MX_PU, MX_W2S = MX_NP * MX_P2, MX_STAGE = MX_W1S + MX_W2S;
 constexpr int MX_REGION = 32 * MX_PU;            // elements per wave-private region
-constexpr size_t MX_LDS = (size_t)8 * MX_REGION * 2 + (size_t)(MX_TMAX + MX_NP) * 4;
+constexpr size_t MX_LDS = (size_t)8 * MX_REGION * 2 + (size_t)(MX_TMAX + MX_NP + 2 * MX_NP) * 4;
 static_assert((size_t)2 * MX_STAGE * 2 <= (size_t)8 * MX_REGION * 2, "the two weight stages alias the parked operand");
 static_assert(MX_LDS <= 160 * 1024, "LDS budget");
 
@@ -40,6 +40,8 @@ struct MixArgs {
     const void* w2s;            // (T / 32, 208, 32) 16-bit slice-major, rows >= 196 zero
     const float* b1; const float* b2;
     int C, halves, T;           // halves = C / 256 workgroups per image; T hidden token units
+    int pair_xcd;               // halves == 2 and B % 8 == 0: the two workgroups of an image get block ids 8 apart (same XCD)
+    float eps;                  // LayerNorm eps (STATS kernels)
     unsigned* ovf;              // fp16 range word (common.h rg_report): the 16-bit LN(x) and gelu(H) operands are tracked like the
                                 // stand-alone producers they replace (layernorm16_t, the 16-bit GEMM epilogue); null = unguarded
 };
@@ -76,7 +78,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
 // EARLY: the residual loads of phase 3 are issued in two batches of 14 / 12 ahead of their stores (two exposed round trips instead of
 // thirteen: hipcc pairs every token tile's loads with an s_waitcnt vmcnt(0) in front of its stores); the operand registers of phase 2
 // are dead by then.  All 26 at once needs 256 registers and spills in the fp16 instantiation.
-template <int PREC, bool EARLY>
+// STATS: the row statistics of LayerNorm are computed INSIDE the kernel (phase 0) instead of by the row_stats_kernel pre-pass: a
+// workgroup holds only half (C = 512) of a token's channels, so each workgroup of an image reads the image's WHOLE rows once more for
+// the statistics -- 2 x the kernel's reads, but the second request for a line is served by L2 when the workgroups of an image run on
+// one XCD (block ids 8 apart: see the id mapping), and the 23 us pre-pass (103 MB from HBM + a launch) disappears.  Same per-lane sums
+// in the same order as row_stats_kernel: bit-identical statistics.
+template <int PREC, bool EARLY, bool STATS>
 __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
@@ -87,13 +94,63 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     el* s_el = reinterpret_cast<el*>(lds);                          // phase 1: 8 regions [32][PU]; phase 2: two stages
     float* s_b1 = reinterpret_cast<float*>(s_el + 8 * MX_REGION);
     float* s_b2 = s_b1 + MX_TMAX;
+    float* s_st = s_b2 + MX_NP;                                      // STATS: {mean, rstd} per token (196 x 2 floats)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.halves, cw = (blockIdx.x % a.halves) * 256 + wave * 32;      // this wave's first channel
+    // (image, channel half) of this workgroup.  Two halves and a batch that is a multiple of 8: ids 16 k + h * 8 + j belong to image
+    // 8 k + j -- the two workgroups of an image are 8 ids apart, i.e. on the same XCD (ids go to the 8 XCDs round-robin) and
+    // dispatched together, so whatever one fetches the other finds in that XCD's L2.
+    int b, hsel;
+    if (a.halves == 2 && a.pair_xcd) {
+        const int grp = blockIdx.x >> 4, r = blockIdx.x & 15;
+        b = grp * 8 + (r & 7);
+        hsel = r >> 3;
+    } else {
+        b = blockIdx.x / a.halves;
+        hsel = blockIdx.x % a.halves;
+    }
+    const int cw = hsel * 256 + wave * 32;                            // this wave's first channel
     const int C = a.C;
     if (t < a.T) s_b1[t] = a.b1[t];
     if (t < MX_NP) s_b2[t] = t < MX_N ? a.b2[t] : 0.f;
     float rgmax = 0.f;                                              // fp16 range guard: largest finite magnitude this lane converts
+
+    // ---- phase 0 (STATS): mean / rstd of the image's 196 token rows, wave w takes tokens w, w + 8, ...; five rows in flight --------------
+    if constexpr (STATS) {
+        const int n4 = C >> 2;
+        const float inv = 1.0f / (float)C;
+        const float* xi = a.x + (long)b * MX_N * C;
+#pragma unroll 1
+        for (int n0 = wave; n0 < MX_N; n0 += 8 * 5) {
+            f4 v[5][4];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int n = n0 + 8 * u;
+                const f4* xr = reinterpret_cast<const f4*>(xi + (long)(n < MX_N ? n : MX_N - 1) * C);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = lane + 64 * k;
+                    v[u][k] = (k * 64 < n4 && i < n4) ? xr[i] : f4{0.f, 0.f, 0.f, 0.f};      // C <= 1024: at most four float4 per lane
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int n = n0 + 8 * u;
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+                const float mean = wave_sum_sw(sm) * inv;
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (lane + 64 * k < n4) { const f4 d = v[u][k] - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+                }
+                const float r = 1.0f / sqrtf(wave_sum_sw(q) * inv + a.eps);
+                if (lane == 0 && n < MX_N) { s_st[2 * n] = mean; s_st[2 * n + 1] = r; }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- phase 1: LayerNorm of the wave's 32-channel slab, parked channel-major (two tokens per word) ----------------------------------
     {
@@ -113,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
                 if (2 * p < MX_N) {
                     xa[i] = *reinterpret_cast<const f4*>(xb0 + (long)(2 * p) * C);
                     xc[i] = *reinterpret_cast<const f4*>(xb0 + (long)(2 * p + 1) * C);
-                    st[i] = *reinterpret_cast<const f4*>(st0 + 4 * p);     // {mean, rstd} of both tokens
+                    if constexpr (STATS) st[i] = *reinterpret_cast<const f4*>(s_st + 4 * p);
+                    else st[i] = *reinterpret_cast<const f4*>(st0 + 4 * p);    // {mean, rstd} of both tokens
                 }
             }
 #pragma unroll
@@ -286,29 +344,37 @@ int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* stats = static_cast<float*>(ws);
     const long rows = (long)B * N;
-    const int sgrid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
-    {
+    const bool instats = mi355::opt_mixer_stats() != 0;                // statistics inside the token kernel (phase 0) or by the pre-pass
+    if (!instats) {
+        const int sgrid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
         MI355_TRACE(st, "row_stats_kernel rows=%ld cols=%d", rows, C);
         if (C <= 256) row_stats_kernel<1><<<sgrid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
         else if (C <= 512) row_stats_kernel<2><<<sgrid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
         else row_stats_kernel<4><<<sgrid, 256, 0, st>>>(x, stats, rows, C, ln_eps);
+        MI355_LAUNCH_CHECK();
     }
-    MI355_LAUNCH_CHECK();
     MixArgs a{};
     a.x = x; a.y = y; a.stats = stats; a.ln_w = ln_w; a.ln_b = ln_b; a.w1p = w1p16; a.w2s = w2s16; a.b1 = b1; a.b2 = b2;
-    a.C = C; a.halves = C / 256; a.T = T;
+    a.C = C; a.halves = C / 256; a.T = T; a.eps = ln_eps;
+    a.pair_xcd = (a.halves == 2 && (B % 8) == 0) ? 1 : 0;
     const long grid = (long)B * a.halves;
     if (grid >= (1L << 31)) return mi355::fail(MI355_EUNSUPPORTED, "mi355_mixer_token_fwd: batch too large");
     a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
     const bool early = mi355::opt_mixer_early() != 0;
-    MI355_TRACE(st, "mixer_token_kernel%s B=%d C=%d", early ? "<early>" : "", B, C);
-#define MIXER_LAUNCH(P_, E_)                                                                                                          \
+    MI355_TRACE(st, "mixer_token_kernel%s%s B=%d C=%d", early ? "<early>" : "", instats ? "<stats>" : "", B, C);
+#define MIXER_LAUNCH(P_, E_, S_)                                                                                                      \
     do {                                                                                                                             \
-        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mixer_token_kernel<P_, E_>), (int)MX_LDS)) return rc;      \
-        mixer_token_kernel<P_, E_><<<(int)grid, 512, MX_LDS, st>>>(a);                                                               \
+        if (int rc = mi355::func_dynamic_lds(reinterpret_cast<const void*>(mixer_token_kernel<P_, E_, S_>), (int)MX_LDS)) return rc;  \
+        mixer_token_kernel<P_, E_, S_><<<(int)grid, 512, MX_LDS, st>>>(a);                                                           \
     } while (0)
-    if (precision == MI355_PREC_FP16) { if (early) MIXER_LAUNCH(1, true); else MIXER_LAUNCH(1, false); }
-    else                              { if (early) MIXER_LAUNCH(2, true); else MIXER_LAUNCH(2, false); }
+#define MIXER_BY(P_)                                                                            \
+    do {                                                                                        \
+        if (early) { if (instats) MIXER_LAUNCH(P_, true, true); else MIXER_LAUNCH(P_, true, false); }   \
+        else       { if (instats) MIXER_LAUNCH(P_, false, true); else MIXER_LAUNCH(P_, false, false); } \
+    } while (0)
+    if (precision == MI355_PREC_FP16) MIXER_BY(1);
+    else MIXER_BY(2);
+#undef MIXER_BY
 #undef MIXER_LAUNCH
     MI355_LAUNCH_CHECK();
     return MI355_OK;

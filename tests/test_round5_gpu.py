@@ -227,3 +227,33 @@ def test_fused_mlp_four_tile_variant_is_bit_identical(prec):
     finally:
         mi355attn.set_option("mlp_tt4", old)
     assert torch.isfinite(y0).all() and torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,C", [(8, 512), (5, 512), (16, 256), (3, 768)])
+def test_mixer_statistics_inside_the_token_kernel_are_bit_identical(B, C, prec):
+    """Option "mixer_stats": LayerNorm row statistics computed inside mixer_token_kernel (phase 0, every workgroup of an image reads the
+    image's rows once more; the two workgroups of an image get block ids 8 apart when B % 8 == 0) against the row_stats_kernel pre-pass:
+    same per-lane sums in the same order, hence the same bits -- for one / two / three workgroups per image and both id mappings."""
+    import mi355attn
+    from mi355attn.modules import MixerLayer
+    torch.manual_seed(B * 100 + C)
+    m = MixerLayer(C, 196, precision=prec).eval().cuda()
+    with torch.no_grad():
+        m.norm1.weight.uniform_(0.5, 1.5)
+        m.norm1.bias.normal_(0, 0.2)
+    x = torch.randn(B, 196, C, device="cuda") * 1.7 + 0.3
+    old = mi355attn.get_option("mixer_stats")
+    try:
+        with torch.no_grad():
+            mi355attn.set_option("mixer_stats", 0)
+            t0 = [t for t, *_ in mi355attn.kernel_trace(lambda: m(x))]
+            y0 = m(x)
+            mi355attn.set_option("mixer_stats", 1)
+            seen = []
+            t1 = [t for t, *_ in mi355attn.kernel_trace(lambda: seen.append(m(x)))]
+    finally:
+        mi355attn.set_option("mixer_stats", old)
+    assert any("row_stats_kernel" in t for t in t0) and not any("row_stats_kernel" in t for t in t1), (t0, t1)
+    assert any("mixer_token_kernel<stats>" in t for t in t1), t1
+    assert torch.isfinite(y0).all() and torch.equal(y0, seen[0])
