@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
 // workgroup holds only half (C = 512) of a token's channels, so each workgroup of an image reads the image's WHOLE rows once more for
 // the statistics -- 2 x the kernel's reads, but the second request for a line is served by L2 when the workgroups of an image run on
 // one XCD (block ids 8 apart: see the id mapping), and the 23 us pre-pass (103 MB from HBM + a launch) disappears.  Same per-lane sums
-// in the same order as row_stats_kernel: bit-identical statistics.
-template <int PREC, bool EARLY, bool STATS>
+// in the same order as row_stats_kernel: bit-identical statistics.  STATS = float4 per lane and row (C / 256; 0 = pre-pass).
+template <int PREC, bool EARLY, int STATS>
 __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     using M_ = Mma<PREC>;
     using v8 = typename M_::v8;
@@ -115,38 +115,52 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
     if (t < MX_NP) s_b2[t] = t < MX_N ? a.b2[t] : 0.f;
     float rgmax = 0.f;                                              // fp16 range guard: largest finite magnitude this lane converts
 
-    // ---- phase 0 (STATS): mean / rstd of the image's 196 token rows, wave w takes tokens w, w + 8, ...; five rows in flight --------------
-    if constexpr (STATS) {
+    // ---- phase 0 (STATS): mean / rstd of the image's 196 token rows, wave w takes tokens w, w + 8, ...: 13 rows in flight, then 12; the
+    //      reductions of a batch are independent chains (their swizzles pipeline) ---------------------------------------------------------
+    if constexpr (STATS != 0) {
+        constexpr int RB = 13;
         const int n4 = C >> 2;
         const float inv = 1.0f / (float)C;
         const float* xi = a.x + (long)b * MX_N * C;
 #pragma unroll 1
-        for (int n0 = wave; n0 < MX_N; n0 += 8 * 5) {
-            f4 v[5][4];
+        for (int n0 = wave; n0 < MX_N; n0 += 8 * RB) {
+            f4 v[RB][STATS];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const int n = n0 + 8 * u;
                 const f4* xr = reinterpret_cast<const f4*>(xi + (long)(n < MX_N ? n : MX_N - 1) * C);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < STATS; ++k) {
                     const int i = lane + 64 * k;
-                    v[u][k] = (k * 64 < n4 && i < n4) ? xr[i] : f4{0.f, 0.f, 0.f, 0.f};      // C <= 1024: at most four float4 per lane
+                    v[u][k] = i < n4 ? xr[i] : f4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            float mean[RB], q[RB];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int n = n0 + 8 * u;
+            for (int u = 0; u < RB; ++u) {
                 float sm = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sm += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
-                const float mean = wave_sum_sw(sm) * inv;
-                float q = 0.f;
+                for (int k = 0; k < STATS; ++k) sm += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+                mean[u] = sm;
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (lane + 64 * k < n4) { const f4 d = v[u][k] - mean; q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+            for (int u = 0; u < RB; ++u) mean[u] = wave_sum_sw(mean[u]) * inv;
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                float qq = 0.f;
+#pragma unroll
+                for (int k = 0; k < STATS; ++k) {
+                    if (lane + 64 * k < n4) { const f4 d = v[u][k] - mean[u]; qq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
                 }
-                const float r = 1.0f / sqrtf(wave_sum_sw(q) * inv + a.eps);
-                if (lane == 0 && n < MX_N) { s_st[2 * n] = mean; s_st[2 * n + 1] = r; }
+                q[u] = qq;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) q[u] = wave_sum_sw(q[u]);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int n = n0 + 8 * u;
+                const float r = 1.0f / sqrtf(q[u] * inv + a.eps);
+                if (lane == 0 && n < MX_N) { s_st[2 * n] = mean[u]; s_st[2 * n + 1] = r; }
             }
         }
         __syncthreads();
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void mixer_token_kernel(const MixArgs a) {
                 if (2 * p < MX_N) {
                     xa[i] = *reinterpret_cast<const f4*>(xb0 + (long)(2 * p) * C);
                     xc[i] = *reinterpret_cast<const f4*>(xb0 + (long)(2 * p + 1) * C);
-                    if constexpr (STATS) st[i] = *reinterpret_cast<const f4*>(s_st + 4 * p);
+                    if constexpr (STATS != 0) st[i] = *reinterpret_cast<const f4*>(s_st + 4 * p);
                     else st[i] = *reinterpret_cast<const f4*>(st0 + 4 * p);    // {mean, rstd} of both tokens
                 }
             }
@@ -344,7 +358,7 @@ int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* stats = static_cast<float*>(ws);
     const long rows = (long)B * N;
-    const bool instats = mi355::opt_mixer_stats() != 0;                // statistics inside the token kernel (phase 0) or by the pre-pass
+    const bool instats = mi355::opt_mixer_stats() != 0 && C == 512;    // statistics inside the token kernel (phase 0; built for C = 512) or by the pre-pass
     if (!instats) {
         const int sgrid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
         MI355_TRACE(st, "row_stats_kernel rows=%ld cols=%d", rows, C);
@@ -369,8 +383,8 @@ int mi355_mixer_token_fwd(const float* x, const float* ln_w, const float* ln_b, 
     } while (0)
 #define MIXER_BY(P_)                                                                            \
     do {                                                                                        \
-        if (early) { if (instats) MIXER_LAUNCH(P_, true, true); else MIXER_LAUNCH(P_, true, false); }   \
-        else       { if (instats) MIXER_LAUNCH(P_, false, true); else MIXER_LAUNCH(P_, false, false); } \
+        if (early) { if (instats) MIXER_LAUNCH(P_, true, 2); else MIXER_LAUNCH(P_, true, 0); }   \
+        else       { if (instats) MIXER_LAUNCH(P_, false, 2); else MIXER_LAUNCH(P_, false, 0); } \
     } while (0)
     if (precision == MI355_PREC_FP16) MIXER_BY(1);
     else MIXER_BY(2);
