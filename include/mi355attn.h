@@ -114,9 +114,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "mlp_tt4"       mi355_mlp_fused_fwd / mi355_proj_mlp_fused_fwd at C = 64: 1 = eight waves with four 16-token tiles each (256 registers per
  *                   lane, a weight fragment read from LDS feeds four MFMAs); 0 (default) = sixteen waves with two tiles (128 registers).
  *                   Bit-identical results.
- *   "mixer_stats"   mi355_mixer_token_fwd: 1 (default) = the LayerNorm row statistics are computed inside the token kernel (every workgroup
+ *   "mixer_stats"   mi355_mixer_token_fwd at C = 512: 1 = the LayerNorm row statistics are computed inside the token kernel (every workgroup
  *                   of an image reads the image's rows once more, the second request served by L2: the two workgroups of an image run
- *                   on one XCD); 0 = by a separate statistics pass over x.  Bit-identical results.
+ *                   on one XCD); 0 (default) = by a separate statistics pass over x.  Bit-identical results; measured in round 5: the two
+ *                   cost the same (MixerLayer 0.428-0.433 vs 0.432-0.437 ms on one box), so the simpler pre-pass stays the default.
  *   "mixer_early"   mi355_mixer_token_fwd: 1 = the kernel issues the residual loads of its epilogue in two batches ahead of their stores (two
  *                   exposed round trips instead of thirteen; bit-identical results); 0 (default) = a token tile's loads right before its stores.
  *   "lpi_patch"     1 (default) = mi355_lpi_fwd / mi355_ln_lpi_fwd at 14 x 14 tokens with C % 32 == 0 run the patch kernel (a lane owns a

@@ -49,7 +49,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"mixer_early", 0, 0, 1},              // mixer_token_kernel: all residual loads of the epilogue before its first store (A/B switch)
     {"gemm_small", 1, 0, 1},               // mi355_linear_fwd: outputs under an eighth of a round of 128 x 128 tiles on one-wave 16 x 32 tiles (gemm_small.hip)
     {"mlp_tt4", 0, 0, 1},                  // fused MLP at C = 64 (CSWin stage 1): 8 waves x 4 token tiles at 256 VGPRs instead of 16 x 2 at 128 (A/B switch)
-    {"mixer_stats", 1, 0, 1},              // mixer_token_kernel: LayerNorm row statistics inside the kernel (1) or by the row_stats_kernel pre-pass (0)
+    {"mixer_stats", 0, 0, 1},              // mixer_token_kernel at C = 512: LayerNorm row statistics inside the kernel (1) or by the row_stats_kernel pre-pass (0, default: measured equal)
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
