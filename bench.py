@@ -157,7 +157,7 @@ def load_pmc_traffic():
     have, want = tab.get("_csrc_sha16"), csrc_fingerprint()
     if have != want:
         return {}, "stale: profiles/pmc_traffic.json was measured at csrc %s, this tree is %s -- traffic not reported" % (have, want)
-    return dict(tab.get("all", {})), "PMC FETCH_SIZE x 2 + WRITE_SIZE per block forward (separate rocprofv3 passes, tools/gpu_round3.sh) at csrc %s" % want
+    return dict(tab.get("all", {})), "PMC FETCH_SIZE x 2 + WRITE_SIZE per block forward (separate rocprofv3 passes, tools/gpu_round5_final.sh) at csrc %s" % want
 
 
 # ------------------------------------------------------------------------------------------------------------
