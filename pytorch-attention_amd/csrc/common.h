@@ -209,6 +209,16 @@ __device__ __forceinline__ void rg_report(float m, unsigned* word, unsigned code
     if (word && (int)__float_as_uint(m) >= (int)(0x477FF000u + 0x00800000u))         // bits(65520.0f) + 2^23
         __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Float form of the same guard (compare + select per group; the accumulator holds the magnitude itself).  gemm16_pa keeps it: its
+// epilogue pieces ride in the next tile's main loop, where the two extra VALU instructions are free, and with the integer form the
+// three-piece instantiations (K = 256) spilled 76 B per lane at their 256-register budget.
+__device__ __forceinline__ float rg_absmax4_f(float m, rg_f4 v) {
+    const float g = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    return g < __builtin_inff() ? fmaxf(m, g) : m;
+}
+__device__ __forceinline__ void rg_report_f(float m, unsigned* word, unsigned code) {
+    if (word && m >= 65520.0f) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ float se_gate(float z, int kind) {
     if (!kind) return sigmoidf_(z);
     const float h = fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f;                    // relu6 clamps; torch's clamp keeps a NaN

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     // C (16-bit): one accumulator tile (row tile i, column tile j) -> slab, accumulator layout (lane = row l15, 4 columns fq4*4..)
     auto epi_c16 = [&](f4 a, f4 b, int j) {
         const f4 v = act4(a + b);
-        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4(rgmax, v);        // fp16 range guard (common.h)
+        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4_f(rgmax, v);      // fp16 range guard, float form (common.h)
         unsigned wa = sw_w16;
         asm volatile("" : "+v"(wa));                // keep the XOR at the use: four hoisted address registers would spill
         *reinterpret_cast<v4*>(slab + (wa ^ (unsigned)(j * 32))) = v4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm16_pa_kernel(const G16Args g, const P
     if (wr == 0) PA_BAR();                                       // barrier balance: 1 + 4 * total_kt + 1 per wave
     if (my_count & 1) drain(acc0);
     else drain(acc1);
-    if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report(rgmax, g.ovf, 3u);
+    if constexpr (OUT16 && std::is_same<T, _Float16>::value) rg_report_f(rgmax, g.ovf, 3u);
 #undef PA_BAR
 }
 
