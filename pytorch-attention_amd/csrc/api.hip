@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -50,6 +50,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"gemm_small", 1, 0, 1},               // mi355_linear_fwd: outputs under an eighth of a round of 128 x 128 tiles on one-wave 16 x 32 tiles (gemm_small.hip)
     {"mlp_tt4", 0, 0, 1},                  // fused MLP at C = 64 (CSWin stage 1): 8 waves x 4 token tiles at 256 VGPRs instead of 16 x 2 at 128 (A/B switch)
     {"mixer_stats", 0, 0, 1},              // mixer_token_kernel at C = 512: LayerNorm row statistics inside the kernel (1) or by the row_stats_kernel pre-pass (0, default: measured equal)
+    {"attn_nw", 8, 7, 8},                  // ViT attention core at 193 .. 208 tokens (13 query tiles): waves per workgroup, 8 (13 / 16 balance) or 7 (13 / 14)
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
@@ -102,6 +103,7 @@ long opt_mixer_early() { return opt(O_MIXER_EARLY); }
 long opt_gemm_small() { return opt(O_GEMM_SMALL); }
 long opt_mlp_tt4() { return opt(O_MLP_TT4); }
 long opt_mixer_stats() { return opt(O_MIXER_STATS); }
+long opt_attn_nw() { return opt(O_ATTN_NW); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the

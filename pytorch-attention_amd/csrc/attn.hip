@@ -445,7 +445,11 @@ int launch_attn(const AttnArgs& a, int B, int precision, hipStream_t st, const A
     do {                                                 \
         if (a.T <= 64) { if (hot && P != 0 && a.T >= 48) GO_FULL(P, 4, 4, 6, 3); else GO_OCC(P, 4, 4, 6); }          \
         else if (a.T <= 128) { if (hot && P != 0 && a.T >= 96) GO_FULL(P, 8, 4, 5, 6); else GO_OCC(P, 8, 4, 5); }    \
-        else if (IO16 && P != 0) { if (a.T >= 192) GO_FULL(P, 14, 8, 1, 12); else GO(P, 14, 8); }                    \
+        else if (IO16 && P != 0) {                                                                                    \
+            /* 193 .. 208 tokens = 13 query tiles: on 8 waves five waves carry two tiles and three carry one (13 / 16), on 7 waves */ \
+            /* six carry two and one carries one (13 / 14): option "attn_nw" (A/B switch, round 5) */                    \
+            if (a.T >= 192 && a.T <= 208 && mi355::opt_attn_nw() == 7) GO_FULL(P, 14, 7, 1, 12);                          \
+            else if (a.T >= 192) GO_FULL(P, 14, 8, 1, 12); else GO(P, 14, 8); }                                          \
         else GO(P, 14, 4);                               \
     } while (0)
     switch (precision) {

@@ -258,3 +258,24 @@ def test_mixer_statistics_inside_the_token_kernel_are_bit_identical(B, C, prec):
     if C == 512:                                                       # phase 0 is built for C = 512 (two float4 per lane and row)
         assert not any("row_stats_kernel" in t for t in t1) and any("mixer_token_kernel<stats>" in t for t in t1), t1
     assert torch.isfinite(y0).all() and torch.equal(y0, seen[0])
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+def test_attention_core_on_seven_waves_is_bit_identical(prec):
+    """Option "attn_nw" = 7: the 13 query tiles of a 197-token head on seven waves (six carry two tiles, one carries one) instead of eight
+    (five carry two, three carry one).  A query tile's arithmetic does not depend on the wave that owns it: same bits."""
+    import mi355attn
+    from mi355attn.modules import Attention
+    torch.manual_seed(3)
+    m = Attention(768, 12, precision=prec).eval().cuda()
+    x = torch.randn(5, 197, 768, device="cuda")
+    old = mi355attn.get_option("attn_nw")
+    try:
+        with torch.no_grad():
+            mi355attn.set_option("attn_nw", 8)
+            y8 = m(x)
+            mi355attn.set_option("attn_nw", 7)
+            y7 = m(x)
+    finally:
+        mi355attn.set_option("attn_nw", old)
+    assert torch.isfinite(y8).all() and torch.equal(y8, y7)
