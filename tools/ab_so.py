@@ -65,7 +65,7 @@ elif op in ("se", "cbam", "eca"):
             lib.mi355_cbam_fwd.restype = ci; lib.mi355_cbam_fwd.argtypes = [vp] * 5 + [ci] * 7 + [vp, sz, vp]
             n = lib.mi355_cbam_workspace_bytes(256, 256, 56, 56)
             wss[k] = torch.zeros(n, dtype=torch.uint8, device=dev)
-            fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_cbam_fwd(x.data_ptr(), w1.data_ptr(), w2.data_ptr(), wc.data_ptr(), outs[k].data_ptr(), 256, 256, 16, 56, 56, 7, 0, wss[k].data_ptr(), n, st))
+            fns[k] = (lambda lib=lib, k=k, n=n: lib.mi355_cbam_fwd(x.data_ptr(), w1.data_ptr(), w2.data_ptr(), wc.data_ptr(), outs[k].data_ptr(), 256, 256, 16, 7, 56, 56, 0, wss[k].data_ptr(), n, st))
         else:
             lib.mi355_eca_workspace_bytes.restype = sz; lib.mi355_eca_workspace_bytes.argtypes = [ci] * 4
             lib.mi355_eca_fwd.restype = ci; lib.mi355_eca_fwd.argtypes = [vp, vp, vp] + [ci] * 5 + [vp, sz, vp]

@@ -140,6 +140,158 @@ static void run(int wps, int ncu, float* sink, unsigned long long* rep) {
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
 
+// 128 x 128 outputs per wave (K = 32 per body): 8 A x 8 B fragments = 64 MFMAs on 64 accumulator quads = 256 ACCUMULATION registers (AGPRs), one wave per
+// SIMD; LDS = 1: the 16 ds_read_b128 fragment reads of the step in the body (0.25 reads per MFMA against 0.375 for the 128 x 64 wave tile)
+template <int LDS>
+__global__ __launch_bounds__(256) void probe128(int iters, float* sink, unsigned long long* rep) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[4 * 16 * 64 * 8];          // per wave: 16 fragments x 64 lanes x 16 bytes
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Float16* mine = img + wave * 16 * 64 * 8;
+    for (int f = 0; f < 16; ++f) *reinterpret_cast<h8*>(mine + (f * 64 + lane) * 8) = frag(lane * 2654435761u + f * 97u + blockIdx.x);
+    __syncthreads();
+    h8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const h8*>(mine + (i * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = *reinterpret_cast<const h8*>(mine + ((8 + i) * 64 + lane) * 8);
+    unsigned long long c0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f4 acc[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        h8 na[8], nb[8];
+        if (LDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) na[i] = *reinterpret_cast<const volatile h8*>(mine + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nb[i] = *reinterpret_cast<const volatile h8*>(mine + ((8 + i) * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i * 8 + j]) : "v"(a[i]), "v"(b[j]));
+        if (LDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a[i] = na[i]; b[i] = nb[i]; }
+        }
+    }
+    float out = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) out += acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+    if (stamp) { rep[0] = __builtin_readcyclecounter() - c0; rep[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    if (out == 12345.678f) sink[0] = out;
+}
+
+template <int LDS>
+static void run128(int ncu, float* sink, unsigned long long* rep) {
+    const int grid = ncu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int iters = 1000;
+    float ms = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        CK(hipEventRecord(e0));
+        probe128<LDS><<<grid, 256>>>(iters, sink, rep);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 0) iters = (int)(iters * 30.0 / (ms > 0.01f ? ms : 0.01f));
+        if (iters > (1 << 22)) iters = 1 << 22;
+    }
+    unsigned long long h[2];
+    CK(hipMemcpy(h, rep, sizeof(h), hipMemcpyDeviceToHost));
+    const double mfma = (double)grid * 4 * iters * 64;
+    const double tf = mfma * 16384.0 / (ms * 1e-3) / 1e12;
+    const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    const double cyc = (double)h[0] / ((double)iters * 64);
+    printf("| 16x16x32, 128 x 128 per wave | %s | 1 | %8.1f | %7.0f | %6.2f | %6.1f |\n", LDS ? "16 ds_read_b128 / K32" : "none", tf, mhz, cyc, ms);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
+// the same 128 x 128 wave tile with the 16 fragment reads of the NEXT step issued by hand BETWEEN the MFMAs of this one (one ds_read_b128 per RPM
+// MFMAs from the start of the body, two register sets used alternately, one counted wait at the end of the body): what a one-wave-per-SIMD main loop
+// can do -- nobody else on the SIMD hides the LDS latency
+#define DSR(dst, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(lds_addr))
+template <int RPM>
+__device__ __forceinline__ void body128(f4 (&acc)[64], const h8 (&ca)[8], const h8 (&cb)[8], h8 (&na)[8], h8 (&nb)[8], unsigned lds_addr) {
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = i * 8 + j;
+            if (m % RPM == 0 && issued < 16) {
+                switch (issued) {
+                    case 0: DSR(na[0], 0); break;      case 1: DSR(nb[0], 8192); break;
+                    case 2: DSR(na[1], 1024); break;   case 3: DSR(nb[1], 9216); break;
+                    case 4: DSR(na[2], 2048); break;   case 5: DSR(nb[2], 10240); break;
+                    case 6: DSR(na[3], 3072); break;   case 7: DSR(nb[3], 11264); break;
+                    case 8: DSR(na[4], 4096); break;   case 9: DSR(nb[4], 12288); break;
+                    case 10: DSR(na[5], 5120); break;  case 11: DSR(nb[5], 13312); break;
+                    case 12: DSR(na[6], 6144); break;  case 13: DSR(nb[6], 14336); break;
+                    case 14: DSR(na[7], 7168); break;  default: DSR(nb[7], 15360); break;
+                }
+                ++issued;
+            }
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(ca[i]), "v"(cb[j]));
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int RPM>
+__global__ __launch_bounds__(256) void probe128i(int iters, float* sink, unsigned long long* rep) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[4 * 16 * 64 * 8];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Float16* mine = img + wave * 16 * 64 * 8;
+    for (int f = 0; f < 16; ++f) *reinterpret_cast<h8*>(mine + (f * 64 + lane) * 8) = frag(lane * 2654435761u + f * 97u + blockIdx.x);
+    __syncthreads();
+    h8 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = *reinterpret_cast<const h8*>(mine + (i * 64 + lane) * 8); b0[i] = *reinterpret_cast<const h8*>(mine + ((8 + i) * 64 + lane) * 8); a1[i] = a0[i]; b1[i] = b0[i]; }
+    const unsigned lds_addr = (unsigned)(size_t)(mine + lane * 8);    // LDS byte address of this lane's 16 bytes of fragment 0
+    unsigned long long c0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f4 acc[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it += 2) {
+        body128<RPM>(acc, a0, b0, a1, b1, lds_addr);
+        body128<RPM>(acc, a1, b1, a0, b0, lds_addr);
+    }
+    float out = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) out += acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+    if (stamp) { rep[0] = __builtin_readcyclecounter() - c0; rep[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    if (out == 12345.678f) sink[0] = out;
+}
+
+template <int RPM>
+static void run128i(int ncu, float* sink, unsigned long long* rep) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int iters = 1000;
+    float ms = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        CK(hipEventRecord(e0));
+        probe128i<RPM><<<ncu, 256>>>(iters, sink, rep);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 0) iters = ((int)(iters * 30.0 / (ms > 0.01f ? ms : 0.01f))) & ~1;
+        if (iters > (1 << 22)) iters = 1 << 22;
+    }
+    unsigned long long h[2];
+    CK(hipMemcpy(h, rep, sizeof(h), hipMemcpyDeviceToHost));
+    const double tf = (double)ncu * 4 * iters * 64 * 16384.0 / (ms * 1e-3) / 1e12;
+    const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    printf("| 16x16x32, 128 x 128 per wave | 16 ds_read_b128 / K32, one per %d MFMAs, by hand | 1 | %8.1f | %7.0f | %6.2f | %6.1f |\n", RPM, tf, mhz, (double)h[0] / ((double)iters * 64), ms);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
 int main() {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
@@ -153,6 +305,8 @@ int main() {
         run<32, 0>(1, ncu, sink, rep); run<32, 0>(2, ncu, sink, rep);
         run<16, 1>(1, ncu, sink, rep); run<16, 1>(2, ncu, sink, rep);
         run<32, 1>(1, ncu, sink, rep); run<32, 1>(2, ncu, sink, rep);
+        run128<0>(ncu, sink, rep); run128<1>(ncu, sink, rep);
+        run128i<4>(ncu, sink, rep); run128i<2>(ncu, sink, rep); run128i<1>(ncu, sink, rep);
     }
     return 0;
 }
