@@ -96,8 +96,9 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_pa"       1 (default) = fp32 (+ residual) outputs with M % 128 == 0, N % 256 == 0, K >= 640 run the two-accumulator
  *                   persistent kernel (the epilogue of tile i rides in the main loop of tile i + 1; no inter-workgroup exchange, so it
  *                   is capture-safe and every row is bit-identical whatever the batch); 0 = never.
- *   "gemm_variant"  0 (default) = kernel chosen by shape; 7 / 15 / 16 force the round-1 tile kernel / the persistent 256 x 256 kernel / the
- *                   two-accumulator persistent kernel (bit-identical results; A/B partners of the tests).  Values above 16 are refused.
+ *   "gemm_variant"  0 (default) = kernel chosen by shape; 7 / 15 / 16 / 17 force the round-1 tile kernel / the persistent 256 x 256 kernel / the
+ *                   two-accumulator persistent kernel / the one-wave-per-SIMD persistent kernel (bit-identical results; A/B partners of the
+ *                   tests).  Values above 17 are refused.
  *   "gemm_pa16"     16-bit outputs with a long reduction (K >= 576) on the two-accumulator kernel: 1 (default) = those with a GELU epilogue
  *                   (its pieces hide most of the GELU that the persistent 256 x 256 kernel exposes), 2 = all, 0 = none.  Shorter
  *                   reductions (K = 256 .. 512) always take it ("gemm_pa" = 1).  Bit-identical results either way.
@@ -111,6 +112,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_small"    1 (default) = mi355_linear_fwd without activation / LayerScale / residual whose output is less than an eighth of a round of
  *                   the engine's 128 x 128 tiles (a classifier head: 256 x 1000) runs on one-wave 16 x 32 tiles spread over every CU
  *                   (gemm_small.hip; same K order, bit-identical results); 0 = always the 128 x 128 engine.
+ *   "gemm_w4"       1 (default) = 16-bit outputs without GELU / LayerScale / residual, M % 256 == 0, N % 256 == 0, 576 <= K < 1536 (the qkv
+ *                   product of a ViT) run the one-wave-per-SIMD persistent kernel (gemm16_w4.hip: four waves x 128 x 128 outputs, 256
+ *                   accumulation registers per lane, a hand-placed MFMA / ds_read / LDS-DMA stream; same K order, bit-identical results);
+ *                   0 = the eight-wave persistent kernel (gemm16_p8.hip) as before.  "gemm_variant" 17 forces the kernel on any shape it takes.
  *   "mlp_tt4"       mi355_mlp_fused_fwd / mi355_proj_mlp_fused_fwd at C = 64: 1 = eight waves with four 16-token tiles each (256 registers per
  *                   lane, a weight fragment read from LDS feeds four MFMAs); 0 (default) = sixteen waves with two tiles (128 registers).
  *                   Bit-identical results.

@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -26,7 +26,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"chunk_images", 0, 0, 1L << 40},    // 0 = auto (about 200 MB of x per chunk)
     {"nt", 3, 0, 3},                       // bit0: non-temporal loads, bit1: non-temporal stores in the final pass
     {"reverse", 0, 0, 1},
-    {"gemm_variant", 0, 0, 16},            // tile/schedule variant of the 16-bit GEMM (gemm16.hip); 0 = dispatch by shape
+    {"gemm_variant", 0, 0, 17},            // tile/schedule variant of the 16-bit GEMM (gemm16.hip); 0 = dispatch by shape
     {"eca_single", 1, 0, 1},               // ECA: one read + one write of x, halo channel rows re-summed per workgroup (chan_fused.hip)
     {"se_single", 1, 0, 1},                // SE: x read once, channel means exchanged as 8-byte {mean, tag} granules (chan_fused.hip)
     {"cbam_single", 1, 0, 1},              // CBAM: x read once, row bands in registers, granule hops per band (cbam_single.hip)
@@ -51,6 +51,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"mlp_tt4", 0, 0, 1},                  // fused MLP at C = 64 (CSWin stage 1): 8 waves x 4 token tiles at 256 VGPRs instead of 16 x 2 at 128 (A/B switch)
     {"mixer_stats", 0, 0, 1},              // mixer_token_kernel at C = 512: LayerNorm row statistics inside the kernel (1) or by the row_stats_kernel pre-pass (0, default: measured equal)
     {"attn_nw", 8, 7, 8},                  // ViT attention core at 193 .. 208 tokens (13 query tiles): waves per workgroup, 8 (13 / 16 balance) or 7 (13 / 14)
+    {"gemm_w4", 1, 0, 1},                  // 16-bit outputs, 576 <= K < 1536, whole 256 x 256 tiles: the one-wave-per-SIMD persistent kernel (gemm16_w4.hip) instead of gemm16_p8
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
@@ -104,6 +105,7 @@ long opt_gemm_small() { return opt(O_GEMM_SMALL); }
 long opt_mlp_tt4() { return opt(O_MLP_TT4); }
 long opt_mixer_stats() { return opt(O_MIXER_STATS); }
 long opt_attn_nw() { return opt(O_ATTN_NW); }
+long opt_gemm_w4() { return opt(O_GEMM_W4); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the

@@ -489,6 +489,13 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
+    if (variant == 17) {                   // one-wave-per-SIMD persistent 256 x 256 kernel (gemm16_w4.hip)
+        const int rc = mi355::gemm16_w4(g, out16, precision, st);
+        if (rc == MI355_EUNSUPPORTED) return mi355::fail(rc, "mi355_linear16_fwd: the one-wave-per-SIMD kernel does not take this shape");
+        if (rc != MI355_OK) return rc;
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     if (variant == 0 && (K == 64 || K == 128) && M >= 2048 && (!out16 || (N & 7) == 0)) {       // short-K, HBM-bound: weight-stationary streaming kernel
         int ncu = 256, dev = 0;
         (void)hipGetDevice(&dev);
@@ -590,6 +597,17 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         const int ncu = mi355::resident_slots(1);
         const long ntiles = (long)cdiv(M, 256) * cdiv(N, 256);
         if (ntiles >= ncu && K >= 256) {
+            // 16-bit outputs of a mid-length reduction (ViT qkv: K = 768): one wave per SIMD with 128 x 128 outputs each needs a third fewer LDS
+            // bytes per flop and, with its two-slab pipelined epilogue, 5.8 k instead of ~11 k exposed cycles per tile (round 5, same process:
+            // qkv 0.193-0.195 -> 0.179-0.182 ms).  Long reductions keep the split last round of the eight-wave kernel.
+            if (out16 && K >= 576 && K < 1536 && mi355::opt_gemm_w4()) {
+                const int rc = mi355::gemm16_w4(g, out16, precision, st);
+                if (rc == MI355_OK) {
+                    MI355_LAUNCH_CHECK();
+                    return MI355_OK;
+                }
+                if (rc != MI355_EUNSUPPORTED) return rc;
+            }
             const int rc = mi355::gemm16_p8(g, out16, precision, ws, ws_bytes, st);
             if (rc == MI355_OK) {
                 MI355_LAUNCH_CHECK();

@@ -103,11 +103,11 @@ def test_options_are_per_device_with_process_defaults(built_lib):
     assert lib.mi355_set_default_option(b"reverse", 1) == 0                # ... also over a later change of the default
     assert lib.mi355_get_option(b"reverse") == 0
     assert lib.mi355_set_default_option(b"reverse", 0) == 0
-    assert lib.mi355_set_option(b"gemm_variant", 16) == 0 and lib.mi355_get_option(b"gemm_variant") == 16
-    for bad in (17, 21, 31, -1):                                           # 17..21 were timing ablations that produce wrong results
+    assert lib.mi355_set_option(b"gemm_variant", 17) == 0 and lib.mi355_get_option(b"gemm_variant") == 17   # 17: gemm16_w4.hip (round 5)
+    for bad in (18, 21, 31, -1):                                           # timing ablations that produce wrong results never ship as option values
         assert lib.mi355_set_option(b"gemm_variant", bad) == -1
         assert b"gemm_variant" in lib.mi355_last_error()
-    assert lib.mi355_get_option(b"gemm_variant") == 16
+    assert lib.mi355_get_option(b"gemm_variant") == 17
     assert lib.mi355_set_option(b"gemm_variant", 0) == 0
     assert lib.mi355_set_option(b"spin_limit", 0) == 0 and lib.mi355_set_option(b"spin_limit", 5) == -1
     assert lib.mi355_set_option(b"spin_limit", 1 << 22) == 0

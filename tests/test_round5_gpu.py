@@ -279,3 +279,87 @@ def test_attention_core_on_seven_waves_is_bit_identical(prec):
     finally:
         mi355attn.set_option("attn_nw", old)
     assert torch.isfinite(y8).all() and torch.equal(y8, y7)
+
+
+# ---- gemm16_w4.hip: the one-wave-per-SIMD persistent kernel --------------------------------------------------------------------------
+W4_CASES = [  # M, N, K, gelu, bias
+    (2048, 2304, 768, False, True),        # fewer tiles than CUs (72)
+    (256 * 20, 768, 768, True, True),      # 60 tiles, GELU epilogue
+    (256 * 90, 768, 320, False, False),    # 270 tiles = 1 round + 14, odd number of K-tiles (5), no bias
+    (256 * 30, 512, 128, False, True),     # two K-tiles: the shortest stream the kernel takes
+    (256 * 33, 1024, 1024, True, False),   # 132 tiles, GELU, no bias
+    (256 * 131, 512, 576, False, True),    # 262 tiles = 1 round + 6
+]
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("case", W4_CASES)
+def test_one_wave_per_simd_gemm_is_bit_identical_to_the_eight_wave_kernel(case, prec):
+    """gemm16_w4.hip (round 5; 16-bit outputs): hand-placed MFMA / ds_read / LDS-DMA stream, accumulators in AGPRs, bias through an LDS-DMA
+    piece, two-slab pipelined epilogue -- same K order per output as gemm16_p8.hip / gemm16_pa.hip, so the bits must agree (variant 17
+    against 15 / 16 / the default dispatch), run to run as well.  fp32 outputs are refused (they belong to gemm16_pa)."""
+    import mi355attn
+    from mi355attn import functional as F
+    M, N, K, gelu, bias = case
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dt = torch.float16 if prec == 1 else torch.bfloat16
+    x16 = torch.randn(M, K, generator=g).to(dev).to(dt)
+    w16 = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dt)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    act = F.ACT_GELU if gelu else F.ACT_NONE
+    old = mi355attn.get_option("gemm_variant")
+    outs = {}
+    try:
+        for v in (17, 0, 15, 16, 17):
+            mi355attn.set_option("gemm_variant", v)
+            try:
+                y = F.linear16(x16, w16, b, act=act, out16=True, precision=prec)
+            except mi355attn.Mi355Error:
+                assert v in (15, 16), "variant %d refused %r" % (v, case)        # the forced partners may not take every shape
+                continue
+            torch.cuda.synchronize()
+            outs.setdefault(v, []).append(y.clone())
+    finally:
+        mi355attn.set_option("gemm_variant", old)
+    _drain_range()
+    assert len(outs[17]) == 2 and torch.equal(outs[17][0], outs[17][1])
+    mi355attn.set_option("gemm_variant", 17)
+    try:
+        with pytest.raises(mi355attn.Mi355Error):
+            F.linear16(x16, w16, b, act=act, out16=False, precision=prec)
+    finally:
+        mi355attn.set_option("gemm_variant", old)
+    for v, ys in outs.items():
+        assert torch.equal(ys[0], outs[17][0]), "variant %d differs from gemm16_w4 on %r" % (v, case)
+    ref = x16.float() @ w16.float().t() + (b if b is not None else 0.0)
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    assert rel_fro(outs[17][0].float(), ref) < (3e-3 if prec == 1 else 8e-3)
+
+
+def test_qkv_shaped_products_take_the_one_wave_per_simd_kernel():
+    """Dispatch: 16-bit outputs, whole 256 x 256 tiles, 576 <= K < 1536 -> gemm16_w4 (option "gemm_w4"); the same call with the option off runs
+    gemm16_p8; the results agree bit for bit."""
+    import mi355attn
+    from mi355attn import functional as F
+    dev = torch.device("cuda", 0)
+    x16 = torch.randn(256 * 300, 768, device=dev).half()
+    w16 = (torch.randn(2304, 768, device=dev) / 27.7).half()
+    b = torch.randn(2304, device=dev)
+    old = mi355attn.get_option("gemm_w4")
+    res = {}
+    try:
+        for v in (1, 0):
+            mi355attn.set_option("gemm_w4", v)
+            box = {}
+            def run():
+                box["y"] = F.linear16(x16, w16, b, out16=True, precision=1)
+            tags = [t for t, *_ in mi355attn.kernel_trace(run)]
+            torch.cuda.synchronize()
+            res[v] = (box["y"].clone(), tags)
+    finally:
+        mi355attn.set_option("gemm_w4", old)
+    assert any("gemm16_w4_kernel" in t for t in res[1][1]), res[1][1]
+    assert any("gemm16_p8_kernel" in t for t in res[0][1]) and not any("gemm16_w4_kernel" in t for t in res[0][1]), res[0][1]
+    assert torch.equal(res[0][0], res[1][0])

@@ -292,12 +292,111 @@ static void run128i(int ncu, float* sink, unsigned long long* rep) {
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
 
+// ... and with the rest of a main loop's traffic: NDMA LDS-DMA pieces (global_load_lds_dwordx4, scalar base + one 32-bit lane offset, 1 KB each, from
+// a 64 KB per-workgroup image that stays in L2) per body, one counted vmcnt wait and (BAR) one s_barrier per body.  A 256 x 256 x 64 tile on four
+// waves needs 8 pieces per wave and K = 32 step.
+__device__ __forceinline__ void probe_dma(const void* base, unsigned off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+}
+template <int NDMA, int BAR>
+__device__ __forceinline__ void body128d(f4 (&acc)[64], const h8 (&ca)[8], const h8 (&cb)[8], h8 (&na)[8], h8 (&nb)[8], unsigned lds_addr,
+                                         const char* src, unsigned voff, unsigned dst) {
+    int issued = 0, dmas = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = i * 8 + j;
+            if (m % 4 == 0 && issued < 16) {
+                switch (issued) {
+                    case 0: DSR(na[0], 0); break;      case 1: DSR(nb[0], 8192); break;
+                    case 2: DSR(na[1], 1024); break;   case 3: DSR(nb[1], 9216); break;
+                    case 4: DSR(na[2], 2048); break;   case 5: DSR(nb[2], 10240); break;
+                    case 6: DSR(na[3], 3072); break;   case 7: DSR(nb[3], 11264); break;
+                    case 8: DSR(na[4], 4096); break;   case 9: DSR(nb[4], 12288); break;
+                    case 10: DSR(na[5], 5120); break;  case 11: DSR(nb[5], 13312); break;
+                    case 12: DSR(na[6], 6144); break;  case 13: DSR(nb[6], 14336); break;
+                    case 14: DSR(na[7], 7168); break;  default: DSR(nb[7], 15360); break;
+                }
+                ++issued;
+            }
+            if (NDMA > 0 && m % (64 / (NDMA > 0 ? NDMA : 1)) == 2 && dmas < NDMA) {
+                probe_dma(src + dmas * 1024, voff, dst + dmas * 1024);
+                ++dmas;
+            }
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(ca[i]), "v"(cb[j]));
+        }
+    if (NDMA > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (BAR) __builtin_amdgcn_s_barrier();
+}
+
+template <int NDMA, int BAR>
+__global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigned long long* rep, const char* gsrc) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[4 * 16 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char land[5 * 16384];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Float16* mine = img + wave * 16 * 64 * 8;
+    for (int f = 0; f < 16; ++f) *reinterpret_cast<h8*>(mine + (f * 64 + lane) * 8) = frag(lane * 2654435761u + f * 97u + blockIdx.x);
+    __syncthreads();
+    h8 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = *reinterpret_cast<const h8*>(mine + (i * 64 + lane) * 8); b0[i] = *reinterpret_cast<const h8*>(mine + ((8 + i) * 64 + lane) * 8); a1[i] = a0[i]; b1[i] = b0[i]; }
+    const unsigned lds_addr = (unsigned)(size_t)(mine + lane * 8);
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(land + wave * 16384));
+    const char* src = gsrc + ((size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave)) * 16384;
+    const unsigned voff = lane * 16;
+    unsigned long long c0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f4 acc[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it += 2) {
+        body128d<NDMA, BAR>(acc, a0, b0, a1, b1, lds_addr, src, voff, dst);
+        body128d<NDMA, BAR>(acc, a1, b1, a0, b0, lds_addr, src + 8192, voff, dst + 8192);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float out = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) out += acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+    if (stamp) { rep[0] = __builtin_readcyclecounter() - c0; rep[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    if (out == 12345.678f) sink[0] = out + land[threadIdx.x];
+}
+
+template <int NDMA, int BAR>
+static void run128d(int ncu, float* sink, unsigned long long* rep, const char* gsrc) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int iters = 1000;
+    float ms = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        CK(hipEventRecord(e0));
+        probe128d<NDMA, BAR><<<ncu, 256>>>(iters, sink, rep, gsrc);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 0) iters = ((int)(iters * 30.0 / (ms > 0.01f ? ms : 0.01f))) & ~1;
+        if (iters > (1 << 22)) iters = 1 << 22;
+    }
+    unsigned long long h[2];
+    CK(hipMemcpy(h, rep, sizeof(h), hipMemcpyDeviceToHost));
+    const double tf = (double)ncu * 4 * iters * 64 * 16384.0 / (ms * 1e-3) / 1e12;
+    const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    printf("| 16x16x32, 128 x 128 per wave | 16 ds_read_b128 + %d LDS-DMA pieces / K32 by hand%s | 1 | %8.1f | %7.0f | %6.2f | %6.1f |\n", NDMA, BAR ? " + s_barrier" : "", tf, mhz,
+           (double)h[0] / ((double)iters * 64), ms);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
 int main() {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int ncu = p.multiProcessorCount;
     float* sink; unsigned long long* rep;
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&rep, 64));
+    char* gsrc; CK(hipMalloc(&gsrc, (size_t)(ncu + 1) * 65536)); CK(hipMemset(gsrc, 0, (size_t)(ncu + 1) * 65536));
     printf("device: %s, %d CUs\n", p.gcnArchName, ncu);
     printf("| MFMA | LDS traffic in the body | waves / SIMD | TFLOP/s | sclk MHz | shader cycles per MFMA and SIMD | ms |\n|---|---|---|---|---|---|---|\n");
     for (int rep_ = 0; rep_ < 2; ++rep_) {
@@ -307,6 +406,7 @@ int main() {
         run<32, 1>(1, ncu, sink, rep); run<32, 1>(2, ncu, sink, rep);
         run128<0>(ncu, sink, rep); run128<1>(ncu, sink, rep);
         run128i<4>(ncu, sink, rep); run128i<2>(ncu, sink, rep); run128i<1>(ncu, sink, rep);
+        run128d<0, 1>(ncu, sink, rep, gsrc); run128d<4, 0>(ncu, sink, rep, gsrc); run128d<8, 0>(ncu, sink, rep, gsrc); run128d<8, 1>(ncu, sink, rep, gsrc); run128d<16, 1>(ncu, sink, rep, gsrc);
     }
     return 0;
 }
