@@ -334,7 +334,7 @@ __device__ __forceinline__ void body128d(f4 (&acc)[64], const h8 (&ca)[8], const
 }
 
 template <int NDMA, int BAR>
-__global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigned long long* rep, const char* gsrc) {
+__global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigned long long* rep, const char* gsrc, int share) {
     __shared__ __attribute__((aligned(16))) _Float16 img[4 * 16 * 64 * 8];
     __shared__ __attribute__((aligned(16))) unsigned char land[5 * 16384];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigne
     for (int i = 0; i < 8; ++i) { a0[i] = *reinterpret_cast<const h8*>(mine + (i * 64 + lane) * 8); b0[i] = *reinterpret_cast<const h8*>(mine + ((8 + i) * 64 + lane) * 8); a1[i] = a0[i]; b1[i] = b0[i]; }
     const unsigned lds_addr = (unsigned)(size_t)(mine + lane * 8);
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(land + wave * 16384));
-    const char* src = gsrc + ((size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave)) * 16384;
+    // share = 1: the 32 workgroups of an XCD (blockIdx & 7) stream the SAME 64 KB image in step -- the sharing pattern of a GEMM's operand tiles
+    const char* src = gsrc + ((size_t)(share ? (blockIdx.x & 7) : blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(wave)) * 16384;
     const unsigned voff = lane * 16;
     unsigned long long c0 = 0, r0 = 0;
     const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
@@ -354,9 +355,13 @@ __global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigne
     f4 acc[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+    // share = 2: every workgroup streams through its own 4 MB window (each piece is read once per sweep: served from beyond L2)
+    unsigned walk = 0;
     for (int it = 0; it < iters; it += 2) {
-        body128d<NDMA, BAR>(acc, a0, b0, a1, b1, lds_addr, src, voff, dst);
-        body128d<NDMA, BAR>(acc, a1, b1, a0, b0, lds_addr, src + 8192, voff, dst + 8192);
+        const char* s0 = share == 2 ? gsrc + (size_t)blockIdx.x * (4u << 20) + walk + __builtin_amdgcn_readfirstlane(wave) * 16384 : src;
+        body128d<NDMA, BAR>(acc, a0, b0, a1, b1, lds_addr, s0, voff, dst);
+        body128d<NDMA, BAR>(acc, a1, b1, a0, b0, lds_addr, s0 + 8192, voff, dst + 8192);
+        walk = (walk + 65536u) & ((4u << 20) - 1u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float out = 0.f;
@@ -367,14 +372,14 @@ __global__ __launch_bounds__(256) void probe128d(int iters, float* sink, unsigne
 }
 
 template <int NDMA, int BAR>
-static void run128d(int ncu, float* sink, unsigned long long* rep, const char* gsrc) {
+static void run128d(int ncu, float* sink, unsigned long long* rep, const char* gsrc, int share = 0) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int iters = 1000;
     float ms = 0.f;
     for (int pass = 0; pass < 3; ++pass) {
         CK(hipEventRecord(e0));
-        probe128d<NDMA, BAR><<<ncu, 256>>>(iters, sink, rep, gsrc);
+        probe128d<NDMA, BAR><<<ncu, 256>>>(iters, sink, rep, gsrc, share);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -385,7 +390,7 @@ static void run128d(int ncu, float* sink, unsigned long long* rep, const char* g
     CK(hipMemcpy(h, rep, sizeof(h), hipMemcpyDeviceToHost));
     const double tf = (double)ncu * 4 * iters * 64 * 16384.0 / (ms * 1e-3) / 1e12;
     const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
-    printf("| 16x16x32, 128 x 128 per wave | 16 ds_read_b128 + %d LDS-DMA pieces / K32 by hand%s | 1 | %8.1f | %7.0f | %6.2f | %6.1f |\n", NDMA, BAR ? " + s_barrier" : "", tf, mhz,
+    printf("| 16x16x32, 128 x 128 per wave | 16 ds_read_b128 + %d LDS-DMA pieces / K32 by hand%s%s | 1 | %8.1f | %7.0f | %6.2f | %6.1f |\n", NDMA, BAR ? " + s_barrier" : "", share == 1 ? ", source shared by the XCD" : (share == 2 ? ", source streamed from beyond L2" : ""), tf, mhz,
            (double)h[0] / ((double)iters * 64), ms);
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -396,7 +401,7 @@ int main() {
     const int ncu = p.multiProcessorCount;
     float* sink; unsigned long long* rep;
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&rep, 64));
-    char* gsrc; CK(hipMalloc(&gsrc, (size_t)(ncu + 1) * 65536)); CK(hipMemset(gsrc, 0, (size_t)(ncu + 1) * 65536));
+    char* gsrc; CK(hipMalloc(&gsrc, (size_t)(ncu + 1) * (4u << 20))); CK(hipMemset(gsrc, 0, (size_t)(ncu + 1) * (4u << 20)));
     printf("device: %s, %d CUs\n", p.gcnArchName, ncu);
     printf("| MFMA | LDS traffic in the body | waves / SIMD | TFLOP/s | sclk MHz | shader cycles per MFMA and SIMD | ms |\n|---|---|---|---|---|---|---|\n");
     for (int rep_ = 0; rep_ < 2; ++rep_) {
@@ -407,6 +412,8 @@ int main() {
         run128<0>(ncu, sink, rep); run128<1>(ncu, sink, rep);
         run128i<4>(ncu, sink, rep); run128i<2>(ncu, sink, rep); run128i<1>(ncu, sink, rep);
         run128d<0, 1>(ncu, sink, rep, gsrc); run128d<4, 0>(ncu, sink, rep, gsrc); run128d<8, 0>(ncu, sink, rep, gsrc); run128d<8, 1>(ncu, sink, rep, gsrc); run128d<16, 1>(ncu, sink, rep, gsrc);
+        run128d<8, 1>(ncu, sink, rep, gsrc, 1); run128d<16, 1>(ncu, sink, rep, gsrc, 1);
+        run128d<4, 1>(ncu, sink, rep, gsrc, 2); run128d<8, 1>(ncu, sink, rep, gsrc, 2); run128d<16, 1>(ncu, sink, rep, gsrc, 2);
     }
     return 0;
 }
