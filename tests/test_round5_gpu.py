@@ -363,3 +363,39 @@ def test_qkv_shaped_products_take_the_one_wave_per_simd_kernel():
     assert any("gemm16_w4_kernel" in t for t in res[1][1]), res[1][1]
     assert any("gemm16_p8_kernel" in t for t in res[0][1]) and not any("gemm16_w4_kernel" in t for t in res[0][1]), res[0][1]
     assert torch.equal(res[0][0], res[1][0])
+
+
+def test_one_wave_per_simd_gemm_under_graph_capture_and_on_a_side_stream():
+    """gemm16_w4 has no inter-workgroup exchange, no workspace and no host-side state per launch: a captured launch replays on changed
+    inputs bit for bit like an eager one, and a launch on a non-default stream gives the same bits."""
+    import mi355attn
+    from mi355attn import functional as F
+    M, N, K = 256 * 64, 2304, 768
+    torch.manual_seed(5)
+    x16 = torch.randn(M, K, device="cuda").half()
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda")
+    tags = [t for t, *_ in mi355attn.kernel_trace(lambda: F.linear16(x16, w16, b, out16=True, precision=1))]
+    assert any("gemm16_w4_kernel" in t for t in tags), tags                  # 576 tiles >= one round: the dispatch takes the kernel
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            y_cap = F.linear16(x16, w16, b, out16=True, precision=1)
+    torch.cuda.current_stream().wait_stream(s)
+    for rep in range(3):
+        x16.copy_(torch.randn(M, K, device="cuda").half())
+        g.replay()
+        torch.cuda.synchronize()
+        y_ref = F.linear16(x16, w16, b, out16=True, precision=1)
+        torch.cuda.synchronize()
+        assert torch.equal(y_cap, y_ref), "replay %d" % rep
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y_side = F.linear16(x16, w16, b, out16=True, precision=1)
+    side.synchronize()
+    assert torch.equal(y_side, y_ref)
+    _drain_range()
