@@ -289,6 +289,8 @@ W4_CASES = [  # M, N, K, gelu, bias
     (256 * 30, 512, 128, False, True),     # two K-tiles: the shortest stream the kernel takes
     (256 * 33, 1024, 1024, True, False),   # 132 tiles, GELU, no bias
     (256 * 131, 512, 576, False, True),    # 262 tiles = 1 round + 6
+    (256 * 197, 2304, 768, False, True),   # the qkv product of ViT-Base at the timed size (B = 256): 1773 tiles = 6.93 rounds
+    (256 * 197, 3072, 768, True, True),    # fc1 of ViT-Base at the timed size, GELU epilogue: 2364 tiles
 ]
 
 
