@@ -600,8 +600,9 @@ def cpu_baseline(blocks, args):
     """The reference's CPU path beside the GPU numbers: per block, the ATen-operator-sequence restatement of the reference forward
     (oracle/aten_seq.py, oracle/cswin.py *_aten: /root/reference does not exist on the GPU box, hence kind "port") on this host's cores,
     on the first n images of the same batch.  The torch thread count is probed PER BLOCK over {8, 16, 32, 64, 128} (capped at the
-    host's hardware threads) ON THE TIMED SAMPLE -- one pass per count, every count tried unless the block has already used its time
-    budget -- then best of 2 more passes at the fastest count.  value = images/s through the same step = 1 / sum_b (t_b / n_b).
+    host's hardware threads) on one sub-batch of 8 images of the timed sample -- every count tried unless the block has already used its
+    time budget -- then the sample is timed at the fastest count in sub-batches of 8 and as one batch, best of <= 4 passes.
+    value = images/s through the same step = 1 / sum_b (t_b / n_b).
     Returns (flat record for the line, verbose per-block list for --detail)."""
     import torch
     cores, threads, model = host_cpu_info()
@@ -615,35 +616,45 @@ def cpu_baseline(blocks, args):
             xs = b["x"][:ns].cpu()
             torch.set_num_threads(cands[min(2, len(cands) - 1)])
             b["cpu"](xs[:max(1, ns // 8)])                     # first touch of the weights / code paths, small
+            # A throughput baseline may pick its batch size: the sample runs in sub-batches of 8 (the intermediates of a full model at 32
+            # images -- 77 MB per MLP hidden tensor -- fall out of the host's caches; at 8 they stay) AND as one batch; the faster one counts.
+            # The thread count is probed on ONE sub-batch (round 5, last lease: probing on the whole sample used up the budget of ViT-Base
+            # before the sub-batch pass was reached, and the line read 18.7 instead of 40 images/s).
+            sub = 8 if ns >= 16 else ns
             probe = {}
             for nthr in cands:
                 if probe and time.perf_counter() - t_blk > budget_s:
                     break                                      # budget used: the remaining (larger) counts are not tried, said in `probe`
                 torch.set_num_threads(nthr)
                 t1 = time.perf_counter()
-                b["cpu"](xs)
+                b["cpu"](xs[:sub])
                 probe[nthr] = time.perf_counter() - t1
+                if probe[nthr] < budget_s / 10:                 # cheap enough: a second pass, the faster one counts (a lone pass is noisy)
+                    t1 = time.perf_counter()
+                    b["cpu"](xs[:sub])
+                    probe[nthr] = min(probe[nthr], time.perf_counter() - t1)
             best_n = min(probe, key=probe.get)
             torch.set_num_threads(best_n)
             used = max(used, best_n)
-            ts = [probe[best_n]]
-            for _ in range(2):
-                if time.perf_counter() - t_blk > 2 * budget_s:
-                    break
+
+            def chunked():
+                t1 = time.perf_counter()
+                for c0 in range(0, ns, sub):
+                    b["cpu"](xs[c0:c0 + sub])
+                return time.perf_counter() - t1
+
+            def whole():
                 t1 = time.perf_counter()
                 b["cpu"](xs)
-                ts.append(time.perf_counter() - t1)
-            t = min(ts)
-            chunk = ns
-            if t > 0.3 and ns >= 16 and time.perf_counter() - t_blk < 2 * budget_s:
-                # a throughput baseline may pick its batch size: the same sample in sub-batches of 8 (the intermediates of a full model at
-                # 32 images -- 77 MB per MLP hidden tensor -- fall out of the host's caches; at 8 they stay)
-                t1 = time.perf_counter()
-                for c0 in range(0, ns, 8):
-                    b["cpu"](xs[c0:c0 + 8])
-                tc = time.perf_counter() - t1
+                return time.perf_counter() - t1
+
+            t, chunk = chunked(), sub
+            for k in range(3):                                  # one whole-batch pass, then alternate: best of <= 4 passes inside the budget
+                if time.perf_counter() - t_blk > 2 * budget_s:
+                    break
+                tc, ck = (whole(), ns) if (k % 2 == 0 and sub != ns) else (chunked(), sub)
                 if tc < t:
-                    t, chunk = tc, 8
+                    t, chunk = tc, ck
             per_image += t / ns
             flop = b.get("alt_work") or (b["work"] if b["bound"] == "mfma" else None)
             rec = {"block": b["name"], "key": b["key"], "images": ns, "sub_batch": chunk, "threads": best_n, "images_per_s": round(ns / t, 1),
@@ -662,10 +673,10 @@ def cpu_baseline(blocks, args):
                                                                                          sorted(probe)))
     out = {"value": round(1.0 / per_image, 2), "unit": "images/s", "cores": used, "kind": "port",
            "host_cores": cores, "host_threads": threads, "host_cpu": model,
-           "sample": "first n images of the same batch per block (n = 64 C2 / 32 others), best of <= 3 passes (+ sub-batches of 8)"}
+           "sample": "first n images of the same batch per block (n = 64 C2 / 32 others), in sub-batches of 8 and as one batch, best of <= 4 passes"}
     out.update(flat)
     out["legend"] = ("img_s_* / thr_* / GFLOPs_* (GBps_* for the HBM-bound blocks) per block key; ATen-operator-sequence restatements of the "
-                     "reference forward (oracle/aten_seq.py); threads probed over {8,16,32,64,128} on the timed sample; cores = largest count used")
+                     "reference forward (oracle/aten_seq.py); threads probed over {8,16,32,64,128} on one sub-batch of 8; cores = largest count used")
     return out, detail
 
 
