@@ -28,6 +28,7 @@ def workload_c3(B, dev):
     x = torch.randn(B, 197, 768, device=dev)
     sd = _sd(m)
     blocks = [dict(name="ViT Attention(768,h12)", key="ViTAttn", module=m.to(dev), x=x, bound="mfma", work=1.048784e9 * B, cpu_n=32,
+                   alt_bytes=2.0 * 197 * 768 * 4 * B + 4 * 768 * 768 * 2,      # x in + y out (fp32) + the 16-bit weights (319 MB)
                    cpu=lambda xs: A.vit_attention_aten(xs, sd, 12), cpu_note=ATEN_NOTE)]
     return dict(name="ViT-Base Attention fwd, x=(%d,197,768) (BASELINE configs[2])" % B, blocks=blocks, dtype="f16")
 
@@ -48,6 +49,7 @@ def workload_c4(B, dev):
         torch.manual_seed(4321)
         x = torch.randn(B, *shp, device=dev)
         blocks.append(dict(name=name, key="CSWin_" + name.split()[1], module=m.to(dev), x=x, bound="mfma", work=flop * B, cpu=mk(_sd(m)), cpu_n=32,
+                           alt_bytes=2.0 * shp[0] * shp[1] * 4 * B,      # both roofs: x in + y out, the block's activation bytes
                            cpu_note="ATen-sequence restatement (strided window views, bmm, softmax, grouped conv2d, fused layer_norm / linear / "
                                     "gelu): the operator sequence of cswin.py:101-127,176-197; within 0.9-1.4x of the real reference on the "
                                     "build container's CPU"))
@@ -57,9 +59,9 @@ def workload_c4(B, dev):
     x = torch.randn(B, 196, 384, device=dev)
     sdb, sda = _sd(xb), _sd(xa)
     blocks.append(dict(name="XCABlock(384,h8)", key="XCABlock", module=xb.to(dev), x=x, fwd_args=(14, 14), bound="mfma", work=710.7e6 * B,
-                       cpu_n=32, cpu=lambda xs: A.xca_block_aten(xs, sdb, 8, 14, 14), cpu_note=ATEN_NOTE))
+                       alt_bytes=2.0 * 196 * 384 * 4 * B, cpu_n=32, cpu=lambda xs: A.xca_block_aten(xs, sdb, 8, 14, 14), cpu_note=ATEN_NOTE))
     blocks.append(dict(name="XCA(384,h8)", key="XCA", module=xa.to(dev), x=x, bound="mfma", work=(173.4 + 7.2 + 7.2 + 57.8) * 1e6 * B,
-                       cpu_n=32, cpu=lambda xs: A.xca_aten(xs, sda, 8), cpu_note=ATEN_NOTE))
+                       alt_bytes=2.0 * 196 * 384 * 4 * B, cpu_n=32, cpu=lambda xs: A.xca_aten(xs, sda, 8), cpu_note=ATEN_NOTE))
     return dict(name="CSWin-T blocks s1-s4 + XCiT-S XCABlock/XCA fwd, B=%d (BASELINE configs[3])" % B, blocks=blocks,
                 dtype="f16")
 
@@ -73,7 +75,10 @@ def workload_c5(B, dev):
 
     # gather=True: bench.py all-gathers this block's logits (mi355attn.dist.gather_batch: one RCCL all-gather over xGMI, 1 MB per rank)
     blocks = [dict(name="VisionTransformer(ViT-Base/16, h12)", key="ViTBase", module=m.to(dev), x=x, bound="mfma", work=35.127656e9 * B,
-                   cpu=lambda xs: A.vit_aten(xs, sd, 12, 12), cpu_n=32, gather=True, cpu_note=ATEN_NOTE)]
+                   # HBM side: images in + logits out + one pass over the 16-bit weights (0.33 GB at B = 256); the forward's
+                   # every-tensor-materialised-once figure is ~30 GB, the counters say what really moved
+                   alt_bytes=(3 * 224 * 224 + 1000) * 4.0 * B + 86.54e6 * 2,
+                   cpu=lambda xs: A.vit_aten(xs, sd, 12, 12), cpu_n=64, cpu_budget_x=6.0, gather=True, cpu_note=ATEN_NOTE)]
     return dict(name="ViT-Base full fwd, %d images per GPU, logits all-gathered (BASELINE configs[4])" % B, blocks=blocks,
                 gather=True, dtype="f16")
 
@@ -85,6 +90,7 @@ def workload_mixer(B, dev):
     x = torch.randn(B, 196, 512, device=dev)
     sd = _sd(m)
     blocks = [dict(name="MixerLayer(512,196)", key="Mixer", module=m.to(dev), x=x, bound="mfma", work=924.8e6 * B, cpu_n=32,
+                   alt_bytes=2.0 * 196 * 512 * 4 * B,
                    cpu=lambda xs: A.mixer_layer_aten(xs, sd), cpu_note=ATEN_NOTE)]
     return dict(name="MLP-Mixer layer fwd, x=(%d,196,512)" % B, blocks=blocks, dtype="f16")
 

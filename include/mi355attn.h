@@ -112,10 +112,13 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_small"    1 (default) = mi355_linear_fwd without activation / LayerScale / residual whose output is less than an eighth of a round of
  *                   the engine's 128 x 128 tiles (a classifier head: 256 x 1000) runs on one-wave 16 x 32 tiles spread over every CU
  *                   (gemm_small.hip; same K order, bit-identical results); 0 = always the 128 x 128 engine.
- *   "gemm_w4"       1 (default) = 16-bit outputs without GELU / LayerScale / residual, M % 256 == 0, N % 256 == 0, 576 <= K < 1536 (the qkv
- *                   product of a ViT) run the one-wave-per-SIMD persistent kernel (gemm16_w4.hip: four waves x 128 x 128 outputs, 256
+ *   "gemm_w4"       1 (default) = 16-bit outputs without LayerScale / residual (a GELU epilogue is taken whenever "gemm_pa16" does not claim
+ *                   it first), M % 256 == 0, N % 256 == 0, 576 <= K < 1536 (the qkv product of a ViT) run the one-wave-per-SIMD persistent kernel (gemm16_w4.hip: four waves x 128 x 128 outputs, 256
  *                   accumulation registers per lane, a hand-placed MFMA / ds_read / LDS-DMA stream; same K order, bit-identical results);
  *                   0 = the eight-wave persistent kernel (gemm16_p8.hip) as before.  "gemm_variant" 17 forces the kernel on any shape it takes.
+ *   "attn_nw"       waves per workgroup of the ViT attention core at 193 .. 208 tokens (13 query tiles): 8 (default; five waves carry two
+ *                   tiles, three carry one) or 7 (six carry two, one carries one).  Bit-identical results (a tile's arithmetic does not depend on
+ *                   its wave); measured equal in round 5.  Range 7 .. 8.
  *   "mlp_tt4"       mi355_mlp_fused_fwd / mi355_proj_mlp_fused_fwd at C = 64: 1 = eight waves with four 16-token tiles each (256 registers per
  *                   lane, a weight fragment read from LDS feeds four MFMAs); 0 (default) = sixteen waves with two tiles (128 registers).
  *                   Bit-identical results.

@@ -371,7 +371,7 @@ int mi355_linear_fwd(const float* X, const float* W, const float* bias, const fl
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear_fwd: K and ldx must be multiples of 4 and X, W 16-byte aligned "
                                                "(K=%d ldx=%d)", K, ldx);
     int rc = MI355_EUNSUPPORTED;
-    if (!gamma && !resid && act == MI355_ACT_NONE)          // small outputs (a classifier head): one-wave 32 x 32 tiles over all CUs, same bits
+    if (!gamma && !resid && act == MI355_ACT_NONE)          // small outputs (a classifier head): one-wave 16 x 32 tiles over all CUs, same bits
         rc = mi355::gemm_small_nt(X, W, bias, Y, M, N, K, ldx, K, ldy, precision, static_cast<hipStream_t>(stream));
     if (rc == MI355_EUNSUPPORTED)
         rc = mi355::gemm_nt(X, W, bias, gamma, resid, Y, M, N, K, ldx, K, ldy, act, precision, static_cast<hipStream_t>(stream));

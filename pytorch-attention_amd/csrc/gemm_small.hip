@@ -110,6 +110,9 @@ int gemm_small_nt(const float* A, const float* B, const float* bias, float* C, i
     const long big_tiles = (long)cdiv(M, 128) * cdiv(N, 128), tiles = (long)cdiv(M, 16) * cdiv(N, 32);
     const int ncu = resident_slots(1);
     if (big_tiles * 8 > ncu || tiles > 32L * ncu) return MI355_EUNSUPPORTED;       // the engine fills at least an eighth of the chip: its tiles win
+    // rejections sit in FRONT of MI355_TRACE (a refused launch must not leave an event pair under this kernel's tag: ADVICE round 5)
+    if (precision != MI355_PREC_STRICT && precision != MI355_PREC_FP16 && precision != MI355_PREC_BF16)
+        return fail(MI355_EINVAL, "precision must be 0, 1 or 2 (got %d)", precision);
     SmallArgs g{A, B, bias, C, M, N, K, lda, ldb, ldc, cdiv(N, 32)};
     MI355_TRACE(st, "gemm_small_kernel<prec %d> M=%d N=%d K=%d", precision, M, N, K);
     switch (precision) {

@@ -141,11 +141,15 @@ def gather_batch(y_local, global_batch=None, group=None, comm=None):
         return out
     sizes = [shard_bounds(global_batch, r, world) for r in range(world)]
     width = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((width,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-    pad[:n_local] = y_local
+    # a host-side process group (gloo) cannot take device tensors: pad, gather and concatenate on the host, then copy back
+    staged = dist.get_backend(group) == "gloo" and y_local.is_cuda
+    src = y_local.cpu() if staged else y_local
+    pad = torch.zeros((width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[:n_local] = src
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    out = torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    return out.to(y_local.device) if staged else out
 
 
 def forward_sharded(fn, x_global, group=None, gather=True):

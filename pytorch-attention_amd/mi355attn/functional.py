@@ -639,11 +639,16 @@ def weight16_scaled(weight, bias, gamma, precision=None):
         g = gamma.detach().reshape(-1)
         w = weight.detach()
         if p == PREC_FP16:
-            ga = g.abs()
-            nz = ga[ga > 0]
-            gmin = float(nz.min()) if nz.numel() else 1.0
-            wmed, wmax = float(w.abs().median()), float(w.abs().max())
-            if gmin * wmed < 8.0 * FP16_MIN_NORMAL or float(ga.max()) * wmax >= 65504.0:
+            # the decision is reduced to ONE flag on the device and read with one synchronising copy (four .item()-style
+            # reads before); a synchronising read is illegal under stream capture, so a first build there is refused with a clear message
+            if w.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight16_scaled: the LayerScale fold decision reads the weights once on the host -- run one eager "
+                                   "forward (warm-up) before capturing this module in a hipGraph")
+            ga, wa = g.abs(), w.abs()
+            gmin = torch.where(ga > 0, ga, torch.full_like(ga, float("inf"))).min()
+            gmin = torch.where(torch.isinf(gmin), torch.ones_like(gmin), gmin)
+            bad = (gmin * wa.median() < 8.0 * FP16_MIN_NORMAL) | (ga.max() * wa.max() >= 65504.0)
+            if bool(bad.item()):
                 return None
         w16 = (w * g[:, None]).to(dtype16(p)).contiguous()      # round-to-nearest-even, like mi355_cast16_fwd
         return w16, (None if bias is None else (bias.detach() * g).contiguous())

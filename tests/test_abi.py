@@ -118,6 +118,7 @@ def test_c2_kernels_have_no_scratch(built_lib):
     """the single-read SE / ECA / CBAM kernels of the C2 bench shape (56 x 56: 13 float4 per lane, full bands)
     must not spill -- read from the AMDGPU metadata of the shipped library (tools/kernel_resources.py), no GPU needed."""
     import sys
+    pytest.importorskip("msgpack")                                   # tools/kernel_resources.py decodes the metadata notes with it
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     rows = kernel_resources.kernels(built_lib)
