@@ -210,4 +210,45 @@ def workload_zoo2(B, dev):
     return dict(name="GC+CoordAtt+Triplet+BAM+SK+CAM fwd, x=(%d,256,56,56) fp32 per GPU" % B, blocks=blocks, dtype="f32")
 
 
-WORKLOADS = {"zoo2": workload_zoo2, "zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}
+def workload_f1(B, dev):
+    """SURVEY 8 f1 (the plain-MHSA copies of the other ViT files) at their NATIVE stage shapes, B images per GPU: SETR (dim 256, 4 heads,
+    1024 tokens), PVT stage 1 / stage 3 (spatial-reduction K/V: sr 8 at 56 x 56, sr 2 at 14 x 14), CMT (sr 2 + relative position bias at
+    28 x 28), SegFormer (sr 8, fused kv projection), P2T (pooled-pyramid K/V at 56 x 56).  Modules, weights and forward arguments are the
+    golden cases of tests/golden/cases.py (built through the drop-in import paths); FLOPs = projections + QK^T + PV (2 x MAC); the
+    spatial-reduction convolutions are counted on their reduced token grid."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+    from cases import BY_ID, PREP, make_arg
+
+    def mhsa_flop(N, Nkv, C, kv_proj=True, sr_conv=0.0):
+        return 2.0 * N * C * C * 2 + (2.0 * Nkv * C * 2 * C if kv_proj else 0.0) + 2.0 * 2 * N * Nkv * C + sr_conv
+
+    specs = [("setr_attn", "SETR_Attn", mhsa_flop(1024, 1024, 256)),
+             ("pvt_attn_s1", "PVT_s1", mhsa_flop(3136, 49, 64, sr_conv=2.0 * 49 * 64 * 64 * 64)),
+             ("pvt_attn_s3", "PVT_s3", mhsa_flop(196, 49, 320, sr_conv=2.0 * 49 * 320 * 320 * 4)),
+             ("cmt_attn", "CMT", mhsa_flop(784, 196, 128, sr_conv=2.0 * 196 * 128 * 4)),
+             ("segformer_attn", "SegFormer", mhsa_flop(3136, 49, 64, sr_conv=2.0 * 49 * 64 * 64 * 64)),
+             ("p2t_attn", "P2T", mhsa_flop(3136, 16 + 9 + 4 + 4, 64))]
+    blocks = []
+    for cid, key, flop in specs:
+        c = BY_ID[cid]
+        cls = getattr(importlib.import_module(c["mod"]), c["cls"])
+        m = _seeded(lambda: cls(*c.get("args", ()), **c.get("kwargs", {})))
+        if c.get("prep"):
+            PREP[c["prep"]](m)
+            m.eval()
+        torch.manual_seed(4321)
+        x = torch.randn(B, *c["shape"][1:], device=dev)
+        sd = _sd(m)
+        args = [make_arg(a) for a in c.get("fwd_args", ())]
+        dargs = tuple(a.to(dev) if isinstance(a, (torch.Tensor, torch.nn.Module)) else a for a in args)
+        blocks.append(dict(name="%s %s%s @ %s" % (c["mod"].split(".")[-1], c["cls"], c.get("args", ()), "x".join(str(v) for v in c["shape"][1:])),
+                           key=key, module=m.to(dev), x=x, fwd_args=dargs, bound="mfma", work=flop * B, cpu_n=32,
+                           alt_bytes=2.0 * x[0].numel() * 4 * B,
+                           cpu=(lambda cc, s: (lambda xs: cc["oracle"](xs, s, torch.float32)))(c, sd)))
+    return dict(name="f1: plain-MHSA copies (SETR, PVT s1/s3, CMT, SegFormer, P2T) at native shapes, B=%d" % B, blocks=blocks, dtype="f16")
+
+
+WORKLOADS = {"f1": workload_f1, "zoo2": workload_zoo2, "zoo": workload_zoo, "xcit": workload_xcit, "cswin": workload_cswin, "mixer_full": workload_mixer_full, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5, "mixer": workload_mixer, "da": workload_da}

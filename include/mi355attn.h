@@ -134,6 +134,9 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.
+ *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
+ *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
+ *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.
  * Unknown key or a value outside the key's range -> MI355_EINVAL. */
 int         mi355_set_option(const char* key, long value);          /* current device */
 int         mi355_set_default_option(const char* key, long value);  /* process default: devices without an own setting */
@@ -166,6 +169,15 @@ int         mi355_sync_status(void);
  * (cleared by the report).  A host that wants certainty for a forward synchronises the stream first.  Remedy: run the module in
  * precision 0 (strict: bf16 hi/lo split, fp32 range) or precision 2 (bf16).  bf16 operands are never flagged. */
 int         mi355_range_status(void);
+/* "Is the range word final for what I have launched?" without draining the device (round 6).  mi355_range_arm(1) arms the calling thread's
+ * current device: from then on the launch check behind every fp16 producer records ONE re-used event on the producer's stream (a relaxed
+ * load per launch otherwise).  mi355_range_wait() synchronises on the LAST such event only -- launches queued behind the last producer keep
+ * running -- and returns the range status (MI355_OK / MI355_ERANGE, cleared by the report); with no producer since the arm it returns the
+ * status without waiting.  mi355_range_arm(0) disarms.  Not for use under hipGraph capture.  This is what the host mirror's modules use
+ * to give the reference's behaviour on large activations by default: a forward whose fp16 operands saturated is run again in precision 0
+ * (option "range_fallback" = 1, per device; 0 = no wait, the next call reports MI355_ERANGE). */
+int         mi355_range_arm(int on);
+int         mi355_range_wait(void);
 
 /* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
 
@@ -623,6 +635,27 @@ int mi355_axpby_fwd(const float* x, const float* u, const float* gamma, float* y
  * in rank order on every rank -- one ncclAllGather over xGMI, asynchronous on `stream`.  RCCL is bound at run time (the copy already
  * loaded in the process wins); without a loadable librccl these return MI355_EUNSUPPORTED. */
 #define MI355_COMM_ID_BYTES 128
+/* ---- SURVEY.md 8(b) names ---------------------------------------------------------------------------------------------------------
+ * The survey's contract lists one `mi355_<op>_workspace_bytes` / `mi355_<op>_fwd` pair per op and three op names this header spells
+ * differently.  Both spellings are exported; the aliases forward to the entries above with the same arguments:
+ *     mi355_sdpa_core_fwd          = mi355_sdpa_fwd            (ViT.py:82-86)
+ *     mi355_gemm_bias_act_fwd      = mi355_linear_fwd          (epilogue none / gelu / residual: `act`, `resid`)
+ *     mi355_mixer_token_mlp_fwd    = mi355_mixer_token_fwd     (+ mi355_mixer_token_mlp_workspace_bytes)
+ * and the ops that need no scratch get the workspace query the contract promises (it returns 0): sdpa_core, gemm_bias_act,
+ * cswin_lepe_attn, xca, layernorm. */
+int    mi355_sdpa_core_fwd(const float* qkv, float* out, int B, int N, int heads, int d, float scale, int precision, mi355_stream_t stream);
+size_t mi355_sdpa_core_workspace_bytes(int B, int N, int heads, int d);
+int    mi355_gemm_bias_act_fwd(const float* X, const float* W, const float* bias, const float* gamma, const float* resid, float* Y, int M, int N,
+                               int K, int ldx, int ldy, int act, int precision, mi355_stream_t stream);
+size_t mi355_gemm_bias_act_workspace_bytes(int M, int N, int K);
+int    mi355_mixer_token_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const void* w1p16, const float* b1,
+                                 const void* w2s16, const float* b2, float* y, int B, int N, int C, int T, int precision, void* ws,
+                                 size_t ws_bytes, mi355_stream_t stream);
+size_t mi355_mixer_token_mlp_workspace_bytes(int B, int N, int C);
+size_t mi355_cswin_lepe_attn_workspace_bytes(int B, int reso, int Ctot);
+size_t mi355_xca_workspace_bytes(int B, int N, int heads, int d);
+size_t mi355_layernorm_workspace_bytes(int rows, int cols);
+
 int mi355_comm_unique_id(void* id_out, size_t id_bytes);
 int mi355_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);
 int mi355_allgather_f32(void* comm, const float* send, float* recv, size_t count, mi355_stream_t stream);

@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_RANGE_FALLBACK, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -52,6 +52,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"mixer_stats", 0, 0, 1},              // mixer_token_kernel at C = 512: LayerNorm row statistics inside the kernel (1) or by the row_stats_kernel pre-pass (0, default: measured equal)
     {"attn_nw", 8, 7, 8},                  // ViT attention core at 193 .. 208 tokens (13 query tiles): waves per workgroup, 8 (13 / 16 balance) or 7 (13 / 14)
     {"gemm_w4", 1, 0, 1},                  // 16-bit outputs, 576 <= K < 1536, whole 256 x 256 tiles: the one-wave-per-SIMD persistent kernel (gemm16_w4.hip) instead of gemm16_p8
+    {"range_fallback", 1, 0, 1},           // host policy of the drop-in modules (read by the binding): 1 = a forward whose fp16 operands saturated is re-run in strict mode, 0 = raise on the next call
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
@@ -106,6 +107,7 @@ long opt_mlp_tt4() { return opt(O_MLP_TT4); }
 long opt_mixer_stats() { return opt(O_MIXER_STATS); }
 long opt_attn_nw() { return opt(O_ATTN_NW); }
 long opt_gemm_w4() { return opt(O_GEMM_W4); }
+long opt_range_fallback() { return opt(O_RANGE_FALLBACK); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the
@@ -193,10 +195,53 @@ unsigned* sync_err_word_on(hipStream_t st) {
     if (!g_sync_block && stream_is_capturing(st)) return nullptr;         // never allocate pinned memory inside a capture
     return sync_err_word();
 }
+// ---- "which launch do I have to wait for before the range word is final?" (round 6: mi355_range_arm / mi355_range_wait) ---------------
+// While a device is ARMED, every launcher that hands a kernel the range word (range_word() below: the fp16 producers) marks the device
+// dirty; the NEXT MI355_LAUNCH_CHECK of any entry point -- i.e. right behind that producer's launch in stream order -- records ONE
+// re-used event on the producer's stream.  mi355_range_wait() synchronises on that event only: the non-reporting launches queued behind
+// the last producer (the attention core and the fp32-output projection behind a qkv product, fc2 behind fc1) keep the GPU busy while
+// the host already launches the caller's next block.  One relaxed load per launch when the device is not armed.
+namespace {
+struct RangeMark {
+    std::atomic<int> armed{0}, dirty{0}, have{0};
+    hipEvent_t ev = nullptr;
+    hipStream_t st = nullptr;
+};
+RangeMark g_rmark[MAX_DEV];
+}  // namespace
+void range_mark_flush() {
+    RangeMark& m = g_rmark[cur_dev()];
+    if (!m.dirty.load(std::memory_order_relaxed)) return;
+    m.dirty.store(0, std::memory_order_relaxed);
+    if (stream_is_capturing(m.st)) return;                                // never record the shared event into a graph
+    if (!m.ev && hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); m.ev = nullptr; return; }
+    if (hipEventRecord(m.ev, m.st) == hipSuccess) m.have.store(1, std::memory_order_relaxed);
+    else (void)hipGetLastError();
+}
 unsigned* range_word(hipStream_t st) {
     if (!g_sync_block && stream_is_capturing(st)) return nullptr;         // never allocate pinned memory inside a capture
     unsigned* w = sync_err_word();
+    if (w) {
+        RangeMark& m = g_rmark[cur_dev()];
+        if (m.armed.load(std::memory_order_relaxed)) { m.st = st; m.dirty.store(1, std::memory_order_relaxed); }
+    }
     return w ? w + 4 : nullptr;                                            // second quarter of the device's 64 bytes
+}
+int range_arm(int on) {
+    RangeMark& m = g_rmark[cur_dev()];
+    m.dirty.store(0, std::memory_order_relaxed);
+    m.have.store(0, std::memory_order_relaxed);
+    m.armed.store(on ? 1 : 0, std::memory_order_relaxed);
+    return MI355_OK;
+}
+int range_wait() {
+    range_mark_flush();                                                    // a producer launched by an entry without a trailing launch check
+    RangeMark& m = g_rmark[cur_dev()];
+    if (m.have.load(std::memory_order_relaxed) && m.ev) {
+        if (hipEventSynchronize(m.ev) != hipSuccess) return fail(MI355_EHIP, "mi355_range_wait: hipEventSynchronize -> %s", hipGetErrorString(hipGetLastError()));
+        m.have.store(0, std::memory_order_relaxed);
+    }
+    return range_pending("mi355_range_wait");
 }
 int range_pending(const char* who) {
     unsigned* w = g_sync_block ? g_sync_block + 16 * cur_dev() + 4 : nullptr;
@@ -399,6 +444,27 @@ long mi355_trace_end(char* report, size_t report_bytes) { return mi355::trace_en
 
 int mi355_sync_status(void) { return mi355::sync_pending("mi355_sync_status"); }
 int mi355_range_status(void) { return mi355::range_pending("mi355_range_status"); }
+// SURVEY.md 8(b) spellings (include/mi355attn.h, last section): same arguments, same code
+int mi355_sdpa_core_fwd(const float* qkv, float* out, int B, int N, int heads, int d, float scale, int precision, mi355_stream_t stream) {
+    return mi355_sdpa_fwd(qkv, out, B, N, heads, d, scale, precision, stream);
+}
+size_t mi355_sdpa_core_workspace_bytes(int, int, int, int) { return 0; }
+int mi355_gemm_bias_act_fwd(const float* X, const float* W, const float* bias, const float* gamma, const float* resid, float* Y, int M, int N,
+                            int K, int ldx, int ldy, int act, int precision, mi355_stream_t stream) {
+    return mi355_linear_fwd(X, W, bias, gamma, resid, Y, M, N, K, ldx, ldy, act, precision, stream);
+}
+size_t mi355_gemm_bias_act_workspace_bytes(int, int, int) { return 0; }
+int mi355_mixer_token_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, float ln_eps, const void* w1p16, const float* b1,
+                              const void* w2s16, const float* b2, float* y, int B, int N, int C, int T, int precision, void* ws,
+                              size_t ws_bytes, mi355_stream_t stream) {
+    return mi355_mixer_token_fwd(x, ln_w, ln_b, ln_eps, w1p16, b1, w2s16, b2, y, B, N, C, T, precision, ws, ws_bytes, stream);
+}
+size_t mi355_mixer_token_mlp_workspace_bytes(int B, int N, int C) { return mi355_mixer_token_workspace_bytes(B, N, C); }
+size_t mi355_cswin_lepe_attn_workspace_bytes(int, int, int) { return 0; }
+size_t mi355_xca_workspace_bytes(int, int, int, int) { return 0; }
+size_t mi355_layernorm_workspace_bytes(int, int) { return 0; }
+int mi355_range_arm(int on) { return mi355::range_arm(on); }
+int mi355_range_wait(void) { return mi355::range_wait(); }
 
 int mi355_event_time_begin(mi355_stream_t stream, void** handle) {
     MI355_CHECK_ARG(handle != nullptr);

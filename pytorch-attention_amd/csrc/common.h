@@ -59,6 +59,11 @@ unsigned* sync_err_word();            // device-visible pinned host word (null i
 // capture when the word does not exist yet (hipHostMalloc is illegal there): the launch then runs unguarded.
 unsigned* range_word(hipStream_t st);
 int   range_pending(const char* who);  // MI355_OK or MI355_ERANGE (reported once)
+// round 6 (api.hip): while the device is armed (mi355_range_arm), the launch check behind a launcher that called range_word() records an
+// event on that stream; mi355_range_wait() waits for the LAST such event only and returns the range status
+void  range_mark_flush();
+int   range_arm(int on);
+int   range_wait();
 unsigned  spin_limit();
 int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
 int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
@@ -138,6 +143,7 @@ int gemm_kn_batched(const float* A, const float* B, const float* bias_row, const
         hipError_t e_ = hipGetLastError();                                                      \
         if (e_ != hipSuccess)                                                                   \
             return mi355::fail(MI355_EHIP, "%s: kernel launch -> %s", __func__, hipGetErrorString(e_)); \
+        mi355::range_mark_flush();                                                              \
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -221,6 +227,15 @@ __device__ __forceinline__ float rg_absmax4_f(float m, rg_f4 v) {
 __device__ __forceinline__ void rg_report_f(float m, unsigned* word, unsigned code) {
     if (word && m >= 65520.0f) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Cheapest form for the VALU-bound fused block kernels (round 6: mlp_fused.hip, cswin_fused.hip): ONE v_max3_f32 with |.| source modifiers per
+// two converted values, the running maximum held as a plain float (starts at 0).  v_max3 returns the non-NaN operands; an inf operand -- the
+// input's own or a saturated product -- makes the maximum inf and IS reported (a false positive for an input that already holds inf costs
+// a strict re-run whose result is the reference's, inf included).  Report with rg_report_f.
+__device__ __forceinline__ float rg_max3abs(float m, float a, float b) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float rg_max3abs4(float m, rg_f4 v) { return rg_max3abs(rg_max3abs(m, v.x, v.y), v.z, v.w); }
 __device__ __forceinline__ float se_gate(float z, int kind) {
     if (!kind) return sigmoidf_(z);
     const float h = fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f;                    // relu6 clamps; torch's clamp keeps a NaN

@@ -32,6 +32,7 @@ struct StripeArgs {
     int B, reso, split, hb;    // hb: heads per branch
     float scale, eps;
     int win_per_img;           // windows per image and branch (reso / split)
+    unsigned* ovf;             // fp16 range word (common.h, code 4): q / k / v and ctx are 16-bit conversions of unbounded products; null for bf16
 };
 
 
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
     if (wi < nwin_total) load_x(b, win);
     __syncthreads();                                               // weights / tables / zeroed s_xn visible
     const float L2E = 1.44269504088896340736f;
+    float rgmax = 0.f;
     float* slab = s_o + wave * 16 * OP;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -236,10 +238,12 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
                 if (ft < 4) {
                     f4 v = acc;
                     if (ft < 2) v = v * a.scale;                   // cswin.py:116: q * scale before the product
+                    if constexpr (PREC == 1) rgmax = rg_max3abs4(rgmax, v);
                     const v4 h = M_::cvt(v);
                     unsigned short* dst = (ft < 2 ? s_q : s_k) + (wq * 16 + l15) * QP + (ft & 1) * 16 + g * 4;
                     *reinterpret_cast<v4*>(dst) = h;
                 } else {
+                    if constexpr (PREC == 1) rgmax = rg_max3abs4(rgmax, acc);       // (acc2 below holds the same values transposed)
                     const v4 h = M_::cvt(acc);
                     *reinterpret_cast<v4*>(s_v + ((ft - 4) * 16 + l15) * VP + wq * 16 + g * 4) = h;
                     // the same tile token-major for LePE (second orientation of the product: the matrix pipe has room)
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
                         lepe_tap<PREC>(r0, r1, nb, w0, w1);
                     }
                 }
+                if constexpr (PREC == 1) rgmax = rg_max3abs4(rg_max3abs4(rgmax, r0), r1);
                 const v4 h0 = M_::cvt(r0), h1 = M_::cvt(r1);
                 *reinterpret_cast<v8*>(static_cast<el*>(a.ctx) + ((long)b * L + win * org_step + soff) * C + ch0 + sc8) =
                     v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? 3 : 2)) void cswin_stripe_kernel(
         }
         b = nb; win = nwin;
     }
+    if constexpr (PREC == 1) rg_report_f(rgmax, a.ovf, 4u);
 }
 
 }  // namespace
@@ -364,6 +370,7 @@ extern "C" int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, c
     if (per_unit < 1) per_unit = 1;
     const int grid = (int)(per_unit * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
     const bool t3 = reso * split >= 48;                           // the model shapes (56 tokens): three key tiles need no validity mask
 #define GO(P_, C_)                                                                       \
     do {                                                                                 \

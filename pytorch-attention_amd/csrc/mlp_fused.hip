@@ -28,6 +28,9 @@ struct MlpArgs {
     // PROJ kernels: x1 = x + ctx Wp^T + bp is formed first (the proj Linear + residual of the block half in front of the MLP,
     // cswin.py:191-193), the MLP then runs on x1:  y = x1 + gamma * (W2 gelu(W1 LN(x1) + b1) + b2)
     const void* ctx; const void* wp; const float* bp;      // ctx (M, C) 16-bit, wp (C, C) 16-bit, bp (C) fp32
+    // fp16 range word (common.h rg_report_f, code 4; null for bf16 / under capture without a word): gelu(H) is the one 16-bit intermediate
+    // whose magnitude the weights do not bound a priori -- LN(x) is at most sqrt(C - 1) -- and it never reaches HBM, so nobody else sees it
+    unsigned* ovf;
 };
 
 // NWV waves per workgroup (one workgroup per CU), TT 16-token tiles per wave and step.  <16, 2>: 128 registers per lane, four waves per
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void mlp_fused_kernel(const MlpA
     __syncthreads();
     float* slab = s_slab + wave * 16 * SP;
     const float invC = 1.0f / (float)C;
+    float rgmax = 0.f;
 
     const long nchunk = (a.M + 16 * TT - 1) / (16 * TT);
     for (long ch = (long)blockIdx.x * NWV + wave; ch < nchunk; ch += (long)gridDim.x * NWV) {
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void mlp_fused_kernel(const MlpA
                 f4 p0 = s[tt][0], p1 = s[tt][1];
                 p0 = gelu16_fast4(p0);
                 p1 = gelu16_fast4(p1);
+                if constexpr (PREC == 1) rgmax = rg_max3abs4(rg_max3abs4(rgmax, p0), p1);
                 const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
                 pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             }
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void mlp_fused_kernel(const MlpA
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
+    if constexpr (PREC == 1) rg_report_f(rgmax, a.ovf, 4u);
 }
 
 // ---- C = 128 (hidden 512: CSWin stage 2, XCiT-nano): the weights (256 KB) do not fit in LDS, so the waves of a workgroup walk the
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_stream_kernel(const MlpArgs 
         *reinterpret_cast<v4*>(d + d2 + 4) = v4{n2[4], n2[5], n2[6], n2[7]};
     };
 
+    float rgmax = 0.f;
     const long ntile = (a.M + 15) / 16;
     const long niter = (ntile + NWV * TT - 1) / (NWV * TT);       // workgroup steps: 256 tokens each, uniform trip count for the barriers
     for (long it = blockIdx.x; it < niter; it += gridDim.x) {
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_stream_kernel(const MlpArgs 
             for (int tt = 0; tt < TT; ++tt) {
                 const f4 p0 = gelu16_fast4(s[tt][0]);
                 const f4 p1 = gelu16_fast4(s[tt][1]);
+                if constexpr (PREC == 1) rgmax = rg_max3abs4(rg_max3abs4(rgmax, p0), p1);
                 const v4 h0 = M_::cvt(p0), h1 = M_::cvt(p1);
                 pf[tt] = v8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             }
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_stream_kernel(const MlpArgs 
             }
         }
     }
+    if constexpr (PREC == 1) rg_report_f(rgmax, a.ovf, 4u);
 }
 
 template <int C, int HD>
@@ -428,6 +437,7 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
     MlpArgs a{};
     a.x = x; a.y = y; a.w1 = w1_16; a.w2 = w2_16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.M = M; a.eps = eps; a.do_ln = layernorm ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -481,6 +491,7 @@ extern "C" int mi355_proj_mlp_fused_fwd(const float* x, const void* ctx16, const
     a.x = x; a.y = y; a.w1 = w1_16; a.w2 = w2_16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.M = M; a.eps = eps; a.do_ln = layernorm ? 1 : 0;
     a.ctx = ctx16; a.wp = wp16; a.bp = bp;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
     const int ncu = mi355::resident_slots(1);
     if (C == 128) {
         constexpr size_t sm = (size_t)2 * (32 * (128 + 8) + 128 * 36) * 2 + (size_t)8 * 16 * 68 * 4 + (size_t)128 * (128 + 8) * 2 + (size_t)512 * 4;

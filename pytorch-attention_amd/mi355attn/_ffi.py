@@ -41,6 +41,8 @@ SIGNATURES = {
     "mi355_trace_end": (ctypes.c_long, [ctypes.c_char_p, c_size]),
     "mi355_sync_status": (c_int, []),
     "mi355_range_status": (c_int, []),
+    "mi355_range_arm": (c_int, [c_int]),
+    "mi355_range_wait": (c_int, []),
     "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_se_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "mi355_se_ex_fwd": (c_int, [c_vp] * 6 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),
@@ -129,6 +131,16 @@ SIGNATURES = {
     "mi355_mfma_yardstick": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
+    # SURVEY.md 8(b) spellings: aliases of mi355_sdpa_fwd / mi355_linear_fwd / mi355_mixer_token_fwd and the zero-byte workspace queries
+    "mi355_sdpa_core_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_int, c_vp]),
+    "mi355_sdpa_core_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_gemm_bias_act_fwd": (c_int, [c_vp] * 6 + [c_int] * 7 + [c_vp]),
+    "mi355_gemm_bias_act_workspace_bytes": (c_size, [c_int] * 3),
+    "mi355_mixer_token_mlp_fwd": (c_int, [c_vp] * 3 + [c_float] + [c_vp] * 5 + [c_int] * 5 + [c_vp, c_size, c_vp]),
+    "mi355_mixer_token_mlp_workspace_bytes": (c_size, [c_int] * 3),
+    "mi355_cswin_lepe_attn_workspace_bytes": (c_size, [c_int] * 3),
+    "mi355_xca_workspace_bytes": (c_size, [c_int] * 4),
+    "mi355_layernorm_workspace_bytes": (c_size, [c_int] * 2),
 }
 
 
