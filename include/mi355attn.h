@@ -134,6 +134,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.
+ *   "gemm_wreg"     1 (default) = fp32 (+ residual) outputs of square short products, N = K = 256 or 384, M >= 4096, no activation / LayerScale
+ *                   (XCiT's proj, CSWin stage-3 proj) run the weight-stationary-in-registers streaming kernel (gemm16_wreg.hip: eight waves, each
+ *                   holds its N / 8 columns of W as MFMA fragments for the whole kernel; X, residual and Y cross HBM once).  Bit-identical
+ *                   results; 0 = the tile kernels as before.
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.
@@ -169,15 +173,19 @@ int         mi355_sync_status(void);
  * (cleared by the report).  A host that wants certainty for a forward synchronises the stream first.  Remedy: run the module in
  * precision 0 (strict: bf16 hi/lo split, fp32 range) or precision 2 (bf16).  bf16 operands are never flagged. */
 int         mi355_range_status(void);
-/* "Is the range word final for what I have launched?" without draining the device (round 6).  mi355_range_arm(1) arms the calling thread's
- * current device: from then on the launch check behind every fp16 producer records ONE re-used event on the producer's stream (a relaxed
- * load per launch otherwise).  mi355_range_wait() synchronises on the LAST such event only -- launches queued behind the last producer keep
- * running -- and returns the range status (MI355_OK / MI355_ERANGE, cleared by the report); with no producer since the arm it returns the
- * status without waiting.  mi355_range_arm(0) disarms.  Not for use under hipGraph capture.  This is what the host mirror's modules use
- * to give the reference's behaviour on large activations by default: a forward whose fp16 operands saturated is run again in precision 0
- * (option "range_fallback" = 1, per device; 0 = no wait, the next call reports MI355_ERANGE). */
+/* "Is the range word final for what I have launched?" without draining the device (round 6).  mi355_range_arm(on) arms the calling thread's
+ * current device (on >= 1) or disarms it (0): while armed, the entries that launch fp16 producers are counted.  mi355_range_wait() records
+ * (if it has not happened yet) ONE event behind the last producer, synchronises on it -- launches queued behind that event keep running --
+ * and returns the range status (MI355_OK / MI355_ERANGE, cleared by the report); with no producer since the arm it returns the status
+ * without waiting.  on = 1 + k (k >= 1) carries a prediction, "the k-th producer entry since this call is the last one" (what
+ * mi355_range_launches() returned after the caller's previous forward of the same module): the event is then recorded in front of the
+ * first launch that follows that producer, so the wait does not cover the non-reporting tail of the forward (attention core, fp32-output
+ * projections).  A wrong prediction costs that slack, never correctness.  Not for use under hipGraph capture.  This is what the host
+ * mirror's modules use to give the reference's behaviour on large activations by default: a forward whose fp16 operands saturated is run
+ * again in precision 0 (option "range_fallback" = 1, per device; 0 = no wait, the next call reports MI355_ERANGE). */
 int         mi355_range_arm(int on);
 int         mi355_range_wait(void);
+long        mi355_range_launches(void);   /* producer entries since the last mi355_range_arm(on >= 1) on this device */
 
 /* ---- channel / spatial attention family: NCHW fp32, HBM-bound ------------------------------------ */
 
@@ -472,7 +480,11 @@ int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, const float*
  * operand type of `precision` (1 fp16, 2 bf16); for C = 128, w2_16 is arranged slice-major: (hidden/32, C, 32) with
  * w2_16[s][c][j] = W2[c][32 s + j] (the kernel streams 32-unit slices of both matrices through LDS).  x, y (M, C), b1', b2, gamma
  * fp32; b2 / gamma may be NULL.  Other shapes:
- * MI355_EUNSUPPORTED (callers use mi355_layernorm16_fwd + mi355_linear16_fwd x 2). */
+ * MI355_EUNSUPPORTED (callers use mi355_layernorm16_fwd + mi355_linear16_fwd x 2).
+ * `layernorm` is a flag word: bit 0 = normalise x; bit 1 (round 6) = the caller has PROVEN from the folded weights that the one unbounded
+ * 16-bit intermediate, gelu(W1' xn + b1'), stays below 65504 (|xn| <= sqrt(C - 1), so max_i (sum_j |W1'[i][j]| sqrt(C - 1) + |b1'[i]|) bounds
+ * it): the kernel then does not report into the fp16 range word and the launch does not count as a producer for mi355_range_wait.  Without
+ * bit 1 (and in precision 1) a saturating hidden activation is reported with code 4. */
 int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const float* b1, const void* w2_16, const float* b2, const float* gamma,
                         float* y, long M, int C, int hidden, int layernorm, float eps, int precision, mi355_stream_t stream);
 

@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_RANGE_FALLBACK, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_RANGE_FALLBACK, O_GEMM_WREG, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -53,6 +53,7 @@ static const OptDesc kOpts[O_COUNT] = {
     {"attn_nw", 8, 7, 8},                  // ViT attention core at 193 .. 208 tokens (13 query tiles): waves per workgroup, 8 (13 / 16 balance) or 7 (13 / 14)
     {"gemm_w4", 1, 0, 1},                  // 16-bit outputs, 576 <= K < 1536, whole 256 x 256 tiles: the one-wave-per-SIMD persistent kernel (gemm16_w4.hip) instead of gemm16_p8
     {"range_fallback", 1, 0, 1},           // host policy of the drop-in modules (read by the binding): 1 = a forward whose fp16 operands saturated is re-run in strict mode, 0 = raise on the next call
+    {"gemm_wreg", 1, 0, 1},                // fp32 (+ residual) outputs with N = K = 256 / 384: weight-stationary-in-registers streaming kernel (gemm16_wreg.hip)
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
@@ -108,6 +109,7 @@ long opt_mixer_stats() { return opt(O_MIXER_STATS); }
 long opt_attn_nw() { return opt(O_ATTN_NW); }
 long opt_gemm_w4() { return opt(O_GEMM_W4); }
 long opt_range_fallback() { return opt(O_RANGE_FALLBACK); }
+long opt_gemm_wreg() { return opt(O_GEMM_WREG); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the
@@ -196,47 +198,72 @@ unsigned* sync_err_word_on(hipStream_t st) {
     return sync_err_word();
 }
 // ---- "which launch do I have to wait for before the range word is final?" (round 6: mi355_range_arm / mi355_range_wait) ---------------
-// While a device is ARMED, every launcher that hands a kernel the range word (range_word() below: the fp16 producers) marks the device
-// dirty; the NEXT MI355_LAUNCH_CHECK of any entry point -- i.e. right behind that producer's launch in stream order -- records ONE
-// re-used event on the producer's stream.  mi355_range_wait() synchronises on that event only: the non-reporting launches queued behind
-// the last producer (the attention core and the fp32-output projection behind a qkv product, fc2 behind fc1) keep the GPU busy while
-// the host already launches the caller's next block.  One relaxed load per launch when the device is not armed.
+// While a device is ARMED, every launcher that hands a kernel the range word (range_word() below: the fp16 producers) counts itself and
+// marks the device dirty.  mi355_range_wait() must synchronise on an event that lies BEHIND the last producer; recording one behind every
+// producer would put ~50 marker packets into a ViT-Base forward (measured: +0.13 ms of 12.1), so the caller PREDICTS the last producer --
+// mi355_range_arm(1 + k): "the k-th producer since this call is the last one", the count its previous forward of the same module reported
+// (mi355_range_launches) -- and the ONE event of the forward is recorded in front of the first launch that follows the k-th producer
+// (TraceScope's constructor sits in front of every instrumented launch).  The non-reporting launches queued behind it (attention core,
+// fp32-output projections, fc2) then keep the GPU busy while the host already returns.  A wrong or missing prediction costs slack, never
+// correctness: a producer launched after the event marks the device dirty again and mi355_range_wait() records a second event at the tail.
 namespace {
 struct RangeMark {
-    std::atomic<int> armed{0}, dirty{0}, have{0};
+    std::atomic<int> armed{0}, dirty{0}, fresh{0}, have{0}, count{0}, expect{0};
     hipEvent_t ev = nullptr;
     hipStream_t st = nullptr;
 };
 RangeMark g_rmark[MAX_DEV];
-}  // namespace
-void range_mark_flush() {
-    RangeMark& m = g_rmark[cur_dev()];
-    if (!m.dirty.load(std::memory_order_relaxed)) return;
+void range_mark_record(RangeMark& m) {
     m.dirty.store(0, std::memory_order_relaxed);
     if (stream_is_capturing(m.st)) return;                                // never record the shared event into a graph
     if (!m.ev && hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); m.ev = nullptr; return; }
     if (hipEventRecord(m.ev, m.st) == hipSuccess) m.have.store(1, std::memory_order_relaxed);
     else (void)hipGetLastError();
 }
+}  // namespace
+// A producer ENTRY may issue several launches (split rounds, helper passes): range_word() only opens it (pending), the entry's closing
+// MI355_LAUNCH_CHECK marks the device dirty, and no event is ever recorded while an entry is open -- so the event always lies behind every
+// launch of the producer it covers.
+void range_mark_before_launch() {                                          // TraceScope: in front of every instrumented launch
+    RangeMark& m = g_rmark[cur_dev()];
+    if (!m.dirty.load(std::memory_order_relaxed) || m.fresh.load(std::memory_order_relaxed)) return;
+    const int e = m.expect.load(std::memory_order_relaxed);
+    if (e > 0 && m.count.load(std::memory_order_relaxed) >= e) range_mark_record(m);
+}
+void range_mark_entry_done() {                                             // MI355_LAUNCH_CHECK: the launches of the current entry are all enqueued
+    RangeMark& m = g_rmark[cur_dev()];
+    if (!m.fresh.load(std::memory_order_relaxed)) return;
+    m.fresh.store(0, std::memory_order_relaxed);
+    m.dirty.store(1, std::memory_order_relaxed);
+}
 unsigned* range_word(hipStream_t st) {
     if (!g_sync_block && stream_is_capturing(st)) return nullptr;         // never allocate pinned memory inside a capture
     unsigned* w = sync_err_word();
     if (w) {
         RangeMark& m = g_rmark[cur_dev()];
-        if (m.armed.load(std::memory_order_relaxed)) { m.st = st; m.dirty.store(1, std::memory_order_relaxed); }
+        if (m.armed.load(std::memory_order_relaxed)) {
+            m.st = st;
+            m.count.fetch_add(1, std::memory_order_relaxed);
+            m.fresh.store(1, std::memory_order_relaxed);                   // an open producer entry ("pending")
+        }
     }
     return w ? w + 4 : nullptr;                                            // second quarter of the device's 64 bytes
 }
 int range_arm(int on) {
     RangeMark& m = g_rmark[cur_dev()];
     m.dirty.store(0, std::memory_order_relaxed);
+    m.fresh.store(0, std::memory_order_relaxed);
     m.have.store(0, std::memory_order_relaxed);
+    if (on) m.count.store(0, std::memory_order_relaxed);                   // a disarm keeps the count for mi355_range_launches()
+    m.expect.store(on > 1 ? on - 1 : 0, std::memory_order_relaxed);
     m.armed.store(on ? 1 : 0, std::memory_order_relaxed);
     return MI355_OK;
 }
+long range_launches() { return g_rmark[cur_dev()].count.load(std::memory_order_relaxed); }
 int range_wait() {
-    range_mark_flush();                                                    // a producer launched by an entry without a trailing launch check
     RangeMark& m = g_rmark[cur_dev()];
+    if (m.fresh.load(std::memory_order_relaxed)) { m.fresh.store(0, std::memory_order_relaxed); m.dirty.store(1, std::memory_order_relaxed); }
+    if (m.dirty.load(std::memory_order_relaxed)) range_mark_record(m);     // no event behind the last producer yet: at the tail of the stream
     if (m.have.load(std::memory_order_relaxed) && m.ev) {
         if (hipEventSynchronize(m.ev) != hipSuccess) return fail(MI355_EHIP, "mi355_range_wait: hipEventSynchronize -> %s", hipGetErrorString(hipGetLastError()));
         m.have.store(0, std::memory_order_relaxed);
@@ -294,6 +321,7 @@ bool g_trace_report_pending = false;
 }  // namespace
 bool trace_on() { return g_trace_dev.load(std::memory_order_relaxed) >= 0; }
 TraceScope::TraceScope(hipStream_t st_, const char* fmt, ...) : idx(-1), st(st_) {
+    range_mark_before_launch();
     const int dev = g_trace_dev.load(std::memory_order_relaxed);
     if (dev < 0 || dev != cur_dev() || stream_is_capturing(st_)) return;
     char tag[160];
@@ -465,6 +493,7 @@ size_t mi355_xca_workspace_bytes(int, int, int, int) { return 0; }
 size_t mi355_layernorm_workspace_bytes(int, int) { return 0; }
 int mi355_range_arm(int on) { return mi355::range_arm(on); }
 int mi355_range_wait(void) { return mi355::range_wait(); }
+long mi355_range_launches(void) { return mi355::range_launches(); }
 
 int mi355_event_time_begin(mi355_stream_t stream, void** handle) {
     MI355_CHECK_ARG(handle != nullptr);

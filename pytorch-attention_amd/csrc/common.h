@@ -36,6 +36,7 @@ long  opt_mlp_tt4();
 long  opt_mixer_stats();
 long  opt_attn_nw();
 long  opt_gemm_w4();
+long  opt_gemm_wreg();
 // one-wave 16 x 32 tiles for small outputs (gemm_small.hip): MI355_EUNSUPPORTED when the shape is the engine's
 int   gemm_small_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int precision,
                     hipStream_t st);
@@ -59,11 +60,13 @@ unsigned* sync_err_word();            // device-visible pinned host word (null i
 // capture when the word does not exist yet (hipHostMalloc is illegal there): the launch then runs unguarded.
 unsigned* range_word(hipStream_t st);
 int   range_pending(const char* who);  // MI355_OK or MI355_ERANGE (reported once)
-// round 6 (api.hip): while the device is armed (mi355_range_arm), the launch check behind a launcher that called range_word() records an
-// event on that stream; mi355_range_wait() waits for the LAST such event only and returns the range status
-void  range_mark_flush();
+// round 6 (api.hip): while the device is armed (mi355_range_arm), launchers that call range_word() are counted; ONE event is recorded in front
+// of the first instrumented launch behind the predicted last producer (or at the tail); mi355_range_wait() waits for it and returns the status
+void  range_mark_before_launch();
+void  range_mark_entry_done();
 int   range_arm(int on);
 int   range_wait();
+long  range_launches();
 unsigned  spin_limit();
 int   sync_pending(const char* who);  // MI355_OK, or MI355_ESYNC with the error text set (the word is cleared: reported once)
 int   resident_slots(int per_cu);     // multiprocessor count of the current device x per_cu
@@ -143,7 +146,7 @@ int gemm_kn_batched(const float* A, const float* B, const float* bias_row, const
         hipError_t e_ = hipGetLastError();                                                      \
         if (e_ != hipSuccess)                                                                   \
             return mi355::fail(MI355_EHIP, "%s: kernel launch -> %s", __func__, hipGetErrorString(e_)); \
-        mi355::range_mark_flush();                                                              \
+        mi355::range_mark_entry_done();                                                         \
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

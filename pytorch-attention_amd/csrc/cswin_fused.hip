@@ -372,6 +372,7 @@ extern "C" int mi355_cswin_stripe_attn_fwd(const float* x, const void* wqkv16, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     a.ovf = precision == MI355_PREC_FP16 ? mi355::range_word(st) : nullptr;
     const bool t3 = reso * split >= 48;                           // the model shapes (56 tokens): three key tiles need no validity mask
+    MI355_TRACE(st, "cswin_stripe_kernel<C=%d> B=%d reso=%d split=%d", C, B, reso, split);
 #define GO(P_, C_)                                                                       \
     do {                                                                                 \
         if (split == 1 && t3) cswin_stripe_kernel<P_, C_, 3, true><<<grid, C_ * 4, 0, st>>>(a);    \

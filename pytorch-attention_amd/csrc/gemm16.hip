@@ -542,6 +542,17 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
             if (rc != MI355_EUNSUPPORTED) return rc;
         }
     }
+    if (variant == 0 && !out16 && N == K && (K == 256 || K == 384) && mi355::opt_gemm_wreg()) {
+        // square short products with an fp32 (+ residual) output (XCiT proj 384 x 384, CSWin stage-3 proj 256 x 256): bound by the residual /
+        // output stream, not by the matrix pipes -- weights stationary in registers, X / residual / Y each cross HBM once (gemm16_wreg.hip;
+        // round 6: XCiT proj 70 -> see profiles/r06_gemm_wreg.md; bit-identical to the tile kernels)
+        const int rc = mi355::gemm16_wreg(g, out16, precision, st);
+        if (rc == MI355_OK) {
+            MI355_LAUNCH_CHECK();
+            return MI355_OK;
+        }
+        if (rc != MI355_EUNSUPPORTED) return rc;
+    }
     if (variant == 0 && !out16 && (g.resid || N <= 768) && mi355::opt_gemm_pa()) {
         // fp32 (+ residual) outputs: the two-accumulator persistent kernel (gemm16_pa.hip) hides the residual / store round trips of
         // tile i under the main loop of tile i + 1 (ViT-Base proj 0.130 -> 0.106 ms, fc2 0.266 -> 0.259; profiles/r03_gemm_pa.md).

@@ -1,0 +1,169 @@
+// gemm16_wreg.hip -- Y (M x N, fp32) = resid + X16 (M x K) . W16^T (N x K) + bias  for SQUARE, SHORT products (N = K = 256 / 384) on gfx950:
+// the projection behind an attention core at token widths 256 ... 384 (XCiT XCA proj, xcit.py:263; CSWin stage 3 proj, cswin.py:192).
+//
+// Why a third GEMM schedule: at N = K = 384 the product is 14.8 GFLOP over 192 MB (16-bit X in, fp32 residual in, fp32 Y out) -- 6 us of
+// matrix pipe against 40 us of HBM at the copy rate of these boxes.  The tile kernels of the engine stream BOTH operands through LDS
+// per output tile and pay an epilogue per tile; on this shape they reach 2.8 TB/s (70 us: profiles/r05_XCABlock_kernel_seq.txt, and the
+// 256 x 256 tile leaves half of its second column tile empty at N = 384).  Here the WEIGHTS ARE STATIONARY IN REGISTERS:
+//
+//   workgroup  = 8 waves, persistent (one per CU); wave w owns output columns [w * N/8, (w + 1) * N/8) for EVERY row: its N/8 x K slice of W
+//                lives in VGPRs as MFMA A-operand fragments for the whole kernel (N = K = 384: 3 column tiles x 12 k-steps x 4 = 144 VGPRs);
+//   row tile   = 32 rows of X, staged once in LDS (double-buffered: the next tile's rows are in flight during the MFMAs) and read by all
+//                eight waves as B-operand fragments; Y^T tiles = W . X^T, so a lane holds 4 consecutive output columns of one row and the
+//                residual load / the store are 16-byte pieces of 192-byte (N = 384) row segments;
+//   per tile   : residual loads issued first, 2 x NT x K/32 MFMAs per wave, ONE workgroup barrier.
+// HBM traffic = X once + residual once + Y once; W is read once per workgroup (75 MB over the chip at N = K = 384, L2-resident).
+// A row's K steps are added in ascending order on the same MFMA instruction and the epilogue is (acc + bias) + resid: bit-identical to
+// gemm16_p8 / gemm16_pa on these shapes (tests/test_round6_kernels_gpu.py).
+#include "gemm16.h"
+#include "bufops.h"
+
+namespace {
+
+using namespace g16;
+
+template <typename T, int K, int NT, bool RESID>
+__global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
+    using v8 = typename Vec8<T>::t;
+    constexpr int NW = 8, NTHR = 512, RT = 2, ROWS = RT * 16;
+    constexpr int KS = K / 32;
+    constexpr int NCW = NT * 16;                  // columns per wave
+    constexpr int N = NW * NCW;
+    constexpr int XP = K + 8;                     // LDS row pitch (elements)
+    constexpr int CH = ROWS * (K / 8);            // 16-byte chunks of a row tile
+    constexpr int NLD = (CH + NTHR - 1) / NTHR;   // chunks per thread
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[2][ROWS * XP];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, gq = lane >> 4;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ W = static_cast<const T*>(g.B);
+    float* __restrict__ Y = static_cast<float*>(g.C);
+    const int n0 = wave * NCW;
+
+    // ---- this wave's slice of W: A-operand fragments (row = output column n0 + nt*16 + l15, k = ks*32 + gq*8 + [0,8)) ----------------
+    v8 wfr[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wfr[nt][ks] = *reinterpret_cast<const v8*>(W + (long)(n0 + nt * 16 + l15) * g.ldb + ks * 32 + gq * 8);
+    f4 bias4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        bias4[nt] = g.bias ? *reinterpret_cast<const f4*>(g.bias + n0 + nt * 16 + gq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+
+    const long ntile = ((long)g.M + ROWS - 1) / ROWS;
+    // chunk c of a row tile: row c / (K/8), 8 elements at column (c % (K/8)) * 8
+    int crow[NLD], ccol[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int c = t + j * NTHR;
+        crow[j] = c / (K / 8);
+        ccol[j] = (c % (K / 8)) * 8;
+    }
+    v8 areg[NLD];
+    auto fetch = [&](long tile) {                 // rows beyond M come back as zeros from the buffer range check (their outputs are dropped)
+        const long r0 = tile * ROWS;
+        const long left = (long)g.M - r0;
+        const int rows = (int)(left < ROWS ? left : ROWS);
+        const rsrc_t rs = make_rsrc(A + r0 * g.lda, (bufops_u32)(((long)(rows - 1) * g.lda + K) * 2));
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const bool live = (CH % NTHR == 0) || (t + j * NTHR < CH);
+            const bufops_u32 off = live ? (bufops_u32)((crow[j] * g.lda + ccol[j]) * 2) : OOB;
+            areg[j] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if ((CH % NTHR == 0) || (t + j * NTHR < CH))
+                *reinterpret_cast<v8*>(&s_x[buf][crow[j] * XP + ccol[j]]) = areg[j];
+    };
+
+    long tile = blockIdx.x;
+    if (tile < ntile) {
+        fetch(tile);
+        commit(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntile; tile += gridDim.x) {
+        const long r0 = tile * ROWS;
+        const long left = (long)g.M - r0;
+        const int rows = (int)(left < ROWS ? left : ROWS);
+        const long next = tile + gridDim.x;
+        // ---- everything this tile needs from HBM is requested up front: its residual rows, then the next tile's X rows ----------------
+        // per-tile descriptors (wave-uniform): a lane's offset is (row * ldc + column) * 4, rows beyond M fall outside num_records
+        const bufops_u32 ybytes = (bufops_u32)(((long)(rows - 1) * g.ldc + N) * 4);
+        f4 rr[RT][NT];
+        if constexpr (RESID) {
+            const rsrc_t rres = make_rsrc(g.resid + r0 * g.ldc, ybytes);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ldc + n0 + nt * 16 + gq * 4) * 4);
+                    rr[rt][nt] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
+                }
+        }
+        if (next < ntile) fetch(next);
+        // ---- Y^T tiles = W . X^T: lane (l15, gq) holds columns n0 + nt*16 + gq*4 + [0,4) of row rt*16 + l15 ------------------------------
+        f4 acc[RT][NT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const v8 xf = *reinterpret_cast<const v8*>(&s_x[buf][(rt * 16 + l15) * XP + ks * 32 + gq * 8]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mma16<T>(wfr[nt][ks], xf, acc[rt][nt]);
+            }
+        }
+        if (next < ntile) commit(buf ^ 1);
+        // ---- epilogue: (acc + bias) + resid, 16-byte stores -----------------------------------------------------------------------------
+        const rsrc_t ry = make_rsrc(Y + r0 * g.ldc, ybytes);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f4 v = acc[rt][nt] + bias4[nt];
+                if constexpr (RESID) v = v + rr[rt][nt];
+                const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ldc + n0 + nt * 16 + gq * 4) * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ry, off, 0, 0);
+            }
+        __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf]
+        buf ^= 1;
+    }
+}
+
+}  // namespace
+
+namespace mi355 {
+
+// MI355_EUNSUPPORTED (nothing launched) unless the shape is one of the square short products this schedule is built for.
+int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
+    if (out16 || g.act != MI355_ACT_NONE || g.gamma || g.resid_period || g.lnc_a || g.rowtau) return MI355_EUNSUPPORTED;
+    if (!(g.N == g.K && (g.K == 256 || g.K == 384))) return MI355_EUNSUPPORTED;
+    if (g.M < 4096 || (g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || g.ldb < g.K) return MI355_EUNSUPPORTED;
+    if ((long)32 * g.ldc * 4 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
+    if (precision != MI355_PREC_FP16 && precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;
+    const long ntile = ((long)g.M + 31) / 32;
+    const int ncu = resident_slots(1);
+    const int grid = (int)(ntile < ncu ? ntile : ncu);
+    MI355_TRACE(st, "gemm16_wreg_kernel<%s,%s> M=%d N=%d K=%d", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.resid ? "resid" : "plain", g.M, g.N, g.K);
+#define GO(T_, K_, NT_)                                                                  \
+    do {                                                                                 \
+        if (g.resid) gemm16_wreg_kernel<T_, K_, NT_, true><<<grid, 512, 0, st>>>(g);     \
+        else         gemm16_wreg_kernel<T_, K_, NT_, false><<<grid, 512, 0, st>>>(g);    \
+    } while (0)
+    if (precision == MI355_PREC_FP16) { if (g.K == 384) GO(_Float16, 384, 3); else GO(_Float16, 256, 2); }
+    else                              { if (g.K == 384) GO(__bf16, 384, 3); else GO(__bf16, 256, 2); }
+#undef GO
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mi355_range_status": (c_int, []),
     "mi355_range_arm": (c_int, [c_int]),
     "mi355_range_wait": (c_int, []),
+    "mi355_range_launches": (ctypes.c_long, []),
     "mi355_se_workspace_bytes": (c_size, [c_int] * 4),
     "mi355_se_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "mi355_se_ex_fwd": (c_int, [c_vp] * 6 + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp]),

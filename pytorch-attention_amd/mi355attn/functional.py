@@ -154,6 +154,8 @@ def range_fallback_forward(module, forward, args, kwargs):
     this thread arms the library (mi355_range_arm: the launch check behind every fp16 producer records one re-used event), runs the
     forward in the package's precision, then waits for the LAST producer of the forward only (mi355_range_wait) -- the launches queued
     behind it (attention core, fp32-output projections) keep the GPU busy while the host returns -- and reads the device's range word.
+    The event is recorded ONCE per forward, in front of the first launch behind the producer the previous forward of this module
+    counted as its last (mi355_range_launches -> `_mi355_nprod`; a first call records at the tail).
     Clean: the result is returned, no device synchronisation happened.  Fired (here or in a pre-launch check inside the forward): ONE
     warning, the device is drained, the forward runs again in strict mode (bf16 hi / lo split: fp32 range, fp32-class accuracy), also
     for sub-modules built with an explicit 16-bit `precision=`.  Option "range_fallback" = 0 (per device) restores the round-3 contract:
@@ -172,10 +174,16 @@ def range_fallback_forward(module, forward, args, kwargs):
     _guard.depth = 1
     why = None
     try:
-        lib().mi355_range_arm(1)
+        # 1 + k: "the k-th fp16 producer of this forward is the last one" -- what the previous forward of this module counted
+        lib().mi355_range_arm(1 + getattr(module, "_mi355_nprod", 0))
         try:
             y = forward(module, *args, **kwargs)
-            if lib().mi355_range_wait() == 0:
+            rc = lib().mi355_range_wait()
+            try:
+                module._mi355_nprod = int(lib().mi355_range_launches())
+            except AttributeError:                            # a module that refuses new attributes: no prediction next time
+                pass
+            if rc == 0:
                 return y
             msg = lib().mi355_last_error()
             why = msg.decode() if msg else "fp16 range word set"
@@ -749,12 +757,20 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None, ctx16=None, proj=None
         if ln is not None:
             b1 = linear(ln.bias.detach().reshape(1, -1).contiguous(), w1.contiguous(), b1, precision=PREC_STRICT).reshape(-1)    # b1 + W1 ln.bias, no vendor BLAS
             w1 = w1 * ln.weight.detach()[None, :]
-        return cast16(w1.contiguous(), p), b1.contiguous()
+        # range proof (round 6): behind a LayerNorm |xn| <= sqrt(C - 1), so the 16-bit hidden activation is bounded by the folded weights
+        # alone; proven once per parameter version (one flag read), the kernel then has nothing to report and the host nothing to wait for.
+        # 60000 leaves room for the fp16 rounding of W1' (2^-11 relative).  Under stream capture no read is possible: unproven.
+        proven = False
+        if ln is not None and p == PREC_FP16 and not (w1.is_cuda and torch.cuda.is_current_stream_capturing()):
+            bound = (w1.abs().sum(dim=1) * float(C - 1) ** 0.5 + b1.abs()).max()
+            proven = bool((bound < 60000.0).item())
+        return cast16(w1.contiguous(), p), b1.contiguous(), proven
 
     parts = [fc1.weight] + ([] if fc1.bias is None else [fc1.bias]) + ([] if ln is None else [ln.weight, ln.bias])
     tag = tuple((t._version, t.data_ptr()) for t in parts)
     anchors = (fc1,) if ln is None else (fc1, ln)
-    w1_16, b1 = _derived_get(anchors, ("mlp_fused_w1", p), tag, build)
+    w1_16, b1, proven = _derived_get(anchors, ("mlp_fused_w1", p), tag, build)
+    ln_flags = (0 if ln is None else 1) | (2 if proven else 0)
     if C == 64:
         w2_16 = weight16(fc2.weight, p)
     else:                                               # slice-major (hidden/32, C, 32): the kernel streams 32-unit slices through LDS
@@ -769,11 +785,11 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None, ctx16=None, proj=None
                                                                   lambda: torch.zeros(C, dtype=torch.float32, device=x.device))
         check(lib().mi355_proj_mlp_fused_fwd(dptr(x), dptr(ctx16), dptr(wp16), dptr(require_device_f32(bp, "proj.bias")), dptr(w1_16), dptr(b1),
                                              dptr(w2_16), dptr(_opt(fc2.bias, "fc2.bias")), dptr(_opt(gamma, "gamma")), dptr(y), M, C, Hd,
-                                             0 if ln is None else 1, float(ln.eps) if ln is not None else 0.0, p, stream_ptr(x.device)),
+                                             ln_flags, float(ln.eps) if ln is not None else 0.0, p, stream_ptr(x.device)),
               "mi355_proj_mlp_fused_fwd")
         return y
     check(lib().mi355_mlp_fused_fwd(dptr(x), dptr(w1_16), dptr(b1), dptr(w2_16), dptr(_opt(fc2.bias, "fc2.bias")), dptr(_opt(gamma, "gamma")),
-                                    dptr(y), M, C, Hd, 0 if ln is None else 1, float(ln.eps) if ln is not None else 0.0, p,
+                                    dptr(y), M, C, Hd, ln_flags, float(ln.eps) if ln is not None else 0.0, p,
                                     stream_ptr(x.device)), "mi355_mlp_fused_fwd")
     return y
 

@@ -66,3 +66,19 @@ def assert_parity(y, r, tol=1e-3, what=""):
 
 def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "attention_mechanisms"))
+
+
+class no_range_fallback:
+    """The round-3 boundary contract for the body: "range_fallback" = 0 on the current device (module(x) does not wait for its fp16
+    producers and does not re-run; a saturated operand is reported by the NEXT call / mi355_range_status).  Default since round 6: 1."""
+
+    def __enter__(self):
+        import mi355attn
+        self.old = mi355attn.get_option("range_fallback")
+        mi355attn.set_option("range_fallback", 0)
+        return self
+
+    def __exit__(self, *exc):
+        import mi355attn
+        mi355attn.set_option("range_fallback", self.old)
+        return False
