@@ -138,6 +138,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   (XCiT's proj, CSWin stage-3 proj) run the weight-stationary-in-registers streaming kernel (gemm16_wreg.hip: eight waves, each
  *                   holds its N / 8 columns of W as MFMA fragments for the whole kernel; X, residual and Y cross HBM once).  Bit-identical
  *                   results; 0 = the tile kernels as before.
+ *   "xca_tr"        1 (default) = mi355_xca16_fwd with 16-bit qkv and N <= 224 tokens forms the d x d covariance on the 16-bit matrix pipe
+ *                   (fp32 accumulation; the products of 16-bit operands are exact in fp32) from one transposed LDS image of q and k
+ *                   (xca_tr_kernel); 0 = the token-streaming kernel with exact-fp32 MFMAs on fp32 copies (any N; differs at the 1e-7 level:
+ *                   the summation order inside the matrix instruction).
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.

@@ -610,6 +610,7 @@ int mi355_stream_copy(const void* src, void* dst, size_t bytes, mi355_stream_t s
     const long n4 = (long)(bytes / 16);
     if (n4 == 0) return MI355_OK;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    MI355_TRACE(static_cast<hipStream_t>(stream), "stream_copy_kernel bytes=%zu", bytes);
     stream_copy_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const float4*>(src),
                                                                             static_cast<float4*>(dst), n4);
     MI355_LAUNCH_CHECK();

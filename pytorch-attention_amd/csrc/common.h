@@ -37,6 +37,7 @@ long  opt_mixer_stats();
 long  opt_attn_nw();
 long  opt_gemm_w4();
 long  opt_gemm_wreg();
+long  opt_xca_tr();
 // one-wave 16 x 32 tiles for small outputs (gemm_small.hip): MI355_EUNSUPPORTED when the shape is the engine's
 int   gemm_small_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int precision,
                     hipStream_t st);

@@ -266,6 +266,163 @@ __global__ __launch_bounds__(256, D <= 48 ? 4 : 2) void xca_kernel(const IT* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// XCA core for 16-bit q / k / v and N <= 224 tokens (XCiT at 224 px: 14 x 14 = 196), round 6.  The streaming kernel above spends its
+// phase 1 on 468 exact-fp32 MFMAs of 32 cycles per (image, head) over fp32 copies of q / k that it parks in LDS chunk by chunk (four
+// stage-barrier-compute-barrier rounds): 58 us for 153 MB.  When q and k ARRIVE in the 16-bit operand format (the output of the qkv
+// GEMM), their products are exact in fp32 anyway (11-bit x 11-bit significands), so G = Q^T K runs on the 16-bit matrix pipe with fp32
+// accumulation -- 63 MFMAs of 16 cycles -- and loses nothing that the inputs still carry:
+//   * ONE stage: the head's q and k go to LDS transposed ([channel][token], zero beyond N) through a 4-token x 8-channel register
+//     transpose (eight 8-byte writes per four 16-byte loads), one barrier;
+//   * G tiles are dealt to the waves whole (full token range each: no partial sums, no reduction order to fix), the squared column
+//     norms are summed from the same LDS image in token order;
+//   * G, then the 16-bit image of A = softmax(G), overwrite the q / k area; phase 2 (norms, temperature, row softmax in fp32) and phase 3
+//     (O = A V^T with V fragments straight from global memory) are those of xca_kernel.
+// 44.5 KB of LDS per workgroup at d = 48: three workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int D, typename T>
+__global__ __launch_bounds__(256, D <= 48 ? 3 : 2) void xca_tr_kernel(const T* __restrict__ qkv, const float* __restrict__ temperature, T* __restrict__ out,
+                                                        int N, int heads) {
+    typedef T v8 __attribute__((ext_vector_type(8)));
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    constexpr int NMAX = 224, TP = NMAX + 8;          // token pitch of the transposed images (elements)
+    constexpr int DT = D / 16, D8 = D / 8, P = D + 1;
+    constexpr int KSA = (D + 31) / 32, AP = KSA * 32 + 8, RPT = (D + 15) / 16;
+    constexpr int UNITS = (NMAX / 4) * D8;            // (4 tokens x 8 channels) units per array
+    __shared__ __attribute__((aligned(16))) unsigned short s_t[2 * D * TP];    // q^T | k^T; later G (fp32, pitch P), then the 16-bit image of A
+    __shared__ float s_n[2 * D];
+    static_assert(D * P * 4 <= 2 * D * TP * 2 && D * AP * 2 <= D * P * 4, "G and the A image fit the q / k area");
+    T* s_q = reinterpret_cast<T*>(s_t);
+    T* s_k = s_q + D * TP;
+    float* s_g = reinterpret_cast<float*>(s_t);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lid = xcd_contiguous_block();
+    const int h = lid % heads, b = lid / heads;
+    const int C = heads * D;
+    const long row3 = 3L * C;
+    const T* base = qkv + (long)b * N * row3 + h * D;
+    // ---- stage q^T and k^T -----------------------------------------------------------------------------------------------------------
+    for (int u = t; u < 2 * UNITS; u += 256) {
+        const int arr = u >= UNITS, uu = u - arr * UNITS, tg = uu / D8, cg = uu % D8;
+        v8 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tg * 4 + j;
+            r[j] = v8{};
+            if (n < N) r[j] = *reinterpret_cast<const v8*>(base + (long)n * row3 + arr * C + cg * 8);
+        }
+        T* dst = (arr ? s_k : s_q) + (cg * 8) * TP + tg * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<v4*>(dst + q * TP) = v4{r[0][q], r[1][q], r[2][q], r[3][q]};
+    }
+    __syncthreads();
+    // ---- squared column norms (token order) and G = Q^T K on the 16-bit pipe ------------------------------------------------------------
+    const int nks = (N + 31) >> 5;
+    float nrm = 0.f;
+    if (t < 2 * D) {
+        const T* col = s_q + t * TP;                   // rows 0 .. D-1 are q^T, D .. 2D-1 are k^T (s_k = s_q + D * TP)
+        for (int c = 0; c < nks * 4; ++c) {
+            const v8 v = *reinterpret_cast<const v8*>(col + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nrm = __builtin_fmaf((float)v[e], (float)v[e], nrm);
+        }
+    }
+    constexpr int NTILE = DT * DT, TPW = (NTILE + 3) / 4;
+    f4 gacc[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        gacc[k] = f4{0.f, 0.f, 0.f, 0.f};
+        const int tile = wave + 4 * k;
+        if (tile < NTILE) {
+            const int i = tile / DT, j = tile % DT;
+            for (int ks = 0; ks < nks; ++ks) {
+                const v8 af = *reinterpret_cast<const v8*>(s_q + (i * 16 + l15) * TP + ks * 32 + g * 8);
+                const v8 bf = *reinterpret_cast<const v8*>(s_k + (j * 16 + l15) * TP + ks * 32 + g * 8);
+                if constexpr (std::is_same<T, _Float16>::value) gacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, gacc[k], 0, 0, 0);
+                else gacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, gacc[k], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // everybody is done reading q^T / k^T
+    if (t < 2 * D) s_n[t] = fmaxf(sqrtf(nrm), 1e-12f);                 // F.normalize: x / max(||x||, 1e-12)
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int tile = wave + 4 * k;
+        if (tile < NTILE) {
+            const int i = tile / DT, j = tile % DT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_g[(i * 16 + g * 4 + r) * P + j * 16 + l15] = gacc[k][r];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: A = softmax_rows(G / (|q_i| |k_j|) * temperature), 16 lanes per row (xca_kernel) ----------------------------------------
+    {
+        const float temp = temperature[h];
+        const int tj = t & 15;
+        float pv[RPT][DT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int i = (t >> 4) + 16 * rr;
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                const int j = tj + 16 * c;
+                pv[rr][c] = i < D ? s_g[i * P + j] / (s_n[i] * s_n[D + j]) * temp : 0.f;
+                m = fmaxf(m, pv[rr][c]);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) { pv[rr][c] = expf(pv[rr][c] - m); sum += pv[rr][c]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+#pragma unroll
+            for (int c = 0; c < DT; ++c) pv[rr][c] = pv[rr][c] / sum;
+        }
+        __syncthreads();
+        T* a16 = reinterpret_cast<T*>(s_t);
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int i = (t >> 4) + 16 * rr;
+            if (i < D) {
+#pragma unroll
+                for (int c = 0; c < 2 * KSA; ++c) a16[i * AP + tj + 16 * c] = c < DT ? (T)pv[rr][c < DT ? c : 0] : (T)0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: O[i][n] = sum_j A[i][j] v[n][j] on the 16-bit pipe, V fragments straight from global memory (xca_kernel, PV16) -----------
+    {
+        const T* a16 = reinterpret_cast<const T*>(s_t);
+        v8 af[DT][KSA];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KSA; ++kk) af[i][kk] = *reinterpret_cast<const v8*>(a16 + (i * 16 + l15) * AP + kk * 32 + g * 8);
+        const int ntiles = (N + 15) >> 4;
+        for (int nt = wave; nt < ntiles; nt += 4) {
+            const int n = nt * 16 + l15;
+            v8 bf[KSA];
+#pragma unroll
+            for (int kk = 0; kk < KSA; ++kk) {
+                bf[kk] = v8{};
+                if (n < N && kk * 32 + g * 8 < D) bf[kk] = *reinterpret_cast<const v8*>(base + (long)n * row3 + 2 * C + kk * 32 + g * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KSA; ++kk) {
+                    if constexpr (std::is_same<T, _Float16>::value) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[kk], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[kk], acc, 0, 0, 0);
+                }
+                if (n < N) *reinterpret_cast<v4*>(out + ((long)b * N + n) * C + h * D + i * 16 + g * 4) = v4{(T)acc.x, (T)acc.y, (T)acc.z, (T)acc.w};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // LPI: workgroup = (image, 32 channels); 256 threads = 32 token lanes x 8 channel quads (16-byte LDS / HBM accesses).
 // Round 3: ONE LDS tile with a zero halo.  The first conv's results of a thread's (at most 8) tokens wait in registers until every
 // thread has read its 3x3 neighbourhoods, then overwrite the tile's interior in place -- 32 KB instead of 50 KB per workgroup at 14x14
@@ -614,6 +771,19 @@ int mi355_xca16_fwd(const void* qkv, int qkv_is16, const float* temperature, voi
     MI355_CHECK_ARG(aligned16(qkv) && aligned16(out16));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = B * heads;
+    if (qkv_is16 && N <= 224 && mi355::opt_xca_tr() && (d == 32 || d == 48 || d == 64)) {
+        // 16-bit q / k / v, at most 224 tokens: covariance on the 16-bit matrix pipe from ONE transposed LDS image (xca_tr_kernel)
+        MI355_TRACE(st, "xca_tr_kernel<d=%d> B=%d N=%d heads=%d", d, B, N, heads);
+#define XTR(D_)                                                                                                                          \
+        do {                                                                                                                             \
+            if (precision == MI355_PREC_FP16) xca_tr_kernel<D_, _Float16><<<grid, 256, 0, st>>>(static_cast<const _Float16*>(qkv), temperature, static_cast<_Float16*>(out16), N, heads); \
+            else                              xca_tr_kernel<D_, __bf16><<<grid, 256, 0, st>>>(static_cast<const __bf16*>(qkv), temperature, static_cast<__bf16*>(out16), N, heads);         \
+        } while (0)
+        if (d == 32) XTR(32); else if (d == 48) XTR(48); else XTR(64);
+#undef XTR
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
     MI355_TRACE(st, "xca_kernel<d=%d,out16%s> B=%d N=%d heads=%d", d, qkv_is16 ? ",in16" : "", B, N, heads);
 #define XCA16(D_)                                                                                                              \
     do {                                                                                                                       \

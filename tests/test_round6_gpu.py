@@ -141,8 +141,10 @@ def test_range_fallback_off_keeps_the_round3_contract():
 
 
 def test_range_wait_does_not_wait_for_launches_behind_the_last_producer():
-    """mi355_range_wait synchronises on the event behind the LAST fp16 producer: with a long non-reporting kernel queued behind a cast16,
-    the wait returns while that kernel is still running (the stream is not idle yet)."""
+    """mi355_range_wait synchronises on ONE event behind the last fp16 producer.  With the prediction "the first producer is the last"
+    (mi355_range_arm(1 + 1)) the event is recorded in front of the first launch behind the cast16: with ~4 ms of non-reporting copies queued
+    behind it the wait returns while they are still running.  Without a prediction (arm(1)) the event goes to the tail: the same wait
+    drains the stream -- correct, just without the slack."""
     import mi355attn
     from mi355attn import functional as F
     L = mi355attn.lib()
@@ -151,19 +153,23 @@ def test_range_wait_does_not_wait_for_launches_behind_the_last_producer():
     big = torch.empty(1 << 28, dtype=torch.float32, device=dev)        # 1 GiB: the copy behind the producer takes ~0.5 ms
     dst = torch.empty_like(big)
     torch.cuda.synchronize()
-    assert L.mi355_range_arm(1) == 0
-    try:
-        F.cast16(x, 1)                                                 # producer (records the event in its launch check)
-        for _ in range(8):
-            F.stream_copy(big, dst)                                    # ~4 ms of non-reporting work behind it
-        done = torch.cuda.Event()
-        done.record()
-        assert L.mi355_range_wait() == 0
-        still_busy = not done.query()
-    finally:
-        L.mi355_range_arm(0)
-    torch.cuda.synchronize()
-    assert still_busy, "mi355_range_wait drained the whole stream"
+    busy = {}
+    for arm in (2, 1):
+        assert L.mi355_range_arm(arm) == 0
+        try:
+            F.cast16(x, 1)                                             # the one producer
+            for _ in range(8):
+                F.stream_copy(big, dst)                                # ~4 ms of non-reporting work behind it
+            done = torch.cuda.Event()
+            done.record()
+            assert L.mi355_range_wait() == 0
+            busy[arm] = not done.query()
+            assert L.mi355_range_launches() == 1
+        finally:
+            L.mi355_range_arm(0)
+        torch.cuda.synchronize()
+    assert busy[2], "with the prediction, mi355_range_wait must not drain the stream"
+    assert not busy[1], "without a prediction the event is recorded at the tail"
 
 
 def test_survey_8b_aliases_run_the_same_code():

@@ -73,3 +73,52 @@ def test_weight_stationary_gemm_output_may_alias_the_residual():
                                 _ffi.stream_ptr(y.device)) == 0
     torch.cuda.synchronize()
     assert torch.equal(y, want)
+
+
+def _xca_ref(qkv16, temperature, heads):
+    """fp64 evaluation of xcit.py:249-262 on the 16-bit inputs (what both kernels are given)."""
+    B, N, C3 = qkv16.shape
+    C = C3 // 3
+    d = C // heads
+    q, k, v = (qkv16.double().cpu().reshape(B, N, 3, heads, d).permute(2, 0, 3, 4, 1))      # (3, B, h, d, N)
+    q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    k = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    a = ((q @ k.transpose(-2, -1)) * temperature.double().cpu().reshape(1, heads, 1, 1)).softmax(dim=-1)
+    return (a @ v).permute(0, 3, 1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("B,N,heads,d", [(5, 196, 8, 48), (3, 197, 4, 32), (2, 224, 2, 64), (4, 50, 8, 48), (2, 16, 4, 32)])
+def test_xca_core_on_the_16bit_pipe_matches_the_streaming_kernel(B, N, heads, d, prec):
+    """xca_tr_kernel (round 6: covariance on the 16-bit matrix pipe from one transposed LDS image) against xca_kernel (exact-fp32 MFMAs on
+    fp32 copies) on the same 16-bit q / k / v: both round the context to the operand type, so they agree to one unit of that rounding;
+    both against the fp64 evaluation."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(B * 1000 + N + d)
+    C = heads * d
+    qkv16 = F.cast16(torch.randn(B, N, 3 * C, device="cuda"), prec)
+    temp = (0.5 + torch.rand(heads, device="cuda")) * 3.0
+    outs, tags = {}, {}
+    old = mi355attn.get_option("xca_tr")
+    try:
+        for v in (1, 0):
+            mi355attn.set_option("xca_tr", v)
+
+            def run():
+                outs[v] = F.xca_core(qkv16, temp, heads, precision=prec, out16=True)
+            tags[v] = _tags(run)
+            torch.cuda.synchronize()
+    finally:
+        mi355attn.set_option("xca_tr", old)
+    assert any("xca_tr_kernel" in t for t in tags[1]) and not any("xca_tr_kernel" in t for t in tags[0]), (tags[1], tags[0])
+    ref = _xca_ref(qkv16, temp, heads).float()
+    tol = 1.5e-3 if prec == 1 else 1.2e-2                               # the output itself is rounded to fp16 / bf16
+    assert_parity(outs[1].float().cpu(), ref, tol, "xca_tr vs fp64")
+    assert_parity(outs[0].float().cpu(), ref, tol, "xca (streaming) vs fp64")
+    # one against the other: the same A within ~1e-7, then the same 16-bit P.V -> at most an ulp of the operand type apart
+    ulp = 2.0 ** -10 if prec == 1 else 2.0 ** -7
+    diff = (outs[1].float() - outs[0].float()).abs().max().item()
+    assert diff <= 2 * ulp * outs[0].float().abs().max().item(), diff
+    again = F.xca_core(qkv16, temp, heads, precision=prec, out16=True)
+    assert torch.equal(again, outs[1]), "run-to-run"
