@@ -38,6 +38,11 @@ long  opt_attn_nw();
 long  opt_gemm_w4();
 long  opt_gemm_wreg();
 long  opt_xca_tr();
+long  opt_mlp_wide();
+// fused LayerNorm + MLP for C = 256 / 384 (mlp_wide.hip): waves split the weights, fragments go global -> VGPR
+bool  mlp_wide_applicable(int C, int hidden);
+int   mlp_wide(const float* x, const void* w1_16, const float* b1, const void* w2_16, const float* b2, const float* gamma, float* y, long M, int C,
+               int layernorm, float eps, int precision, hipStream_t st);
 // one-wave 16 x 32 tiles for small outputs (gemm_small.hip): MI355_EUNSUPPORTED when the shape is the engine's
 int   gemm_small_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int precision,
                     hipStream_t st);

@@ -430,10 +430,17 @@ extern "C" int mi355_mlp_fused_fwd(const float* x, const void* w1_16, const floa
                                    float* y, long M, int C, int hidden, int layernorm, float eps, int precision, mi355_stream_t stream) {
     MI355_CHECK_ARG(x && w1_16 && b1 && w2_16 && y && M > 0);
     MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
-    if (!((C == 64 && hidden == 256) || (C == 128 && hidden == 512)))
-        return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: built for C = 64, hidden = 256 and C = 128, hidden = 512 (got C = %d, hidden = %d)", C, hidden);
     if (!aligned16(x) || !aligned16(y) || !aligned16(w1_16) || !aligned16(w2_16))
         return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: 16-byte aligned buffers required");
+    if (mi355::mlp_wide_applicable(C, hidden) && mi355::opt_mlp_wide()) {        // C = 256 / 384: the weight-split kernel (mlp_wide.hip), W2 row-major
+        if ((b2 && !aligned16(b2)) || (gamma && !aligned16(gamma)) || !aligned16(b1))
+            return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: 16-byte aligned bias / LayerScale vectors required at C = %d", C);
+        if (int rc = mi355::mlp_wide(x, w1_16, b1, w2_16, b2, gamma, y, M, C, layernorm, eps, precision, static_cast<hipStream_t>(stream))) return rc;
+        MI355_LAUNCH_CHECK();
+        return MI355_OK;
+    }
+    if (!((C == 64 && hidden == 256) || (C == 128 && hidden == 512)))
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_mlp_fused_fwd: built for C = 64 / 128 / 256 / 384 with hidden = 4 C (got C = %d, hidden = %d)", C, hidden);
     MlpArgs a{};
     a.x = x; a.y = y; a.w1 = w1_16; a.w2 = w2_16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.M = M; a.eps = eps; a.do_ln = (layernorm & 1) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, D <= 48 ? 4 : 2) void xca_kernel(const IT* __r
 //   * G tiles are dealt to the waves whole (full token range each: no partial sums, no reduction order to fix), the squared column
 //     norms are summed from the same LDS image in token order;
 //   * G, then the 16-bit image of A = softmax(G), overwrite the q / k area; phase 2 (norms, temperature, row softmax in fp32) and phase 3
-//     (O = A V^T with V fragments straight from global memory) are those of xca_kernel.
+//     (O = A V^T with V fragments straight from global memory -- requested at kernel start, beside q and k) are those of xca_kernel.
 // 44.5 KB of LDS per workgroup at d = 48: three workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int D, typename T>
@@ -300,19 +300,41 @@ __global__ __launch_bounds__(256, D <= 48 ? 3 : 2) void xca_tr_kernel(const T* _
     const int C = heads * D;
     const long row3 = 3L * C;
     const T* base = qkv + (long)b * N * row3 + h * D;
-    // ---- stage q^T and k^T -----------------------------------------------------------------------------------------------------------
-    for (int u = t; u < 2 * UNITS; u += 256) {
+    // ---- everything the workgroup needs from HBM is requested up front: q and k (to be transposed into LDS), and this wave's V fragments
+    //      of phase 3 (token tiles wave, wave + 4, ...: at most four of the fourteen), which wait in registers until A exists ------------------
+    constexpr int UPT = (2 * UNITS + 255) / 256;       // (4 tokens x 8 channels) units per thread
+    v8 r[UPT][4];
+#pragma unroll
+    for (int it = 0; it < UPT; ++it) {
+        const int u = t + it * 256;
         const int arr = u >= UNITS, uu = u - arr * UNITS, tg = uu / D8, cg = uu % D8;
-        v8 r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tg * 4 + j;
-            r[j] = v8{};
-            if (n < N) r[j] = *reinterpret_cast<const v8*>(base + (long)n * row3 + arr * C + cg * 8);
+            r[it][j] = v8{};
+            if (u < 2 * UNITS && n < N) r[it][j] = *reinterpret_cast<const v8*>(base + (long)n * row3 + arr * C + cg * 8);
         }
-        T* dst = (arr ? s_k : s_q) + (cg * 8) * TP + tg * 4;
+    }
+    constexpr int VT = (NMAX / 16 + 3) / 4;            // token tiles of phase 3 per wave
+    v8 vfr[VT][KSA];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<v4*>(dst + q * TP) = v4{r[0][q], r[1][q], r[2][q], r[3][q]};
+    for (int i = 0; i < VT; ++i) {
+        const int n = (wave + 4 * i) * 16 + l15;
+#pragma unroll
+        for (int kk = 0; kk < KSA; ++kk) {
+            vfr[i][kk] = v8{};
+            if (n < N && kk * 32 + g * 8 < D) vfr[i][kk] = *reinterpret_cast<const v8*>(base + (long)n * row3 + 2 * C + kk * 32 + g * 8);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < UPT; ++it) {
+        const int u = t + it * 256;
+        if (u < 2 * UNITS) {
+            const int arr = u >= UNITS, uu = u - arr * UNITS, tg = uu / D8, cg = uu % D8;
+            T* dst = (arr ? s_k : s_q) + (cg * 8) * TP + tg * 4;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<v4*>(dst + q * TP) = v4{r[it][0][q], r[it][1][q], r[it][2][q], r[it][3][q]};
+        }
     }
     __syncthreads();
     // ---- squared column norms (token order) and G = Q^T K on the 16-bit pipe ------------------------------------------------------------
@@ -399,22 +421,16 @@ __global__ __launch_bounds__(256, D <= 48 ? 3 : 2) void xca_tr_kernel(const T* _
         for (int i = 0; i < DT; ++i)
 #pragma unroll
             for (int kk = 0; kk < KSA; ++kk) af[i][kk] = *reinterpret_cast<const v8*>(a16 + (i * 16 + l15) * AP + kk * 32 + g * 8);
-        const int ntiles = (N + 15) >> 4;
-        for (int nt = wave; nt < ntiles; nt += 4) {
-            const int n = nt * 16 + l15;
-            v8 bf[KSA];
 #pragma unroll
-            for (int kk = 0; kk < KSA; ++kk) {
-                bf[kk] = v8{};
-                if (n < N && kk * 32 + g * 8 < D) bf[kk] = *reinterpret_cast<const v8*>(base + (long)n * row3 + 2 * C + kk * 32 + g * 8);
-            }
+        for (int vi = 0; vi < VT; ++vi) {
+            const int n = (wave + 4 * vi) * 16 + l15;
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
                 f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < KSA; ++kk) {
-                    if constexpr (std::is_same<T, _Float16>::value) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[kk], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[kk], acc, 0, 0, 0);
+                    if constexpr (std::is_same<T, _Float16>::value) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], vfr[vi][kk], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], vfr[vi][kk], acc, 0, 0, 0);
                 }
                 if (n < N) *reinterpret_cast<v4*>(out + ((long)b * N + n) * C + h * D + i * 16 + g * 4) = v4{(T)acc.x, (T)acc.y, (T)acc.z, (T)acc.w};
             }

@@ -733,8 +733,12 @@ def weight16_scaled(weight, bias, gamma, precision=None):
 
 
 def mlp_fused_ok(C, hidden, precision=None):
-    """Shape / precision envelope of mi355_mlp_fused_fwd."""
-    return _prec(precision) in (PREC_FP16, PREC_BF16) and (C, hidden) in ((64, 256), (128, 512))
+    """Shape / precision envelope of mi355_mlp_fused_fwd (round 6: C = 256 / 384 on the weight-split kernel, option "mlp_wide")."""
+    if _prec(precision) not in (PREC_FP16, PREC_BF16):
+        return False
+    if (C, hidden) in ((64, 256), (128, 512)):
+        return True
+    return (C, hidden) in ((256, 1024), (384, 1536)) and lib().mi355_get_option(b"mlp_wide") == 1
 
 
 def proj_mlp_fused_ok(C, hidden, precision=None):
@@ -771,7 +775,7 @@ def mlp_fused(x, ln, fc1, fc2, gamma=None, precision=None, ctx16=None, proj=None
     anchors = (fc1,) if ln is None else (fc1, ln)
     w1_16, b1, proven = _derived_get(anchors, ("mlp_fused_w1", p), tag, build)
     ln_flags = (0 if ln is None else 1) | (2 if proven else 0)
-    if C == 64:
+    if C != 128:                                        # C = 64 (weights resident in LDS) and C = 256 / 384 (fragments global -> VGPR): row-major
         w2_16 = weight16(fc2.weight, p)
     else:                                               # slice-major (hidden/32, C, 32): the kernel streams 32-unit slices through LDS
         w2_16 = _derived_get((fc2,), ("mlp_fused_w2", p), (fc2.weight._version, fc2.weight.data_ptr()),

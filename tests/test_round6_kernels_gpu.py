@@ -122,3 +122,80 @@ def test_xca_core_on_the_16bit_pipe_matches_the_streaming_kernel(B, N, heads, d,
     assert diff <= 2 * ulp * outs[0].float().abs().max().item(), diff
     again = F.xca_core(qkv16, temp, heads, precision=prec, out16=True)
     assert torch.equal(again, outs[1]), "run-to-run"
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("C,M,use_gamma", [(256, 50176, False), (384, 50176, True), (384, 1000, False), (256, 97, True), (384, 196 * 3 + 5, True)])
+def test_wide_fused_mlp_matches_the_reference_expression(C, M, use_gamma, prec):
+    """mlp_wide.hip (LayerNorm + fc1 + GELU + fc2 + LayerScale + residual in one kernel at C = 256 / 384) against an fp64 evaluation of
+    x + gamma * fc2(gelu(fc1(LN(x)))) (cswin.py:194-196 / xcit.py:294 with Mlp), on a ragged row count (steps that are not full, rows
+    beyond M), and against the composition it replaces (LayerNorm launch + two GEMMs, option "mlp_wide" = 0)."""
+    import torch.nn as nn
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(C + M)
+    ln = nn.LayerNorm(C)
+    fc1, fc2 = nn.Linear(C, 4 * C), nn.Linear(4 * C, C)
+    with torch.no_grad():
+        ln.weight.add_(0.2 * torch.randn(C))
+        ln.bias.add_(0.1 * torch.randn(C))
+    gamma = (0.5 + torch.rand(C)) if use_gamma else None
+    x = torch.randn(M, C) * 1.5 + 0.3
+    xd = x.double()
+    u = torch.nn.functional.layer_norm(xd, (C,), ln.weight.double(), ln.bias.double(), ln.eps)
+    h = torch.nn.functional.gelu(u @ fc1.weight.double().t() + fc1.bias.double())
+    br = h @ fc2.weight.double().t() + fc2.bias.double()
+    ref = (xd + (br * gamma.double() if use_gamma else br)).float()
+    ln, fc1, fc2 = ln.cuda(), fc1.cuda(), fc2.cuda()
+    gd = gamma.cuda() if use_gamma else None
+    xg = x.cuda()
+    tol = 1e-3 if prec == 1 else 8e-3
+    assert F.mlp_fused_ok(C, 4 * C, prec)
+    got = {}
+
+    def run():
+        got["y"] = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec)
+    tags = _tags(run)
+    assert any("mlp_wide_kernel" in t for t in tags), tags
+    y = got["y"].view(M, C)
+    assert_parity(y.cpu(), ref, tol, "mlp_wide vs fp64")
+    # the BRANCH alone (y - x): the residual must not hide an error of the MLP
+    assert_parity((y - xg).cpu(), (ref.double() - xd).float(), 2 * tol, "mlp_wide branch vs fp64")
+    again = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec).view(M, C)
+    assert torch.equal(again, y), "run-to-run"
+    # batch independence: the first rows alone give the same bits (a row's arithmetic does not depend on its step)
+    if M > 300:
+        sub = F.mlp_fused(xg[:200].contiguous().view(1, 200, C), ln, fc1, fc2, gamma=gd, precision=prec).view(200, C)
+        assert torch.equal(sub, y[:200])
+    # the composition it replaces
+    u16 = F.layernorm16(xg, ln.weight, ln.bias, ln.eps, prec)
+    h16 = F.linear16(u16, F.weight16(fc1.weight, prec), fc1.bias, act=F.ACT_GELU, out16=True, precision=prec)
+    comp = F.linear16(h16, F.weight16(fc2.weight, prec), fc2.bias, gamma=gd, resid=xg, precision=prec)
+    assert_parity(y.cpu(), comp.cpu(), tol, "mlp_wide vs LayerNorm + two GEMMs")
+
+
+def test_wide_fused_mlp_reports_a_saturating_hidden_activation():
+    """fc1 scaled so that gelu(H) passes 65504: the static proof fails on the host, the kernel tracks and reports (code 4), and module(x)
+    of a CSWin stage-3 block falls back to strict mode like the reference (cswin.py:194-196 computes in fp32)."""
+    import warnings
+    import oracle as O
+    import mi355attn
+    from mi355attn.modules import CSWinBlock
+    torch.manual_seed(1234)
+    m = CSWinBlock(256, 14, 8, split_size=7, qkv_bias=True).eval()
+    with torch.no_grad():
+        m.mlp.fc1.weight.mul_(1e5)
+        m.mlp.fc2.weight.mul_(1e-4)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(4, 196, 256)
+    ref = O.cswin_block_forward(x, sd, 14, 8, 7)
+    md = m.cuda()
+    mi355attn.range_status(wait=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            y = md(x.cuda())
+        torch.cuda.synchronize()
+    assert len([i for i in w if "strict mode" in str(i.message)]) == 1, [str(i.message) for i in w]
+    assert_parity(y.cpu(), ref, 2e-4, "CSWin s3 with a saturating hidden activation [strict re-run]")
