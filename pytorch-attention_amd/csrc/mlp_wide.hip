@@ -2,24 +2,26 @@
 // the MLP half of a CSWin stage-3 block (cswin.py:194-196) and of an XCiT-S XCABlock (xcit.py:294), gfx950.  Round 6.
 //
 // Unfused, this half is three launches -- LayerNorm, fc1 + GELU, fc2 + residual -- that move the 16-bit hidden tensor (M x 4C: 154 MB at
-// C = 384, B = 256) out to HBM and back and pay two short-K GEMM epilogues: 218 us of the 469-us XCABlock, 134 of the 265-us CSWin stage-3
+// C = 384, B = 256) out to HBM and back and pay two short-K GEMM epilogues: 224 us of the 469-us XCABlock, 134 of the 265-us CSWin stage-3
 // block (profiles/r06_*_kernel_seq.txt).  mlp_fused.hip stops at C = 128 because its waves split the TOKENS and every wave reads every
-// weight fragment from LDS.  Here the waves split the WEIGHTS:
+// weight fragment from LDS.  Here the waves split the WEIGHTS, and the two products run on DIFFERENT waves:
 //
 //   workgroup  = 8 waves, persistent, one per CU; a step = R <= 112 token rows (7 row tiles of 16; the launcher picks R so that the steps
 //                fill whole rounds: B = 256 x 196 tokens on 256 CUs = 512 steps of 98 rows);
 //   per step   : the rows are LayerNorm'ed in registers (a row per wave pass) and parked in LDS once, 16 bit (s_xn, 88 KB at C = 384);
-//   per 256 hidden units ("macro-slice"):
-//     stage 1  wave w owns hidden units [32 w, 32 w + 32) of the slice for ALL rows:  H^T = W1' . Xn^T.  Its W1' rows are needed by no other
-//              wave, so the fragments go global -> VGPR (16-byte loads along K, two k-steps ahead of their MFMAs) -- they never touch LDS;
-//              the Xn fragment a wave reads from LDS feeds two MFMAs.  + b1', GELU, 16-bit -> s_h[row][256] (59 KB).   barrier
-//     stage 2  wave w owns output channels [C/8 w, C/8 (w + 1)) for all rows:  Y^T += W2 . gelu(H)^T, W2 fragments global -> VGPR again,
-//              a gelu(H) fragment read from LDS feeds C/128 MFMAs.                                                      barrier
-//   epilogue   (+ b2) * gamma + x (re-read: L2 / Infinity-Cache resident) -> 16-byte stores of C/2-byte row segments.
-// LDS reads per step 6.7 MB against 18.8 MB for the token-split form at this width; the weights cross L2 -> CU once per step (2.36 MB at
-// C = 384), which is the kernel's floor: 512 steps x 2.36 MB = 1.2 GB at the ~10 TB/s the chip's CUs pull together.
-// LayerNorm's affine part is folded into W1 / b1 by the caller (W1' = W1 diag(ln_w), b1' = b1 + W1 ln_b); weights 16-bit (fp16 / bf16 per
-// `precision`), accumulation fp32, the hidden activation is rounded to 16 bit exactly where the unfused path rounds it.
+//   waves 0-3  PRODUCERS, per slice of 128 hidden units:  H^T = W1' . Xn^T for the wave's 32 hidden units and ALL rows.  Its W1' rows are
+//              needed by no other wave, so the fragments go global -> VGPR (16-byte loads along K, two k-steps ahead of their MFMAs) and never
+//              touch LDS; an Xn fragment read from LDS feeds two MFMAs.  + b1', GELU, 16 bit -> s_h[slice & 1][row][128];
+//   waves 4-7  CONSUMERS, one slice behind:  Y^T += W2 . gelu(H)^T for the wave's C/4 output channels and all rows, W2 fragments
+//              global -> VGPR, a gelu(H) fragment read from LDS feeds C/64 MFMAs;
+//   ONE barrier per slice hands buffer (slice & 1) over.  Every SIMD hosts one producer and one consumer wave: the GELU of slice i (VALU)
+//   runs under the second product of slice i - 1 (matrix pipe) -- the version with all eight waves in both roles (two barriers per 256
+//   hidden units, GELU between them with the matrix pipe idle) measured 242 us at C = 384 against 224 us for the three launches;
+//   epilogue   (consumers) (+ b2) * gamma + x (re-read: L2 / Infinity-Cache resident) -> 16-byte stores of C-byte row segments.
+// The weights cross L2 -> CU once per step (2.36 MB at C = 384): 512 steps x 2.36 MB = 1.2 GB at the ~10 TB/s the chip's CUs pull together
+// is the kernel's floor.  LayerNorm's affine part is folded into W1 / b1 by the caller (W1' = W1 diag(ln_w), b1' = b1 + W1 ln_b); weights
+// 16-bit (fp16 / bf16 per `precision`), accumulation fp32, the hidden activation is rounded to 16 bit exactly where the unfused path
+// rounds it.
 #include "common.h"
 #include "mma.h"
 
@@ -43,16 +45,18 @@ __global__ __launch_bounds__(512, 1) void mlp_wide_kernel(const WideArgs a) {
     using v4 = typename M_::v4;
     using el = typename M_::e;
     constexpr int HD = 4 * C, NW = 8, RT = 7, RS = RT * 16;
-    constexpr int KS = C / 32;                 // k-steps of stage 1
-    constexpr int NT = C / 128;                // 16-column output tiles per wave (stage 2)
+    constexpr int KS = C / 32;                 // k-steps of the first product
+    constexpr int NT = C / 64;                 // 16-column output tiles per consumer wave
     constexpr int NCW = NT * 16;
-    constexpr int HS = 256, NMS = HD / HS, KS2 = HS / 32;
+    constexpr int HS = 128, NSL = HD / HS, KS2 = HS / 32;
     constexpr int XP = C + 8, HP = HS + 8;     // LDS row pitches (elements)
     constexpr int FPL = C / 64;                // floats of a row per lane in the LayerNorm pass (4 or 6)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     el* s_xn = reinterpret_cast<el*>(lds);
-    el* s_h = s_xn + RS * XP;
+    el* s_h = s_xn + RS * XP;                  // two buffers of RS x HP
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+    const bool producer = wave < 4;            // wave-uniform
+    const int rw = wave & 3;                   // index inside the role
     const el* __restrict__ w1 = static_cast<const el*>(a.w1);
     const el* __restrict__ w2 = static_cast<const el*>(a.w2);
     const float invC = 1.0f / (float)C;
@@ -97,98 +101,129 @@ __global__ __launch_bounds__(512, 1) void mlp_wide_kernel(const WideArgs a) {
         }
         __syncthreads();
 
-        f4 o[RT][NT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) o[rt][ct] = f4{0.f, 0.f, 0.f, 0.f};
-
+        if (producer) {
+            // =========== H^T = W1' Xn^T, + b1', GELU -> s_h[sl & 1]: 32 hidden units per wave and slice, all rows ==========================
 #pragma unroll 1
-        for (int ms = 0; ms < NMS; ++ms) {
-            // ================= stage 1: H^T = W1' Xn^T for this wave's 32 hidden units of the slice =====================================
-            const int h0 = ms * HS + wave * 32;
-            f4 s[RT][2];
+            for (int it = 0; it <= NSL; ++it) {
+                if (it < NSL) {
+                    const int h0 = it * HS + rw * 32;
+                    f4 s[RT][2];
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const f4 bias = *reinterpret_cast<const f4*>(a.b1 + h0 + h2 * 16 + g * 4);
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const f4 bias = *reinterpret_cast<const f4*>(a.b1 + h0 + h2 * 16 + g * 4);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) s[rt][h2] = bias;
-            }
-            const el* w1p = w1 + (long)(h0 + l15) * C + g * 8;       // A fragment of hidden tile h2 at k-step ks: w1p + h2 * 16 * C + ks * 32
-            v8 wf[3][2];
+                        for (int rt = 0; rt < RT; ++rt) s[rt][h2] = bias;
+                    }
+                    const el* w1p = w1 + (long)(h0 + l15) * C + g * 8;       // A fragment of hidden tile h2 at k-step ks: + h2 * 16 * C + ks * 32
+                    v8 wf[3][2];
 #pragma unroll
-            for (int pre = 0; pre < 2; ++pre)
+                    for (int pre = 0; pre < 2; ++pre)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) wf[pre][h2] = *reinterpret_cast<const v8*>(w1p + (long)h2 * 16 * C + pre * 32);
+                        for (int h2 = 0; h2 < 2; ++h2) wf[pre][h2] = *reinterpret_cast<const v8*>(w1p + (long)h2 * 16 * C + pre * 32);
+                    // Xn fragments in a flat pipeline over (ks, rt), three reads ahead of their MFMAs
+                    v8 xf[4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 2 < KS) {
+                    for (int pre = 0; pre < 3; ++pre) xf[pre] = *reinterpret_cast<const v8*>(s_xn + (pre * 16 + l15) * XP + g * 8);
 #pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) wf[(ks + 2) % 3][h2] = *reinterpret_cast<const v8*>(w1p + (long)h2 * 16 * C + (ks + 2) * 32);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (ks + 2 < KS) {
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) wf[(ks + 2) % 3][h2] = *reinterpret_cast<const v8*>(w1p + (long)h2 * 16 * C + (ks + 2) * 32);
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int idx = ks * RT + rt, nx = idx + 3;
+                            if (nx < KS * RT)
+                                xf[nx & 3] = *reinterpret_cast<const v8*>(s_xn + ((nx % RT) * 16 + l15) * XP + (nx / RT) * 32 + g * 8);
+                            s[rt][0] = M_::mma(wf[ks % 3][0], xf[idx & 3], s[rt][0]);
+                            s[rt][1] = M_::mma(wf[ks % 3][1], xf[idx & 3], s[rt][1]);
+                        }
+                    }
+                    // GELU, 16 bit, parked row-major: lane (l15, g) holds hidden units h2 * 16 + g * 4 + [0,4) of row rt * 16 + l15
+                    el* hb = s_h + (it & 1) * (RS * HP);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const f4 p = gelu16_fast4(s[rt][h2]);
+                            if constexpr (PREC == 1) rgmax = rg_max3abs4(rgmax, p);
+                            *reinterpret_cast<v4*>(hb + (rt * 16 + l15) * HP + rw * 32 + h2 * 16 + g * 4) = M_::cvt(p);
+                        }
                 }
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const v8 xf = *reinterpret_cast<const v8*>(s_xn + (rt * 16 + l15) * XP + ks * 32 + g * 8);
-                    s[rt][0] = M_::mma(wf[ks % 3][0], xf, s[rt][0]);
-                    s[rt][1] = M_::mma(wf[ks % 3][1], xf, s[rt][1]);
-                }
+                __syncthreads();                                     // slice `it` is complete in s_h[it & 1]; the consumers are done with slice it - 2
             }
-            // the first W2 fragments of stage 2 are requested before the GELU pass, they land under it
-            const el* w2p = w2 + (long)(wave * NCW + l15) * HD + ms * HS + g * 8;     // A fragment of column tile ct at k-step k2: + ct * 16 * HD + k2 * 32
-            v8 vf[3][NT];
-#pragma unroll
-            for (int pre = 0; pre < 2; ++pre)
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) vf[pre][ct] = *reinterpret_cast<const v8*>(w2p + (long)ct * 16 * HD + pre * 32);
-            // GELU, 16 bit, parked row-major: lane (l15, g) holds hidden units h2 * 16 + g * 4 + [0,4) of row rt * 16 + l15
+        } else {
+            // =========== Y^T += W2 gelu(H)^T, one slice behind the producers: C/4 output channels per wave, all rows ==========================
+            f4 o[RT][NT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f4 p = gelu16_fast4(s[rt][h2]);
-                    if constexpr (PREC == 1) rgmax = rg_max3abs4(rgmax, p);
-                    *reinterpret_cast<v4*>(s_h + (rt * 16 + l15) * HP + wave * 32 + h2 * 16 + g * 4) = M_::cvt(p);
-                }
-            __syncthreads();                                         // (A) gelu(H) of the slice complete
-            // ================= stage 2: Y^T += W2 gelu(H)^T for this wave's C/8 output channels ==============================================
+                for (int ct = 0; ct < NT; ++ct) o[rt][ct] = f4{0.f, 0.f, 0.f, 0.f};
+            const el* w2p = w2 + (long)(rw * NCW + l15) * HD + g * 8;        // A fragment of column tile ct at hidden offset hoff: + ct * 16 * HD + hoff
+            v8 vcur[NT], vnxt[NT];
 #pragma unroll
-            for (int k2 = 0; k2 < KS2; ++k2) {
-                if (k2 + 2 < KS2) {
+            for (int ct = 0; ct < NT; ++ct) vcur[ct] = *reinterpret_cast<const v8*>(w2p + (long)ct * 16 * HD);
+            __syncthreads();                                         // it = 0: nothing to consume yet
+#pragma unroll 1
+            for (int sl = 0; sl < NSL; ++sl) {
+                const el* hb = s_h + (sl & 1) * (RS * HP) + l15 * HP + g * 8;
+                // gelu(H) fragments: a pipeline over (k2, rt), two reads ahead of their MFMAs, rotated through three registers
+                v8 p0 = *reinterpret_cast<const v8*>(hb), p1 = *reinterpret_cast<const v8*>(hb + 16 * HP), p2;
+#pragma unroll 1
+                for (int k2 = 0; k2 < KS2; ++k2) {
+                    // the W2 fragments of the next k-step (of the next slice behind the last one) are requested a k-step ahead
+                    const int hoff = sl * HS + (k2 + 1) * 32;        // == (sl + 1) * HS when k2 + 1 == KS2
+                    if (hoff < HD) {
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) vf[(k2 + 2) % 3][ct] = *reinterpret_cast<const v8*>(w2p + (long)ct * 16 * HD + (k2 + 2) * 32);
+                        for (int ct = 0; ct < NT; ++ct) vnxt[ct] = *reinterpret_cast<const v8*>(w2p + (long)ct * 16 * HD + hoff);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int nrt = (rt + 2) % RT, dk = (rt + 2) / RT;          // compile-time
+                        if (dk == 0 || k2 + 1 < KS2) p2 = *reinterpret_cast<const v8*>(hb + nrt * 16 * HP + (k2 + dk) * 32);
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) o[rt][ct] = M_::mma(vcur[ct], p0, o[rt][ct]);
+                        p0 = p1; p1 = p2;
+                        __builtin_amdgcn_sched_barrier(0);           // keep the reads two ahead, not seven: the accumulators leave no room
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) vcur[ct] = vnxt[ct];
                 }
+                __syncthreads();
+            }
+            // ---- epilogue: (+ b2) * gamma + x -> y; lane (l15, g) holds channels rw * NCW + ct * 16 + g * 4 + [0,4) of row rt * 16 + l15.
+            //      The residual rows of two column tiles are requested together (one exposed L2 round trip per pair) ---------------------------
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                f4 xr[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    const v8 pf = *reinterpret_cast<const v8*>(s_h + (rt * 16 + l15) * HP + k2 * 32 + g * 8);
-#pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) o[rt][ct] = M_::mma(vf[k2 % 3][ct], pf, o[rt][ct]);
+                    const int r = rt * 16 + l15;
+                    xr[rt] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (r < rows) xr[rt] = *reinterpret_cast<const f4*>(a.x + (row0 + r) * C + rw * NCW + ct * 16 + g * 4);
                 }
-            }
-            __syncthreads();                                         // (B) everybody is done reading s_h (and, after the last slice, s_xn)
-        }
-        // ---- epilogue: (+ b2) * gamma + x -> y; lane (l15, g) holds channels wave * NCW + ct * 16 + g * 4 + [0,4) of row rt * 16 + l15 ---------
+                const int c0 = rw * NCW + ct * 16 + g * 4;
+                const f4 b2 = a.b2 ? *reinterpret_cast<const f4*>(a.b2 + c0) : f4{0.f, 0.f, 0.f, 0.f};
+                const f4 gm = a.gamma ? *reinterpret_cast<const f4*>(a.gamma + c0) : f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const int c0 = wave * NCW + ct * 16 + g * 4;
-            const f4 b2 = a.b2 ? *reinterpret_cast<const f4*>(a.b2 + c0) : f4{0.f, 0.f, 0.f, 0.f};
-            const f4 gm = a.gamma ? *reinterpret_cast<const f4*>(a.gamma + c0) : f4{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int r = rt * 16 + l15;
-                if (r < rows) {
-                    const long off = (row0 + r) * C + c0;
-                    f4 v = o[rt][ct] + b2;
-                    if (a.gamma) v = v * gm;
-                    *reinterpret_cast<f4*>(a.y + off) = v + *reinterpret_cast<const f4*>(a.x + off);
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r = rt * 16 + l15;
+                    if (r < rows) {
+                        f4 v = o[rt][ct] + b2;
+                        if (a.gamma) v = v * gm;
+                        *reinterpret_cast<f4*>(a.y + (row0 + r) * C + c0) = v + xr[rt];
+                    }
                 }
             }
         }
+        // the next step's LayerNorm overwrites s_xn: the producers' last read of it lies in front of the last slice barrier, which every wave
+        // has passed; s_h[0] is written again only behind the barrier that follows that LayerNorm
     }
     if constexpr (PREC == 1) rg_report_f(rgmax, a.ovf, 4u);
 }
 
 template <int C>
-constexpr size_t wide_smem() { return (size_t)112 * (C + 8) * 2 + (size_t)112 * (256 + 8) * 2; }
+constexpr size_t wide_smem() { return (size_t)112 * (C + 8) * 2 + (size_t)2 * 112 * (128 + 8) * 2; }
 
 }  // namespace
 
