@@ -142,10 +142,13 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   (fp32 accumulation; the products of 16-bit operands are exact in fp32) from one transposed LDS image of q and k
  *                   (xca_tr_kernel); 0 = the token-streaming kernel with exact-fp32 MFMAs on fp32 copies (any N; differs at the 1e-7 level:
  *                   the summation order inside the matrix instruction).
- *   "mlp_wide"      1 (default) = mi355_mlp_fused_fwd also takes C = 256 and C = 384 with hidden = 4 C (CSWin stage 3, XCiT-S: mlp_wide.hip -- the
- *                   eight waves of a persistent workgroup split the WEIGHTS, whose fragments go global -> VGPR, the token rows are LayerNorm'ed into
- *                   LDS once per 98-row step and gelu(H) passes through LDS 256 hidden units at a time); 0 = those shapes are MI355_EUNSUPPORTED
- *                   and the host mirror composes LayerNorm + two GEMMs as before.
+ *   "mlp_wide"      1 = mi355_mlp_fused_fwd also takes C = 256 and C = 384 with hidden = 4 C (CSWin stage 3, XCiT-S: mlp_wide.hip -- producer waves
+ *                   form gelu(W1' LN(x) + b1') 128 hidden units at a time, consumer waves the second product one slice behind, weight fragments go
+ *                   global -> VGPR, the token rows are LayerNorm'ed into LDS once per 98-row step); 0 (default) = those shapes are
+ *                   MI355_EUNSUPPORTED and the host mirror composes LayerNorm + two GEMMs.  Built, parity-tested and measured in round 6: 257 us
+ *                   against 224 us for the three launches at C = 384, 157 against 137 at C = 256 (profiles/r06_mlp_wide.md: with 98 rows per
+ *                   step every weight byte is used for 98 rows, the 256 x 128 GEMM tiles use it for 256 -- the fused kernel pulls as many bytes
+ *                   from L2 as the two GEMMs and cannot hold more rows' accumulators), hence opt-in.
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.

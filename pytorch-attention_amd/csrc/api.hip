@@ -55,7 +55,8 @@ static const OptDesc kOpts[O_COUNT] = {
     {"range_fallback", 1, 0, 1},           // host policy of the drop-in modules (read by the binding): 1 = a forward whose fp16 operands saturated is re-run in strict mode, 0 = raise on the next call
     {"gemm_wreg", 1, 0, 1},                // fp32 (+ residual) outputs with N = K = 256 / 384: weight-stationary-in-registers streaming kernel (gemm16_wreg.hip)
     {"xca_tr", 1, 0, 1},                   // XCA core with 16-bit q / k / v and N <= 224: covariance on the 16-bit matrix pipe from one transposed LDS image (xcit.hip xca_tr_kernel)
-    {"mlp_wide", 1, 0, 1},                 // mi355_mlp_fused_fwd takes C = 256 / 384 (hidden 4C) on the weight-split kernel (mlp_wide.hip); 0 = MI355_EUNSUPPORTED as before round 6
+    {"mlp_wide", 0, 0, 1},                 // 1 = mi355_mlp_fused_fwd takes C = 256 / 384 (hidden 4C) on the weight-split kernel (mlp_wide.hip); measured SLOWER than LayerNorm + two GEMMs
+                                           // (profiles/r06_mlp_wide.md), hence opt-in; 0 (default) = those shapes are MI355_EUNSUPPORTED
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {

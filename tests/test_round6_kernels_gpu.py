@@ -150,22 +150,27 @@ def test_wide_fused_mlp_matches_the_reference_expression(C, M, use_gamma, prec):
     gd = gamma.cuda() if use_gamma else None
     xg = x.cuda()
     tol = 1e-3 if prec == 1 else 8e-3
-    assert F.mlp_fused_ok(C, 4 * C, prec)
-    got = {}
+    assert not F.mlp_fused_ok(C, 4 * C, prec), "opt-in: measured slower than the composition (profiles/r06_mlp_wide.md)"
+    mi355attn.set_option("mlp_wide", 1)
+    try:
+        assert F.mlp_fused_ok(C, 4 * C, prec)
+        got = {}
 
-    def run():
-        got["y"] = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec)
-    tags = _tags(run)
-    assert any("mlp_wide_kernel" in t for t in tags), tags
-    y = got["y"].view(M, C)
+        def run():
+            got["y"] = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec)
+        tags = _tags(run)
+        assert any("mlp_wide_kernel" in t for t in tags), tags
+        y = got["y"].view(M, C)
+        again = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec).view(M, C)
+        sub = F.mlp_fused(xg[:200].contiguous().view(1, 200, C), ln, fc1, fc2, gamma=gd, precision=prec).view(200, C) if M > 300 else None
+    finally:
+        mi355attn.set_option("mlp_wide", 0)
     assert_parity(y.cpu(), ref, tol, "mlp_wide vs fp64")
     # the BRANCH alone (y - x): the residual must not hide an error of the MLP
     assert_parity((y - xg).cpu(), (ref.double() - xd).float(), 2 * tol, "mlp_wide branch vs fp64")
-    again = F.mlp_fused(xg.view(1, M, C), ln, fc1, fc2, gamma=gd, precision=prec).view(M, C)
     assert torch.equal(again, y), "run-to-run"
     # batch independence: the first rows alone give the same bits (a row's arithmetic does not depend on its step)
-    if M > 300:
-        sub = F.mlp_fused(xg[:200].contiguous().view(1, 200, C), ln, fc1, fc2, gamma=gd, precision=prec).view(200, C)
+    if sub is not None:
         assert torch.equal(sub, y[:200])
     # the composition it replaces
     u16 = F.layernorm16(xg, ln.weight, ln.bias, ln.eps, prec)
@@ -192,10 +197,16 @@ def test_wide_fused_mlp_reports_a_saturating_hidden_activation():
     ref = O.cswin_block_forward(x, sd, 14, 8, 7)
     md = m.cuda()
     mi355attn.range_status(wait=True)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        with torch.no_grad():
-            y = md(x.cuda())
-        torch.cuda.synchronize()
-    assert len([i for i in w if "strict mode" in str(i.message)]) == 1, [str(i.message) for i in w]
+    mi355attn.set_option("mlp_wide", 1)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                tags = _tags(lambda: md(x.cuda()))
+                y = md(x.cuda())
+            torch.cuda.synchronize()
+    finally:
+        mi355attn.set_option("mlp_wide", 0)
+    assert any("mlp_wide_kernel" in t for t in tags), tags
+    assert len([i for i in w if "strict mode" in str(i.message)]) == 2, [str(i.message) for i in w]      # two forwards, each falls back
     assert_parity(y.cpu(), ref, 2e-4, "CSWin s3 with a saturating hidden activation [strict re-run]")
