@@ -420,6 +420,12 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
  * mi355_linear16_fwd only where the split does not apply; with it the fp32 summation order over K changes (covered by the same
  * tolerance).  ws may be NULL / too small: identical to mi355_linear16_fwd. */
 size_t mi355_linear16_workspace_bytes(int M, int N, int K);
+/* Y = resid + X16 W16^T + bias (fp32) AND the LayerNorm statistics of every row of Y: row_stats[2 m] = mean, row_stats[2 m + 1] =
+ * 1 / sqrt(var + eps) (two-pass, biased variance -- what mi355_ln_lpi_fwd computes with a pass of its own).  Built where a workgroup owns
+ * whole output rows: N = K = 256 / 384, M >= 4096 (the weight-stationary kernel, option "gemm_wreg"); other shapes MI355_EUNSUPPORTED.
+ * XCABlock (xcit.py:290-293): the proj GEMM writes x1 = x + gamma1 * XCA(..) and the statistics norm3 needs in front of LPI. */
+int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K, int ldx,
+                             int ldy, int precision, float* row_stats, float eps, mi355_stream_t stream);
 int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
                           int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, void* ws, size_t ws_bytes,
                           mi355_stream_t stream);
@@ -678,6 +684,12 @@ size_t mi355_mixer_token_mlp_workspace_bytes(int B, int N, int C);
 size_t mi355_cswin_lepe_attn_workspace_bytes(int B, int reso, int Ctot);
 size_t mi355_xca_workspace_bytes(int B, int N, int heads, int d);
 size_t mi355_layernorm_workspace_bytes(int rows, int cols);
+
+/* mi355_ln_lpi_fwd with the LayerNorm statistics given (stats (B*H*W, 2) from mi355_linear16_stats_fwd): no statistics pass, no workspace. */
+int mi355_ln_lpi_stats_fwd(const float* x, const float* stats, const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                           const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, const float* w2,
+                           const float* b2, const float* gamma, const float* resid, float* y, int B, int H, int W, int C,
+                           mi355_stream_t stream);
 
 int mi355_comm_unique_id(void* id_out, size_t id_bytes);
 int mi355_comm_init(const void* id, size_t id_bytes, int rank, int world, void** comm_out);

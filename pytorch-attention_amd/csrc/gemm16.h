@@ -24,6 +24,10 @@ struct G16Args {
     void* lnc_a; int lnc_lda; float* lnc_stats; const float* lnc_c;
     // ... CONSUMER side -- gemm16_p8 16-bit outputs only:  Y = act(rowtau[m].x * acc + rowtau[m].y * colsum[n] + bias[n])
     const float* rowtau; const float* colsum;
+    // gemm16_wreg only (round 6): beside Y the kernel writes the LayerNorm statistics of every OUTPUT row, row_stats[2 m] = mean,
+    // row_stats[2 m + 1] = 1 / sqrt(var + ln_eps) (two-pass, biased variance: the expression of ln_stats_kernel) -- the rows are complete
+    // inside one workgroup there, so the statistics pass over Y that the next block would launch (XCABlock: norm3 in front of LPI) is free
+    float* row_stats;
 };
 
 template <typename T> struct Vec8;

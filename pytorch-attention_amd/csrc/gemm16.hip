@@ -465,6 +465,24 @@ int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, c
     return mi355::linear16_dispatch(g, out16, precision, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
+int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K, int ldx,
+                             int ldy, int precision, float* row_stats, float eps, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X16 && W16 && resid && Y && row_stats && M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!aligned16(X16) || !aligned16(W16) || !aligned16(Y) || !aligned16(resid) || (bias && !aligned16(bias)) || !mi355::opt_gemm_wreg())
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear16_stats_fwd: 16-byte aligned buffers and option gemm_wreg = 1 required");
+    G16Args g{};
+    g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = MI355_ACT_NONE;
+    g.row_stats = row_stats; g.ln_eps = eps;
+    const int rc = mi355::gemm16_wreg(g, 0, precision, static_cast<hipStream_t>(stream));
+    if (rc == MI355_EUNSUPPORTED)
+        return mi355::fail(rc, "mi355_linear16_stats_fwd: built for N = K = 256 / 384, M >= 4096 (got M=%d N=%d K=%d): use mi355_linear16_fwd and a statistics pass", M, N, K);
+    if (rc != MI355_OK) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
 }  // extern "C"
 
 // Kernel choice of mi355_linear16_ws_fwd on a checked argument block (also the product of the patch embedding, gemm.hip, which

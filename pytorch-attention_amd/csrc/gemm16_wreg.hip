@@ -22,7 +22,7 @@ namespace {
 
 using namespace g16;
 
-template <typename T, int K, int NT, bool RESID>
+template <typename T, int K, int NT, bool RESID, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
     using v8 = typename Vec8<T>::t;
     constexpr int NW = 8, NTHR = 512, RT = 2, ROWS = RT * 16;
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
     constexpr int CH = ROWS * (K / 8);            // 16-byte chunks of a row tile
     constexpr int NLD = (CH + NTHR - 1) / NTHR;   // chunks per thread
     __shared__ __attribute__((aligned(16))) unsigned short s_x[2][ROWS * XP];
+    __shared__ float s_part[STATS ? 2 : 1][NW][ROWS];      // STATS: per-wave partial row sums, then partial sums of squared deviations
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, gq = lane >> 4;
     const T* __restrict__ A = static_cast<const T*>(g.A);
@@ -126,16 +127,60 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
         if (next < ntile) commit(buf ^ 1);
         // ---- epilogue: (acc + bias) + resid, 16-byte stores -----------------------------------------------------------------------------
         const rsrc_t ry = make_rsrc(Y + r0 * g.ldc, ybytes);
+        float rsum[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+            rsum[rt] = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f4 v = acc[rt][nt] + bias4[nt];
                 if constexpr (RESID) v = v + rr[rt][nt];
+                if constexpr (STATS) { acc[rt][nt] = v; rsum[rt] += (v.x + v.y) + (v.z + v.w); }
                 const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ldc + n0 + nt * 16 + gq * 4) * 4);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ry, off, 0, 0);
             }
-        __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf]
+        }
+        if constexpr (STATS) {
+            // LayerNorm statistics of the rows just written (two-pass): lane (l15, gq) holds NCW / 4 values of row rt * 16 + l15; the four
+            // quarter-row groups of a wave are folded with two xor-shuffles, the eight waves through LDS in wave order (fixed: reproducible)
+            const float invN = 1.0f / (float)N;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float s = rsum[rt];
+                s += __shfl_xor(s, 16, WAVE);
+                s += __shfl_xor(s, 32, WAVE);
+                if (gq == 0) s_part[0][wave][rt * 16 + l15] = s;
+            }
+            __syncthreads();
+            float mean[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += s_part[0][w][rt * 16 + l15];
+                mean[rt] = s * invN;
+                float q = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f4 d = acc[rt][nt] - mean[rt];
+                    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+                q += __shfl_xor(q, 16, WAVE);
+                q += __shfl_xor(q, 32, WAVE);
+                if (gq == 0) s_part[STATS ? 1 : 0][wave][rt * 16 + l15] = q;
+            }
+            __syncthreads();
+            if (wave == 0 && lane < ROWS && lane < rows) {
+                float q = 0.f, s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { q += s_part[STATS ? 1 : 0][w][lane]; s += s_part[0][w][lane]; }
+                float2 st;
+                st.x = s * invN;
+                st.y = 1.0f / sqrtf(q * invN + g.ln_eps);
+                *reinterpret_cast<float2*>(g.row_stats + (r0 + lane) * 2) = st;
+            }
+        }
+        __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf] (and s_part)
         buf ^= 1;
     }
 }
@@ -147,6 +192,7 @@ namespace mi355 {
 // MI355_EUNSUPPORTED (nothing launched) unless the shape is one of the square short products this schedule is built for.
 int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
     if (out16 || g.act != MI355_ACT_NONE || g.gamma || g.resid_period || g.lnc_a || g.rowtau) return MI355_EUNSUPPORTED;
+    if (g.row_stats && (!g.resid || (reinterpret_cast<uintptr_t>(g.row_stats) & 7))) return MI355_EUNSUPPORTED;
     if (!(g.N == g.K && (g.K == 256 || g.K == 384))) return MI355_EUNSUPPORTED;
     if (g.M < 4096 || (g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || g.ldb < g.K) return MI355_EUNSUPPORTED;
     if ((long)32 * g.ldc * 4 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
@@ -154,10 +200,11 @@ int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
     const long ntile = ((long)g.M + 31) / 32;
     const int ncu = resident_slots(1);
     const int grid = (int)(ntile < ncu ? ntile : ncu);
-    MI355_TRACE(st, "gemm16_wreg_kernel<%s,%s> M=%d N=%d K=%d", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.resid ? "resid" : "plain", g.M, g.N, g.K);
+    MI355_TRACE(st, "gemm16_wreg_kernel<%s,%s> M=%d N=%d K=%d", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.row_stats ? "resid+stats" : (g.resid ? "resid" : "plain"), g.M, g.N, g.K);
 #define GO(T_, K_, NT_)                                                                  \
     do {                                                                                 \
-        if (g.resid) gemm16_wreg_kernel<T_, K_, NT_, true><<<grid, 512, 0, st>>>(g);     \
+        if (g.row_stats) gemm16_wreg_kernel<T_, K_, NT_, true, true><<<grid, 512, 0, st>>>(g);    \
+        else if (g.resid) gemm16_wreg_kernel<T_, K_, NT_, true><<<grid, 512, 0, st>>>(g);     \
         else         gemm16_wreg_kernel<T_, K_, NT_, false><<<grid, 512, 0, st>>>(g);    \
     } while (0)
     if (precision == MI355_PREC_FP16) { if (g.K == 384) GO(_Float16, 384, 3); else GO(_Float16, 256, 2); }

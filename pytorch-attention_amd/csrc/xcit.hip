@@ -879,4 +879,16 @@ int mi355_ln_lpi_fwd(const float* x, const float* ln_w, const float* ln_b, float
     return lpi_launch(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, B, H, W, C, stats, ln_w, ln_b, st);
 }
 
+// The same with the LayerNorm statistics GIVEN: stats (B*H*W, 2) = (mean, 1 / sqrt(var + eps)) per token, as written by
+// mi355_linear16_stats_fwd beside the tensor x (XCABlock: the proj GEMM in front of this block writes them for free).
+int mi355_ln_lpi_stats_fwd(const float* x, const float* stats, const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                           const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, const float* w2,
+                           const float* b2, const float* gamma, const float* resid, float* y, int B, int H, int W, int C,
+                           mi355_stream_t stream) {
+    MI355_CHECK_ARG(x && stats && ln_w && ln_b && w1 && b1 && bn_w && bn_b && bn_mean && bn_var && w2 && b2 && y);
+    MI355_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && aligned16(x));
+    return lpi_launch(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, gamma, resid, y, B, H, W, C, stats, ln_w, ln_b,
+                      static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -852,6 +852,26 @@ def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=Fa
     return y
 
 
+def linear16_stats(x16, w16, bias, resid, eps, precision=None):
+    """(Y, stats) with Y = resid + x16 @ w16^T + bias (fp32) and stats (rows, 2) = (mean, 1 / sqrt(var + eps)) of every row of Y -- the
+    LayerNorm statistics the next block needs, written by the GEMM that owns whole rows (mi355_linear16_stats_fwd: N = K = 256 / 384).
+    Returns None where the entry is not built for the shape (the caller then runs linear16 and lets the consumer compute its statistics)."""
+    _range_check()
+    p = _prec(precision)
+    x16 = _require16(x16, "x16", p)
+    w16 = _require16(w16, "w16", p)
+    N, K = w16.shape
+    M = x16.numel() // K
+    if not (N == K and K in (256, 384) and M >= 4096 and resid is not None and lib().mi355_get_option(b"gemm_wreg") == 1):
+        return None
+    bias, resid = _opt(bias, "bias"), require_device_f32(resid, "resid")
+    y = torch.empty(x16.shape[:-1] + (N,), dtype=torch.float32, device=x16.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x16.device)
+    check(lib().mi355_linear16_stats_fwd(dptr(x16), dptr(w16), dptr(bias), dptr(resid), dptr(y), M, N, K, K, N, p, dptr(stats), float(eps),
+                                         stream_ptr(x16.device)), "mi355_linear16_stats_fwd")
+    return y, stats
+
+
 def layernorm16_t(x, weight, bias, eps=1e-5, NP=None, precision=None):
     """LayerNorm over C of x (B, N, C), written transposed per image in 16 bit: (B, C, NP), zeros for n >= N."""
     x = require_device_f32(x, "x")
@@ -1128,7 +1148,7 @@ def xca_core(qkv, temperature, num_heads, precision=None, out16=False):
     return out
 
 
-def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None, resid=None, ln=None):
+def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None, resid=None, ln=None, stats=None):
     """XCiT LPI on tokens x (B,N,C) with eval-mode BatchNorm; optional fused `resid + gamma * LPI(x)`.  `ln` (an nn.LayerNorm): the
     block becomes resid + gamma * LPI(ln(x)) with the normalisation applied on the way into the stencil kernel (mi355_ln_lpi_fwd)."""
     x = require_device_f32(x, "x")
@@ -1143,6 +1163,15 @@ def lpi(x, w1, b1, bn_w, bn_b, bn_mean, bn_var, bn_eps, w2, b2, H, W, gamma=None
     y = torch.empty_like(x)
     n = lib().mi355_lpi_workspace_bytes(B, H, W, C)
     ws = workspace(n, x.device)
+    if ln is not None and stats is not None:              # `stats`: (mean, rstd) per token, written by the GEMM that produced x (linear16_stats)
+        lw, lb = require_device_f32(ln.weight, "ln.weight"), require_device_f32(ln.bias, "ln.bias")
+        stats = require_device_f32(stats, "stats")
+        if stats.numel() != B * N * 2:
+            raise ValueError("lpi: stats must hold (mean, rstd) for every token")
+        check(lib().mi355_ln_lpi_stats_fwd(dptr(x), dptr(stats), dptr(lw), dptr(lb), *[dptr(a) for a in pre], float(bn_eps),
+                                           *[dptr(a) for a in post], dptr(gamma), dptr(resid), dptr(y), B, H, W, C, stream_ptr(x.device)),
+              "mi355_ln_lpi_stats_fwd")
+        return y
     if ln is not None:
         lw, lb = require_device_f32(ln.weight, "ln.weight"), require_device_f32(ln.bias, "ln.bias")
         check(lib().mi355_ln_lpi_fwd(dptr(x), dptr(lw), dptr(lb), float(ln.eps), *[dptr(a) for a in pre], float(bn_eps),

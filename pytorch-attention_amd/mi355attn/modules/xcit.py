@@ -51,11 +51,12 @@ class LPI(nn.Module):
         self.bn = nn.BatchNorm2d(in_features)
         self.conv2 = nn.Conv2d(in_features, out_features, kernel_size=3, padding=1, groups=out_features)
 
-    def forward(self, x, H, W, gamma=None, resid=None, ln=None):
-        """`ln`: the LayerNorm in front of the block (XCABlock passes norm3 with the un-normalised x): fused into the kernel."""
+    def forward(self, x, H, W, gamma=None, resid=None, ln=None, stats=None):
+        """`ln`: the LayerNorm in front of the block (XCABlock passes norm3 with the un-normalised x): fused into the kernel.  `stats`: that
+        LayerNorm's (mean, rstd) per token when the producer of x has already written them (XCA's proj GEMM)."""
         bn = self.bn
         return F.lpi(x, self.conv1.weight, self.conv1.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                     self.conv2.weight, self.conv2.bias, H, W, gamma=gamma, resid=resid, ln=ln)
+                     self.conv2.weight, self.conv2.bias, H, W, gamma=gamma, resid=resid, ln=ln, stats=stats)
 
 
 class XCA(nn.Module):
@@ -70,10 +71,13 @@ class XCA(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.precision = precision
 
-    def forward(self, x, gamma=None, resid=None, ln=None):
+    def forward(self, x, gamma=None, resid=None, ln=None, stats_eps=None):
         """`ln`: the LayerNorm in front of the block (XCABlock passes norm1 with the un-normalised x) -- applied on the way into the qkv
-        GEMM when the width allows (functional.ln_linear16), else by the caller."""
+        GEMM when the width allows (functional.ln_linear16), else by the caller.  `stats_eps` (round 6): the caller wants the LayerNorm
+        statistics of the OUTPUT rows (eps of the LayerNorm that follows: XCABlock's norm3) -- the return value is then (y, stats) with
+        stats None where the projection kernel does not own whole rows."""
         _dropout_is_identity(self)
+        want_stats = stats_eps is not None
         if _fast(self.precision, self.qkv, self.proj):
             p = F._prec(self.precision)      # GEMMs on 16-bit operands; the d x d covariance core itself is exact fp32
             if ln is not None:
@@ -85,12 +89,19 @@ class XCA(nn.Module):
             folded = F.weight16_scaled(self.proj.weight, self.proj.bias, gamma, p) if gamma is not None else None
             if folded is not None:                            # LayerScale folded into the projection (no activation in between)
                 w16, b = folded
-                return F.linear16(ctx16, w16, b, resid=resid, precision=p)
+                if want_stats and resid is not None:
+                    got = F.linear16_stats(ctx16, w16, b, resid, stats_eps, p)
+                    if got is not None:
+                        return got
+                y = F.linear16(ctx16, w16, b, resid=resid, precision=p)
+                return (y, None) if want_stats else y
             # no LayerScale, or gamma * W would leave the fp16 normal range (eta = 1e-5 initialisations): gamma in the fp32 epilogue
-            return F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid, precision=p)
+            y = F.linear16(ctx16, F.weight16(self.proj.weight, p), self.proj.bias, gamma=gamma, resid=resid, precision=p)
+            return (y, None) if want_stats else y
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias, precision=self.precision)
         ctx = F.xca_core(qkv, self.temperature, self.num_heads, precision=self.precision)
-        return F.linear(ctx, self.proj.weight, self.proj.bias, gamma=gamma, resid=resid, precision=self.precision)
+        y = F.linear(ctx, self.proj.weight, self.proj.bias, gamma=gamma, resid=resid, precision=self.precision)
+        return (y, None) if want_stats else y
 
 
 class XCABlock(nn.Module):
@@ -122,11 +133,12 @@ class XCABlock(nn.Module):
                 return F.layernorm16(t, ln.weight, ln.bias, ln.eps, p)
             return F.layernorm(t, ln.weight, ln.bias, ln.eps)
 
+        # the proj GEMM of the attention branch writes norm3's statistics of x beside x where it owns whole rows (gemm16_wreg, round 6)
         if fast and F.ln_linear16_ok(x.shape[-1], 3 * x.shape[-1], p):
-            x = self.attn(x, gamma=self.gamma1, resid=x, ln=self.norm1)               # LayerNorm fused into the qkv GEMM
+            x, st = self.attn(x, gamma=self.gamma1, resid=x, ln=self.norm1, stats_eps=self.norm3.eps)   # LayerNorm fused into the qkv GEMM
         else:
-            x = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x)
-        x = self.local_mp(x, H, W, gamma=self.gamma3, resid=x, ln=self.norm3)          # norm3 fused into the LPI kernel
+            x, st = self.attn(norm(self.norm1, x, fast), gamma=self.gamma1, resid=x, stats_eps=self.norm3.eps)
+        x = self.local_mp(x, H, W, gamma=self.gamma3, resid=x, ln=self.norm3, stats=st)   # norm3 fused into the LPI kernel
         if fast and F.mlp_fused_ok(x.shape[-1], self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
             return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, gamma=self.gamma2, precision=p)   # LN2 + MLP + LayerScale + residual
         return self.mlp(norm(self.norm2, x, fast), gamma=self.gamma2, resid=x)

@@ -210,3 +210,56 @@ def test_wide_fused_mlp_reports_a_saturating_hidden_activation():
     assert any("mlp_wide_kernel" in t for t in tags), tags
     assert len([i for i in w if "strict mode" in str(i.message)]) == 2, [str(i.message) for i in w]      # two forwards, each falls back
     assert_parity(y.cpu(), ref, 2e-4, "CSWin s3 with a saturating hidden activation [strict re-run]")
+
+
+@pytest.mark.parametrize("M,K", [(50176, 384), (4096 + 21, 256)])
+def test_weight_stationary_gemm_writes_the_row_statistics_of_its_output(M, K):
+    """mi355_linear16_stats_fwd: Y is bit-identical to the plain kernel and stats = (mean, 1 / sqrt(var + eps)) of every row of Y (two-pass,
+    biased variance) -- what XCABlock's norm3 needs in front of LPI (xcit.py:292), without the statistics pass over Y."""
+    from mi355attn import functional as F
+    torch.manual_seed(M + K)
+    x16 = F.cast16(torch.randn(M, K, device="cuda"), 1)
+    w16 = F.cast16((torch.randn(K, K, device="cuda") / K ** 0.5).contiguous(), 1)
+    b = torch.randn(K, device="cuda")
+    r = torch.randn(M, K, device="cuda") * 2.0 + 0.7
+    plain = F.linear16(x16, w16, b, resid=r, precision=1)
+    got = F.linear16_stats(x16, w16, b, r, 1e-6, 1)
+    assert got is not None
+    y, st = got
+    torch.cuda.synchronize()
+    assert torch.equal(y, plain)
+    yd = y.double()
+    mean = yd.mean(dim=1)
+    rstd = 1.0 / torch.sqrt(yd.var(dim=1, unbiased=False) + 1e-6)
+    assert float((st[:, 0].double() - mean).abs().max()) <= 2e-6 * float(yd.abs().max())
+    assert float(((st[:, 1].double() - rstd) / rstd).abs().max()) <= 5e-6
+    y2, st2 = F.linear16_stats(x16, w16, b, r, 1e-6, 1)
+    assert torch.equal(st2, st) and torch.equal(y2, y), "run-to-run"
+    assert F.linear16_stats(x16[:, :K], F.cast16(torch.randn(128, K, device="cuda"), 1), None, torch.randn(M, 128, device="cuda"), 1e-6, 1) is None
+
+
+def test_xcablock_uses_the_statistics_of_the_proj_gemm():
+    """XCABlock at the XCiT-S width: no ln_stats_kernel launch any more, the result still matches the oracle and the launch without the
+    fold (option gemm_wreg = 0) to rounding."""
+    import oracle as O
+    import mi355attn
+    from mi355attn.modules import XCABlock
+    torch.manual_seed(1234)
+    m = XCABlock(384, 8, qkv_bias=True, eta=1.0).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(24, 196, 384)
+    ref = O.xca_block_forward(x, sd, 8, 14, 14)
+    md, xd = m.cuda(), x.cuda()
+    out = {}
+    with torch.no_grad():
+        tags = _tags(lambda: out.__setitem__("y", md(xd, 14, 14)))
+        mi355attn.set_option("gemm_wreg", 0)
+        try:
+            tags0 = _tags(lambda: out.__setitem__("y0", md(xd, 14, 14)))
+        finally:
+            mi355attn.set_option("gemm_wreg", 1)
+    assert any("resid+stats" in t for t in tags) and not any("ln_stats_kernel" in t for t in tags), tags
+    assert any("ln_stats_kernel" in t for t in tags0), tags0
+    assert_parity(out["y"].cpu(), ref, 1e-3, "XCABlock with the statistics fold")
+    assert_parity(out["y"].cpu(), out["y0"].cpu(), 2e-5, "fold vs statistics pass")
