@@ -134,7 +134,7 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "ln_fold"       1 = the ViT encoder chain of the host mirror folds its LayerNorms into the neighbouring GEMMs
  *                   (mi355_linear16_emit_fwd / mi355_ln_finalize_fwd / mi355_linear16_lnfold_fwd); 0 (default) = one LayerNorm launch
  *                   each.  Measured in round 4: the fold costs more in the GEMM epilogues than the 36 us launches it removes.
- *   "gemm_wreg"     1 (default) = fp32 (+ residual) outputs of square short products, N = K = 256 or 384, M >= 4096, no activation / LayerScale
+ *   "gemm_wreg"     1 (default) = fp32 (+ residual) outputs of square short products, N = K = 256 or 384, M >= 32, no activation / LayerScale
  *                   (XCiT's proj, CSWin stage-3 proj) run the weight-stationary-in-registers streaming kernel (gemm16_wreg.hip: eight waves, each
  *                   holds its N / 8 columns of W as MFMA fragments for the whole kernel; X, residual and Y cross HBM once).  Bit-identical
  *                   results; 0 = the tile kernels as before.
@@ -422,7 +422,7 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
 size_t mi355_linear16_workspace_bytes(int M, int N, int K);
 /* Y = resid + X16 W16^T + bias (fp32) AND the LayerNorm statistics of every row of Y: row_stats[2 m] = mean, row_stats[2 m + 1] =
  * 1 / sqrt(var + eps) (two-pass, biased variance -- what mi355_ln_lpi_fwd computes with a pass of its own).  Built where a workgroup owns
- * whole output rows: N = K = 256 / 384, M >= 4096 (the weight-stationary kernel, option "gemm_wreg"); other shapes MI355_EUNSUPPORTED.
+ * whole output rows: N = K = 256 / 384, M >= 32 (the weight-stationary kernel, option "gemm_wreg"); other shapes MI355_EUNSUPPORTED.
  * XCABlock (xcit.py:290-293): the proj GEMM writes x1 = x + gamma1 * XCA(..) and the statistics norm3 needs in front of LPI. */
 int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K, int ldx,
                              int ldy, int precision, float* row_stats, float eps, mi355_stream_t stream);

@@ -477,7 +477,7 @@ int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias
     g.row_stats = row_stats; g.ln_eps = eps;
     const int rc = mi355::gemm16_wreg(g, 0, precision, static_cast<hipStream_t>(stream));
     if (rc == MI355_EUNSUPPORTED)
-        return mi355::fail(rc, "mi355_linear16_stats_fwd: built for N = K = 256 / 384, M >= 4096 (got M=%d N=%d K=%d): use mi355_linear16_fwd and a statistics pass", M, N, K);
+        return mi355::fail(rc, "mi355_linear16_stats_fwd: built for N = K = 256 / 384, M >= 32 (got M=%d N=%d K=%d): use mi355_linear16_fwd and a statistics pass", M, N, K);
     if (rc != MI355_OK) return rc;
     MI355_LAUNCH_CHECK();
     return MI355_OK;

@@ -194,7 +194,7 @@ int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
     if (out16 || g.act != MI355_ACT_NONE || g.gamma || g.resid_period || g.lnc_a || g.rowtau) return MI355_EUNSUPPORTED;
     if (g.row_stats && (!g.resid || (reinterpret_cast<uintptr_t>(g.row_stats) & 7))) return MI355_EUNSUPPORTED;
     if (!(g.N == g.K && (g.K == 256 || g.K == 384))) return MI355_EUNSUPPORTED;
-    if (g.M < 4096 || (g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || g.ldb < g.K) return MI355_EUNSUPPORTED;
+    if (g.M < 32 || (g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || g.ldb < g.K) return MI355_EUNSUPPORTED;
     if ((long)32 * g.ldc * 4 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
     if (precision != MI355_PREC_FP16 && precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;
     const long ntile = ((long)g.M + 31) / 32;

@@ -862,7 +862,7 @@ def linear16_stats(x16, w16, bias, resid, eps, precision=None):
     w16 = _require16(w16, "w16", p)
     N, K = w16.shape
     M = x16.numel() // K
-    if not (N == K and K in (256, 384) and M >= 4096 and resid is not None and lib().mi355_get_option(b"gemm_wreg") == 1):
+    if not (N == K and K in (256, 384) and M >= 32 and resid is not None and lib().mi355_get_option(b"gemm_wreg") == 1):
         return None
     bias, resid = _opt(bias, "bias"), require_device_f32(resid, "resid")
     y = torch.empty(x16.shape[:-1] + (N,), dtype=torch.float32, device=x16.device)

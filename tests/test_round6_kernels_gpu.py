@@ -19,7 +19,7 @@ def _tags(fn):
 
 @pytest.mark.parametrize("prec", [1, 2])
 @pytest.mark.parametrize("M,K,resid,bias", [(50176, 384, True, True), (50176, 256, True, True), (4096 + 37, 384, True, False),
-                                            (8192 + 16, 256, False, True), (12544, 384, False, False)])
+                                            (8192 + 16, 256, False, True), (12544, 384, False, False), (392, 384, True, True), (40, 256, True, False)])
 def test_weight_stationary_gemm_is_bit_identical_to_the_tile_kernels(M, K, resid, bias, prec):
     import mi355attn
     from mi355attn import functional as F
@@ -212,7 +212,7 @@ def test_wide_fused_mlp_reports_a_saturating_hidden_activation():
     assert_parity(y.cpu(), ref, 2e-4, "CSWin s3 with a saturating hidden activation [strict re-run]")
 
 
-@pytest.mark.parametrize("M,K", [(50176, 384), (4096 + 21, 256)])
+@pytest.mark.parametrize("M,K", [(50176, 384), (4096 + 21, 256), (588, 384), (33, 256)])
 def test_weight_stationary_gemm_writes_the_row_statistics_of_its_output(M, K):
     """mi355_linear16_stats_fwd: Y is bit-identical to the plain kernel and stats = (mean, 1 / sqrt(var + eps)) of every row of Y (two-pass,
     biased variance) -- what XCABlock's norm3 needs in front of LPI (xcit.py:292), without the statistics pass over Y."""
@@ -262,4 +262,4 @@ def test_xcablock_uses_the_statistics_of_the_proj_gemm():
     assert any("resid+stats" in t for t in tags) and not any("ln_stats_kernel" in t for t in tags), tags
     assert any("ln_stats_kernel" in t for t in tags0), tags0
     assert_parity(out["y"].cpu(), ref, 1e-3, "XCABlock with the statistics fold")
-    assert_parity(out["y"].cpu(), out["y0"].cpu(), 2e-5, "fold vs statistics pass")
+    assert_parity(out["y"].cpu(), out["y0"].cpu(), 1e-4, "fold vs statistics pass")
