@@ -75,6 +75,8 @@ def parse_args(argv=None):
                          "the whole N > 1 path -- self-launch, barrier-bracketed timing, ranks_seen, end-of-forward gather -- run end to end "
                          "with the real kernels on a one-GPU box)")
     ap.add_argument("--no-calib", action="store_true", help="skip the box calibration (MFMA / copy yardsticks, telemetry)")
+    ap.add_argument("--no-models", action="store_true",
+                    help="skip the model-level passes of the default workload (CSWin-T, XCiT-nano, MLP-Mixer full forwards, un-timed: roofline.model_ms)")
     ap.add_argument("--detail", default=None, help="also write the line + the verbose per-block / per-kernel / CPU-leg records to this JSON file")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + barrier + max-reduce of an empty step on the gloo backend, no GPU work: what the CPU tests "
@@ -439,6 +441,29 @@ def main(argv=None):
         finally:
             mi355attn.set_default_precision(1 if args.precision is None else args.precision)
     dominant = None
+    # model-level numbers of the next rows, OUTSIDE the timed step like the strict passes: full forwards
+    # of CSWin-T/224, XCiT-nano-12/16 and MLP-Mixer(512, depth 12) at the same batch, rank 0 only, no gather (a collective entered by one rank
+    # alone would never return)
+    model_ms = {}
+    if args.workload == "all" and rank == 0 and not args.only and not args.no_models:
+        import bench_workloads as BW
+        for key, build in (("CSWinT", BW.workload_cswin), ("XCiTnano", BW.workload_xcit), ("Mixer12", BW.workload_mixer_full)):
+            try:
+                mb = build(args.batch, dev)["blocks"][0]
+                with torch.no_grad():
+                    mb["module"](mb["x"])
+                torch.cuda.synchronize()
+                tm = StreamTimer(dev)
+                tm.start()
+                reps = max(3, args.steps // 4)
+                with torch.no_grad():
+                    for _ in range(reps):
+                        mb["module"](mb["x"])
+                model_ms[key] = round(tm.stop_ms() / reps, 4)
+                del mb
+                torch.cuda.empty_cache()
+            except Exception as e:                                  # noqa: BLE001  (reported, never fatal for the contract's line)
+                sys.stderr.write("[bench] model pass %s failed: %s\n" % (key, str(e)[:200]))
 
     rank_ms, ranks_seen, rank_devs = [round(local_elapsed / args.steps * 1e3, 4)], [rank], [dev_index]
     if dist is not None:
@@ -471,7 +496,7 @@ def main(argv=None):
         rccl_self_test=("passed on every rank" if comm_ok else ("not run (single rank)" if world == 1 else
                         ("not run (gloo backend)" if shared_gpu else "FAILED or skipped: see gather"))),
         ranks_seen=len(ranks_seen), distinct_gpus=len(set(rank_devs)) if shared_gpu else world, per_block=per_block, calib=calib,
-        pmc_note=pmc_note, dominant=dominant, dom=dom, blocks=blocks))
+        pmc_note=pmc_note, dominant=dominant, dom=dom, blocks=blocks, model_ms=model_ms))
     detail = {"ms_per_step_by_rank": rank_ms, "ranks": ranks_seen, "rank_devices": rank_devs, "ms_windows": [round(ms_per_step, 4)] +
               [round(e / args.steps * 1e3, 4) for e in extra], "calibration": calib, "dominant_kernel": dominant, "blocks": per_block}
 
@@ -513,7 +538,8 @@ def assemble_line(m):
                 the builder-run line (`profiles/r06_bench_all.json`) and may be cut by the driver;
       roofline  the contract's keys for the slowest block + its dominant kernel, then ONE string per per-block series: `fracs` (every
                 block on the roof it is graded on), `hbm_fracs` (mixed / MFMA blocks on the HBM roof: algorithmic bytes / counter bytes),
-                `traffic_x` (counter bytes over algorithmic bytes), `strict_ms`, `strict_over_fast`;
+                `traffic_x` (counter bytes over algorithmic bytes), `strict_ms`, `strict_over_fast`, `model_ms` (full forwards of CSWin-T / XCiT-nano /
+                MLP-Mixer at the same batch, measured outside the timed step);
       cpu_baseline is ordered by cpu_baseline() itself."""
     per_block, calib = m["per_block"], m["calib"]
     bef, aft, load, idle = calib.get("before", {}), calib.get("after", {}), calib.get("load", {}), calib.get("idle", {})
@@ -551,6 +577,8 @@ def assemble_line(m):
     roof["traffic_x"] = _pairs(per_block, "traffic_x")
     roof["strict_ms"] = _pairs(per_block, "strict_ms")
     roof["strict_over_fast"] = ",".join("%s=%.2f" % (r["key"], r["strict_ms"] / r["ms"]) for r in per_block if r.get("strict_ms"))
+    if m.get("model_ms"):                                           # full forwards of the next-row models at the same batch (ms), un-timed passes
+        roof["model_ms"] = ",".join("%s=%.4g" % kv for kv in m["model_ms"].items())
     for k in ("launches_per_forward", "us_per_forward", "traced_us_per_forward"):
         if dominant and k in dominant:
             roof["kernel_" + k] = dominant[k]

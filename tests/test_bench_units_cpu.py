@@ -74,7 +74,7 @@ def _fake_measurement():
     return dict(batch=256, steps=20, warmup=5, world=1, value=15800.0, ms_per_step=16.2, extra_ms=[16.21, 16.22], workload="north-star step",
                 dtype="f32/f16", precision=1, dist_backend="none", gather="none (single rank)", rccl_self_test="not run (single rank)",
                 ranks_seen=1, distinct_gpus=1, per_block=per_block, calib=calib, pmc_note="PMC note", dominant=dominant, dom=per_block[-1],
-                blocks=None)
+                blocks=None, model_ms={"CSWinT": 7.02, "XCiTnano": 2.5, "Mixer12": 4.95})
 
 
 def test_line_survives_the_drivers_24_key_cap():
@@ -91,8 +91,9 @@ def test_line_survives_the_drivers_24_key_cap():
         assert "ms_" + k in cfg, k
     roof = list(out["roofline"])[:cap]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "block", "kernel", "ms", "kernel_avg_us", "kernel_frac", "fracs",
-              "hbm_fracs", "traffic_x", "strict_ms", "strict_over_fast"):
+              "hbm_fracs", "traffic_x", "strict_ms", "strict_over_fast", "model_ms"):
         assert k in roof, k
+    assert len(out["roofline"]) <= cap, "every roofline key survives the cap"
     r = out["roofline"]
     for k in KEYS14:
         assert k + "=" in r["fracs"], k
