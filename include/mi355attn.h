@@ -426,6 +426,13 @@ size_t mi355_linear16_workspace_bytes(int M, int N, int K);
  * XCABlock (xcit.py:290-293): the proj GEMM writes x1 = x + gamma1 * XCA(..) and the statistics norm3 needs in front of LPI. */
 int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, int M, int N, int K, int ldx,
                              int ldy, int precision, float* row_stats, float eps, mi355_stream_t stream);
+/* Y = resid + X16 W16^T + bias (fp32) AND the next LayerNorm of every row of Y in the 16-bit operand format:
+ * U16[m][n] = T((Y[m][n] - mean_m) / sqrt(var_m + eps) * ln_w[n] + ln_b[n]) (row stride ldu elements) -- what mi355_layernorm16_fwd would
+ * compute from Y with a launch and a pass of its own.  Built at N = K = 256, M >= 32 (other shapes MI355_EUNSUPPORTED).  CSWinBlock at stage 3 (cswin.py:192-194):
+ * x = x + proj(att) and norm2(x) in one launch.  The fp16 conversions report into the range word (code 2). */
+int mi355_linear16_ln16_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, const float* ln_w,
+                            const float* ln_b, float eps, void* U16, int M, int N, int K, int ldx, int ldy, int ldu, int precision,
+                            mi355_stream_t stream);
 int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y,
                           int M, int N, int K, int ldx, int ldy, int act, int out16, int precision, void* ws, size_t ws_bytes,
                           mi355_stream_t stream);

@@ -28,6 +28,10 @@ struct G16Args {
     // row_stats[2 m + 1] = 1 / sqrt(var + ln_eps) (two-pass, biased variance: the expression of ln_stats_kernel) -- the rows are complete
     // inside one workgroup there, so the statistics pass over Y that the next block would launch (XCABlock: norm3 in front of LPI) is free
     float* row_stats;
+    // ... or, instead, the NEXT LayerNorm applied to the output rows and written in the operand format (16-bit, row stride ln16_ld):
+    //   ln16_out[m][n] = T( (Y[m][n] - mean_m) * rstd_m * ln16_w[n] + ln16_b[n] )  -- the expression of layernorm_kernel; CSWin stage 3:
+    // proj + residual and norm2 in one launch (cswin.py:192-194).  ovf (above) receives the fp16 range report of these conversions (code 2).
+    void* ln16_out; const float* ln16_w; const float* ln16_b; int ln16_ld;
 };
 
 template <typename T> struct Vec8;

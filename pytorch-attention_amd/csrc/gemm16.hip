@@ -483,6 +483,27 @@ int mi355_linear16_stats_fwd(const void* X16, const void* W16, const float* bias
     return MI355_OK;
 }
 
+int mi355_linear16_ln16_fwd(const void* X16, const void* W16, const float* bias, const float* resid, float* Y, const float* ln_w,
+                            const float* ln_b, float eps, void* U16, int M, int N, int K, int ldx, int ldy, int ldu, int precision,
+                            mi355_stream_t stream) {
+    MI355_CHECK_ARG(X16 && W16 && resid && Y && ln_w && ln_b && U16 && M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldu >= N);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!aligned16(X16) || !aligned16(W16) || !aligned16(Y) || !aligned16(resid) || (bias && !aligned16(bias)) || !mi355::opt_gemm_wreg())
+        return mi355::fail(MI355_EUNSUPPORTED, "mi355_linear16_ln16_fwd: 16-byte aligned buffers and option gemm_wreg = 1 required");
+    G16Args g{};
+    g.A = X16; g.B = W16; g.C = Y; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = MI355_ACT_NONE;
+    g.ln16_out = U16; g.ln16_w = ln_w; g.ln16_b = ln_b; g.ln16_ld = ldu; g.ln_eps = eps;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == MI355_PREC_FP16) g.ovf = mi355::range_word(st);                // U16 is an fp16 operand tensor: a producer
+    const int rc = mi355::gemm16_wreg(g, 0, precision, st);
+    if (rc == MI355_EUNSUPPORTED)
+        return mi355::fail(rc, "mi355_linear16_ln16_fwd: built for N = K = 256 / 384, M >= 32 (got M=%d N=%d K=%d): use mi355_linear16_fwd + mi355_layernorm16_fwd", M, N, K);
+    if (rc != MI355_OK) return rc;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
 }  // extern "C"
 
 // Kernel choice of mi355_linear16_ws_fwd on a checked argument block (also the product of the patch embedding, gemm.hip, which

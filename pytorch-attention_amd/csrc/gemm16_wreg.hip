@@ -17,12 +17,13 @@
 // gemm16_p8 / gemm16_pa on these shapes (tests/test_round6_kernels_gpu.py).
 #include "gemm16.h"
 #include "bufops.h"
+#include <type_traits>
 
 namespace {
 
 using namespace g16;
 
-template <typename T, int K, int NT, bool RESID, bool STATS = false>
+template <typename T, int K, int NT, bool RESID, int STATS = 0>       // STATS: 0 none, 1 row statistics, 2 LayerNorm'ed 16-bit copy
 __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
     using v8 = typename Vec8<T>::t;
     constexpr int NW = 8, NTHR = 512, RT = 2, ROWS = RT * 16;
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
     for (int nt = 0; nt < NT; ++nt)
         bias4[nt] = g.bias ? *reinterpret_cast<const f4*>(g.bias + n0 + nt * 16 + gq * 4) : f4{0.f, 0.f, 0.f, 0.f};
 
+    float rgmax = 0.f;
     const long ntile = ((long)g.M + ROWS - 1) / ROWS;
     // chunk c of a row tile: row c / (K/8), 8 elements at column (c % (K/8)) * 8
     int crow[NLD], ccol[NLD];
@@ -170,19 +172,45 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
                 if (gq == 0) s_part[STATS ? 1 : 0][wave][rt * 16 + l15] = q;
             }
             __syncthreads();
-            if (wave == 0 && lane < ROWS && lane < rows) {
-                float q = 0.f, s = 0.f;
+            if constexpr (STATS == 1) {
+                if (wave == 0 && lane < ROWS && lane < rows) {
+                    float q = 0.f, s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { q += s_part[STATS ? 1 : 0][w][lane]; s += s_part[0][w][lane]; }
-                float2 st;
-                st.x = s * invN;
-                st.y = 1.0f / sqrtf(q * invN + g.ln_eps);
-                *reinterpret_cast<float2*>(g.row_stats + (r0 + lane) * 2) = st;
+                    for (int w = 0; w < NW; ++w) { q += s_part[1][w][lane]; s += s_part[0][w][lane]; }
+                    float2 st;
+                    st.x = s * invN;
+                    st.y = 1.0f / sqrtf(q * invN + g.ln_eps);
+                    *reinterpret_cast<float2*>(g.row_stats + (r0 + lane) * 2) = st;
+                }
+            } else {
+                // the next LayerNorm, applied to the values this lane still holds: (v - mean) * rstd * w + b -> 16 bit, 8-byte stores
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                const rsrc_t ru = make_rsrc(static_cast<T*>(g.ln16_out) + r0 * g.ln16_ld, (bufops_u32)(((long)(rows - 1) * g.ln16_ld + N) * 2));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) q += s_part[1][w][rt * 16 + l15];
+                    const float rstd = 1.0f / sqrtf(q * invN + g.ln_eps);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        // the affine vectors are re-read per tile (L2 hits): kept for the kernel's lifetime they cost 24 VGPRs the K = 384
+                        // instantiation does not have (104 B of scratch)
+                        const f4 lw = *reinterpret_cast<const f4*>(g.ln16_w + n0 + nt * 16 + gq * 4);
+                        const f4 lb = *reinterpret_cast<const f4*>(g.ln16_b + n0 + nt * 16 + gq * 4);
+                        const f4 o = (acc[rt][nt] - mean[rt]) * rstd * lw + lb;
+                        if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4_f(rgmax, o);
+                        const t4 h = t4{(T)o.x, (T)o.y, (T)o.z, (T)o.w};
+                        const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ln16_ld + n0 + nt * 16 + gq * 4) * 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, h), ru, off, 0, 0);
+                    }
+                }
             }
         }
         __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf] (and s_part)
         buf ^= 1;
     }
+    if constexpr (STATS == 2 && std::is_same<T, _Float16>::value) rg_report_f(rgmax, g.ovf, 2u);
 }
 
 }  // namespace
@@ -193,6 +221,10 @@ namespace mi355 {
 int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
     if (out16 || g.act != MI355_ACT_NONE || g.gamma || g.resid_period || g.lnc_a || g.rowtau) return MI355_EUNSUPPORTED;
     if (g.row_stats && (!g.resid || (reinterpret_cast<uintptr_t>(g.row_stats) & 7))) return MI355_EUNSUPPORTED;
+    if (g.ln16_out && g.K != 256) return MI355_EUNSUPPORTED;      // the LayerNorm-emitting epilogue is built at N = K = 256 (at 384 it would spill: 256 VGPRs + 20 B)
+    if (g.ln16_out && (!g.resid || g.row_stats || !g.ln16_w || !g.ln16_b || !aligned16(g.ln16_w) || !aligned16(g.ln16_b) || !aligned16(g.ln16_out) ||
+                       (g.ln16_ld & 3) || g.ln16_ld < g.N))
+        return MI355_EUNSUPPORTED;
     if (!(g.N == g.K && (g.K == 256 || g.K == 384))) return MI355_EUNSUPPORTED;
     if (g.M < 32 || (g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || g.ldb < g.K) return MI355_EUNSUPPORTED;
     if ((long)32 * g.ldc * 4 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
@@ -200,10 +232,11 @@ int gemm16_wreg(const G16Args& g, int out16, int precision, hipStream_t st) {
     const long ntile = ((long)g.M + 31) / 32;
     const int ncu = resident_slots(1);
     const int grid = (int)(ntile < ncu ? ntile : ncu);
-    MI355_TRACE(st, "gemm16_wreg_kernel<%s,%s> M=%d N=%d K=%d", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.row_stats ? "resid+stats" : (g.resid ? "resid" : "plain"), g.M, g.N, g.K);
+    MI355_TRACE(st, "gemm16_wreg_kernel<%s,%s> M=%d N=%d K=%d", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.ln16_out ? "resid+ln16" : (g.row_stats ? "resid+stats" : (g.resid ? "resid" : "plain")), g.M, g.N, g.K);
 #define GO(T_, K_, NT_)                                                                  \
     do {                                                                                 \
-        if (g.row_stats) gemm16_wreg_kernel<T_, K_, NT_, true, true><<<grid, 512, 0, st>>>(g);    \
+        if (g.ln16_out) { if constexpr (K_ == 256) gemm16_wreg_kernel<T_, K_, NT_, true, 2><<<grid, 512, 0, st>>>(g); }   \
+        else if (g.row_stats) gemm16_wreg_kernel<T_, K_, NT_, true, 1><<<grid, 512, 0, st>>>(g);   \
         else if (g.resid) gemm16_wreg_kernel<T_, K_, NT_, true><<<grid, 512, 0, st>>>(g);     \
         else         gemm16_wreg_kernel<T_, K_, NT_, false><<<grid, 512, 0, st>>>(g);    \
     } while (0)

@@ -133,6 +133,7 @@ SIGNATURES = {
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
     "mi355_linear16_stats_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp, c_float, c_vp]),
+    "mi355_linear16_ln16_fwd": (c_int, [c_vp] * 7 + [c_float, c_vp] + [c_int] * 7 + [c_vp]),
     "mi355_ln_lpi_stats_fwd": (c_int, [c_vp] * 10 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp]),
     # SURVEY.md 8(b) spellings: aliases of mi355_sdpa_fwd / mi355_linear_fwd / mi355_mixer_token_fwd and the zero-byte workspace queries
     "mi355_sdpa_core_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_int, c_vp]),

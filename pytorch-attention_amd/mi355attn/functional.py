@@ -872,6 +872,27 @@ def linear16_stats(x16, w16, bias, resid, eps, precision=None):
     return y, stats
 
 
+def linear16_ln16(x16, w16, bias, resid, ln, precision=None):
+    """(Y, U16): Y = resid + x16 @ w16^T + bias (fp32) and U16 = ln(Y) in the 16-bit operand format, one launch (mi355_linear16_ln16_fwd:
+    N = K = 256; the projection + residual and the LayerNorm in front of the MLP of a CSWin stage-3 block, cswin.py:192-194).
+    Returns None where the entry is not built for the shape."""
+    _range_check()
+    p = _prec(precision)
+    x16 = _require16(x16, "x16", p)
+    w16 = _require16(w16, "w16", p)
+    N, K = w16.shape
+    M = x16.numel() // K
+    if not (N == K and K == 256 and M >= 32 and resid is not None and lib().mi355_get_option(b"gemm_wreg") == 1):
+        return None
+    bias, resid = _opt(bias, "bias"), require_device_f32(resid, "resid")
+    lw, lb = require_device_f32(ln.weight, "ln.weight"), require_device_f32(ln.bias, "ln.bias")
+    y = torch.empty(x16.shape[:-1] + (N,), dtype=torch.float32, device=x16.device)
+    u = torch.empty(x16.shape[:-1] + (N,), dtype=dtype16(p), device=x16.device)
+    check(lib().mi355_linear16_ln16_fwd(dptr(x16), dptr(w16), dptr(bias), dptr(resid), dptr(y), dptr(lw), dptr(lb), float(ln.eps), dptr(u),
+                                        M, N, K, K, N, N, p, stream_ptr(x16.device)), "mi355_linear16_ln16_fwd")
+    return y, u
+
+
 def layernorm16_t(x, weight, bias, eps=1e-5, NP=None, precision=None):
     """LayerNorm over C of x (B, N, C), written transposed per image in 16 bit: (B, C, NP), zeros for n >= N."""
     x = require_device_f32(x, "x")

@@ -126,8 +126,15 @@ class CSWinBlock(nn.Module):
             if F.proj_mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
                 # proj + residual + LN2 + fc1 + GELU + fc2 + residual in one launch: x1 never reaches HBM
                 return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=p, ctx16=att, proj=self.proj)
+            fused_mlp = F.mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None
+            if not fused_mlp:
+                # stage 3 (C = 256): the proj GEMM owns whole rows, so it also writes norm2(x) in the operand format (round 6: no LayerNorm launch)
+                got = F.linear16_ln16(att, F.weight16(self.proj.weight, p), self.proj.bias, x, self.norm2, p)
+                if got is not None:
+                    x, u = got
+                    return self.mlp(u, resid=x)
             x = F.linear16(att, F.weight16(self.proj.weight, p), self.proj.bias, resid=x, precision=p)
-            if F.mlp_fused_ok(C, self.mlp.fc1.weight.shape[0], p) and self.mlp.fc1.bias is not None:
+            if fused_mlp:
                 return F.mlp_fused(x, self.norm2, self.mlp.fc1, self.mlp.fc2, precision=p)      # LN2 + fc1 + GELU + fc2 + residual
             u = F.layernorm16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
         else:

@@ -263,3 +263,57 @@ def test_xcablock_uses_the_statistics_of_the_proj_gemm():
     assert any("ln_stats_kernel" in t for t in tags0), tags0
     assert_parity(out["y"].cpu(), ref, 1e-3, "XCABlock with the statistics fold")
     assert_parity(out["y"].cpu(), out["y0"].cpu(), 1e-4, "fold vs statistics pass")
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M", [50176, 588, 40])
+def test_weight_stationary_gemm_emits_the_next_layernorm(M, prec):
+    """mi355_linear16_ln16_fwd (N = K = 256: CSWin stage 3, cswin.py:192-194): Y bit-identical to the plain kernel, U16 = LayerNorm(Y) in the
+    operand format against an fp64 evaluation and against mi355_layernorm16_fwd on the same Y (one unit of the operand type apart at most)."""
+    import torch.nn as nn
+    from mi355attn import functional as F
+    K = 256
+    torch.manual_seed(M + prec)
+    x16 = F.cast16(torch.randn(M, K, device="cuda"), prec)
+    w16 = F.cast16((torch.randn(K, K, device="cuda") / K ** 0.5).contiguous(), prec)
+    b = torch.randn(K, device="cuda")
+    r = torch.randn(M, K, device="cuda") * 1.5 - 0.4
+    ln = nn.LayerNorm(K).cuda()
+    with torch.no_grad():
+        ln.weight.add_(0.3 * torch.randn(K, device="cuda"))
+        ln.bias.add_(0.2 * torch.randn(K, device="cuda"))
+    plain = F.linear16(x16, w16, b, resid=r, precision=prec)
+    got = {}
+    tags = _tags(lambda: got.__setitem__("r", F.linear16_ln16(x16, w16, b, r, ln, prec)))
+    assert any("resid+ln16" in t for t in tags), tags
+    y, u = got["r"]
+    torch.cuda.synchronize()
+    assert torch.equal(y, plain)
+    ref = torch.nn.functional.layer_norm(y.double(), (K,), ln.weight.double(), ln.bias.double(), ln.eps).float()
+    tol = 1e-3 if prec == 1 else 8e-3
+    assert_parity(u.float().cpu(), ref.cpu(), tol, "emitted LayerNorm vs fp64")
+    u0 = F.layernorm16(y, ln.weight, ln.bias, ln.eps, prec)
+    ulp = 2.0 ** -10 if prec == 1 else 2.0 ** -7
+    assert float((u.float() - u0.float()).abs().max()) <= 2 * ulp * float(u0.float().abs().max())
+    y2, u2 = F.linear16_ln16(x16, w16, b, r, ln, prec)
+    assert torch.equal(u2, u) and torch.equal(y2, y), "run-to-run"
+    if M > 300:                                                        # batch independence
+        ys, us = F.linear16_ln16(x16[:200].contiguous(), w16, b, r[:200].contiguous(), ln, prec)
+        assert torch.equal(us, u[:200]) and torch.equal(ys, y[:200])
+
+
+def test_cswin_stage3_block_has_no_second_layernorm_launch():
+    import oracle as O
+    from mi355attn.modules import CSWinBlock
+    torch.manual_seed(1234)
+    m = CSWinBlock(256, 14, 8, split_size=7, qkv_bias=True).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(8, 196, 256)
+    ref = O.cswin_block_forward(x, sd, 14, 8, 7)
+    md, xd = m.cuda(), x.cuda()
+    out = {}
+    with torch.no_grad():
+        tags = _tags(lambda: out.__setitem__("y", md(xd)))
+    assert sum("layernorm" in t for t in tags) == 1 and any("resid+ln16" in t for t in tags), tags
+    assert_parity(out["y"].cpu(), ref, 1e-3, "CSWin s3 with norm2 emitted by the proj GEMM")
