@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
     constexpr int CH = ROWS * (K / 8);            // 16-byte chunks of a row tile
     constexpr int NLD = (CH + NTHR - 1) / NTHR;   // chunks per thread
     __shared__ __attribute__((aligned(16))) unsigned short s_x[2][ROWS * XP];
-    __shared__ float s_part[STATS ? 2 : 1][NW][ROWS];      // STATS: per-wave partial row sums, then partial sums of squared deviations
+    __shared__ float s_part[STATS ? 2 : 1][2][NW][ROWS];   // STATS: per-wave partial (mean, M2) of the tile's rows, double-buffered by tile parity
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, gq = lane >> 4;
     const T* __restrict__ A = static_cast<const T*>(g.A);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
         commit(0);
     }
     __syncthreads();
-    int buf = 0;
+    int buf = 0, tile_par = 0;
     for (; tile < ntile; tile += gridDim.x) {
         const long r0 = tile * ROWS;
         const long left = (long)g.M - r0;
@@ -129,58 +129,77 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
         if (next < ntile) commit(buf ^ 1);
         // ---- epilogue: (acc + bias) + resid, 16-byte stores -----------------------------------------------------------------------------
         const rsrc_t ry = make_rsrc(Y + r0 * g.ldc, ybytes);
-        float rsum[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            rsum[rt] = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f4 v = acc[rt][nt] + bias4[nt];
                 if constexpr (RESID) v = v + rr[rt][nt];
-                if constexpr (STATS) { acc[rt][nt] = v; rsum[rt] += (v.x + v.y) + (v.z + v.w); }
+                if constexpr (STATS != 0) acc[rt][nt] = v;
                 const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ldc + n0 + nt * 16 + gq * 4) * 4);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v), ry, off, 0, 0);
             }
         }
-        if constexpr (STATS) {
-            // LayerNorm statistics of the rows just written (two-pass): lane (l15, gq) holds NCW / 4 values of row rt * 16 + l15; the four
-            // quarter-row groups of a wave are folded with two xor-shuffles, the eight waves through LDS in wave order (fixed: reproducible)
-            const float invN = 1.0f / (float)N;
+        if constexpr (STATS != 0) {
+            // LayerNorm statistics of the rows just written WITHOUT a second workgroup barrier: every lane forms (mean, M2 = sum of squared
+            // deviations) of its own NCW / 4 values exactly (two passes over registers), partials are merged pairwise with the parallel-variance
+            // update  mean = mean_a + d n_b / n,  M2 = M2_a + M2_b + d^2 n_a n_b / n,  d = mean_b - mean_a  -- across the four quarter-row
+            // lane groups by two xor-shuffles, across the eight waves through LDS in wave order (fixed order: reproducible, and as robust as
+            // the two-pass form against |mean| >> std).  The exchange area is double-buffered by tile parity, so the tile's ONE barrier
+            // (the one the X double buffer needs anyway) also publishes the partials.
+            constexpr float NL = (float)(NT * 4);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                float s = rsum[rt];
-                s += __shfl_xor(s, 16, WAVE);
-                s += __shfl_xor(s, 32, WAVE);
-                if (gq == 0) s_part[0][wave][rt * 16 + l15] = s;
-            }
-            __syncthreads();
-            float mean[RT];
+                float sum = 0.f;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) s += s_part[0][w][rt * 16 + l15];
-                mean[rt] = s * invN;
-                float q = 0.f;
+                for (int nt = 0; nt < NT; ++nt) sum += (acc[rt][nt].x + acc[rt][nt].y) + (acc[rt][nt].z + acc[rt][nt].w);
+                float m = sum * (1.0f / NL), q = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const f4 d = acc[rt][nt] - mean[rt];
+                    const f4 d = acc[rt][nt] - m;
                     q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
                 }
-                q += __shfl_xor(q, 16, WAVE);
-                q += __shfl_xor(q, 32, WAVE);
-                if (gq == 0) s_part[STATS ? 1 : 0][wave][rt * 16 + l15] = q;
-            }
-            __syncthreads();
-            if constexpr (STATS == 1) {
-                if (wave == 0 && lane < ROWS && lane < rows) {
-                    float q = 0.f, s = 0.f;
+                float n = NL;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) { q += s_part[1][w][lane]; s += s_part[0][w][lane]; }
-                    float2 st;
-                    st.x = s * invN;
-                    st.y = 1.0f / sqrtf(q * invN + g.ln_eps);
-                    *reinterpret_cast<float2*>(g.row_stats + (r0 + lane) * 2) = st;
+                for (int sh = 16; sh <= 32; sh <<= 1) {               // equal counts on both sides: mean = (a + b) / 2, M2 += d^2 n / 2
+                    const float mo = __shfl_xor(m, sh, WAVE), qo = __shfl_xor(q, sh, WAVE);
+                    const float d = mo - m;
+                    q = (q + qo) + d * d * (n * 0.5f);
+                    m = 0.5f * (m + mo);                               // symmetric in the two partners: both lanes get the same bits
+                    n *= 2.0f;
+                }
+                if (gq == 0) { s_part[tile_par][0][wave][rt * 16 + l15] = m; s_part[tile_par][1][wave][rt * 16 + l15] = q; }
+            }
+        }
+        __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf]; partials published
+        if constexpr (STATS != 0) {
+            constexpr float NWV = (float)NCW;          // values behind one wave's partial
+            const float invN = 1.0f / (float)N;
+            float mean[RT], rstd[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float m = s_part[tile_par][0][0][rt * 16 + l15], q = s_part[tile_par][1][0][rt * 16 + l15], n = NWV;
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const float mb = s_part[tile_par][0][w][rt * 16 + l15], qb = s_part[tile_par][1][w][rt * 16 + l15];
+                    const float d = mb - m, nn = n + NWV;
+                    q = (q + qb) + d * d * (n * NWV / nn);
+                    m = m + d * (NWV / nn);
+                    n = nn;
+                }
+                mean[rt] = m;
+                rstd[rt] = 1.0f / sqrtf(q * invN + g.ln_eps);
+            }
+            if constexpr (STATS == 1) {
+                if (gq == 0) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (wave == rt && rt * 16 + l15 < rows) {        // wave rt writes the 16 rows of row tile rt: one 8-byte store per row
+                            float2 st;
+                            st.x = mean[rt]; st.y = rstd[rt];
+                            *reinterpret_cast<float2*>(g.row_stats + (r0 + rt * 16 + l15) * 2) = st;
+                        }
+                    }
                 }
             } else {
                 // the next LayerNorm, applied to the values this lane still holds: (v - mean) * rstd * w + b -> 16 bit, 8-byte stores
@@ -188,17 +207,12 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
                 const rsrc_t ru = make_rsrc(static_cast<T*>(g.ln16_out) + r0 * g.ln16_ld, (bufops_u32)(((long)(rows - 1) * g.ln16_ld + N) * 2));
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    float q = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) q += s_part[1][w][rt * 16 + l15];
-                    const float rstd = 1.0f / sqrtf(q * invN + g.ln_eps);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        // the affine vectors are re-read per tile (L2 hits): kept for the kernel's lifetime they cost 24 VGPRs the K = 384
-                        // instantiation does not have (104 B of scratch)
+                        // the affine vectors are re-read per tile (L2 hits): kept for the kernel's lifetime they would cost 2 NT more VGPR quads
                         const f4 lw = *reinterpret_cast<const f4*>(g.ln16_w + n0 + nt * 16 + gq * 4);
                         const f4 lb = *reinterpret_cast<const f4*>(g.ln16_b + n0 + nt * 16 + gq * 4);
-                        const f4 o = (acc[rt][nt] - mean[rt]) * rstd * lw + lb;
+                        const f4 o = (acc[rt][nt] - mean[rt]) * rstd[rt] * lw + lb;
                         if constexpr (std::is_same<T, _Float16>::value) rgmax = rg_absmax4_f(rgmax, o);
                         const t4 h = t4{(T)o.x, (T)o.y, (T)o.z, (T)o.w};
                         const bufops_u32 off = (bufops_u32)(((rt * 16 + l15) * g.ln16_ld + n0 + nt * 16 + gq * 4) * 2);
@@ -206,8 +220,8 @@ __global__ __launch_bounds__(512, 1) void gemm16_wreg_kernel(const G16Args g) {
                     }
                 }
             }
+            tile_par ^= 1;
         }
-        __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf] (and s_part)
         buf ^= 1;
     }
     if constexpr (STATS == 2 && std::is_same<T, _Float16>::value) rg_report_f(rgmax, g.ovf, 2u);
