@@ -507,7 +507,10 @@ def main(argv=None):
         detail["cpu_blocks"] = cpu_detail
     out["ms_per_step_by_rank"] = rank_ms
     out["ms_windows"] = detail["ms_windows"]
-    out["blocks"] = [{k: v for k, v in r.items() if k != "bound"} for r in per_block]
+    # the per-block list stays LAST and short (the scalar / string series above carry the same figures; --detail has every field): the line
+    # must stay under ~8 KB for readers that keep a bounded tail
+    keep = ("block", "key", "ms", "achieved", "unit", "frac", "traffic", "strict_ms", "alt_TFLOPs")
+    out["blocks"] = [{k: r[k] for k in keep if k in r} for r in per_block]
     line = json.dumps(out, separators=(",", ":"))
     if args.detail:
         try:
@@ -516,7 +519,7 @@ def main(argv=None):
                 json.dump({"line": out, "detail": detail}, f, indent=1)
         except OSError as e:
             sys.stderr.write("[bench] --detail %s not written: %s\n" % (args.detail, e))
-    sys.stderr.write("[bench] JSON line: %d bytes\n" % len(line))
+    sys.stderr.write("[bench] JSON line: %d bytes%s\n" % (len(line), "" if len(line) < 8192 else "  (WARNING: above 8 KB)"))
     print(line)
     if dist is not None:
         dist.destroy_process_group()
