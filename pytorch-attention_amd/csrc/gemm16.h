@@ -53,5 +53,6 @@ size_t gemm16_p8_workspace_bytes(int M, int N, int K);
 int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, int abl = 0);        // g.lnc_a != null: emitting variant                                 // gemm16_pa.hip
 int gemm16_w4(const g16::G16Args& g, int out16, int precision, hipStream_t st);                        // gemm16_w4.hip
 int gemm16_wreg(const g16::G16Args& g, int out16, int precision, hipStream_t st);                      // gemm16_wreg.hip
+int gemm16_wst(const g16::G16Args& g, int out16, int precision, hipStream_t st);                       // gemm16_wst.hip
 int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }
