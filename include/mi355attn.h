@@ -149,6 +149,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   against 224 us for the three launches at C = 384, 157 against 137 at C = 256 (profiles/r06_mlp_wide.md: with 98 rows per
  *                   step every weight byte is used for 98 rows, the 256 x 128 GEMM tiles use it for 256 -- the fused kernel pulls as many bytes
  *                   from L2 as the two GEMMs and cannot hold more rows' accumulators), hence opt-in.
+ *   "gemm_wst"      1 / 2 = 16-bit outputs with K = 768 and N % 192 == 0 (the qkv / fc1 products of ViT-Base) keep a 192-column slab of W in the
+ *                   registers of a persistent workgroup and stream X through LDS once per slab (gemm16_wst.hip; 1 = products without activation,
+ *                   2 = GELU epilogues too).  A row's K halves are added as two chains: results differ from the tile kernels by at most one unit
+ *                   of the 16-bit output.  0 (default): measured slower than the tile kernels (profiles/r06_gemm_wst.md: qkv 208-219 vs 174-180 us).
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.

@@ -317,3 +317,42 @@ def test_cswin_stage3_block_has_no_second_layernorm_launch():
         tags = _tags(lambda: out.__setitem__("y", md(xd)))
     assert sum("layernorm" in t for t in tags) == 1 and any("resid+ln16" in t for t in tags), tags
     assert_parity(out["y"].cpu(), ref, 1e-3, "CSWin s3 with norm2 emitted by the proj GEMM")
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,act", [(50432, 2304, 0), (8192 + 21, 3072, 1), (8192, 768, 0)])
+def test_weight_stationary_k768_gemm_is_correct_when_opted_in(M, N, act, prec):
+    """gemm16_wst.hip (opt-in, `gemm_wst`; measured slower: profiles/r06_gemm_wst.md): against an fp64 product of sampled rows, against the tile
+    kernels (one unit of the 16-bit output at most: the K halves are two chains), run to run, and for a ragged row count (rows beyond M clamped
+    on the way in, never stored)."""
+    import mi355attn
+    from mi355attn import functional as F
+    K = 768
+    torch.manual_seed(M + N + prec)
+    x16 = F.cast16(torch.randn(M, K, device="cuda"), prec)
+    w16 = F.cast16((torch.randn(N, K, device="cuda") / K ** 0.5).contiguous(), prec)
+    b = torch.randn(N, device="cuda")
+    a = F.ACT_GELU if act else F.ACT_NONE
+    outs, tags = {}, {}
+    try:
+        for v in (2, 0):
+            mi355attn.set_option("gemm_wst", v)
+            tags[v] = _tags(lambda: outs.__setitem__(v, F.linear16(x16, w16, b, act=a, out16=True, precision=prec)))
+        mi355attn.set_option("gemm_wst", 2)
+        again = F.linear16(x16, w16, b, act=a, out16=True, precision=prec)
+        sub = F.linear16(x16[:4096].contiguous(), w16, b, act=a, out16=True, precision=prec)
+    finally:
+        mi355attn.set_option("gemm_wst", 0)
+    torch.cuda.synchronize()
+    assert any("gemm16_wst_kernel" in t for t in tags[2]) and not any("gemm16_wst_kernel" in t for t in tags[0]), (tags[2], tags[0])
+    rows = torch.tensor([0, 1, 31, 32, 33, M // 2, M - 33, M - 32, M - 2, M - 1], device="cuda")
+    ref = x16[rows].double() @ w16.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    tol = 1e-3 if prec == 1 else 8e-3
+    assert_parity(outs[2][rows].float().cpu(), ref.float().cpu(), tol, "gemm16_wst vs fp64")
+    ulp = 2.0 ** -10 if prec == 1 else 2.0 ** -7
+    scale = float(outs[0].float().abs().max())
+    assert float((outs[2].float() - outs[0].float()).abs().max()) <= 2 * ulp * scale
+    assert torch.equal(again, outs[2]), "run-to-run"
+    assert torch.equal(sub, outs[2][:4096]), "a row's bits do not depend on the rows around it"

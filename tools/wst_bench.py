@@ -14,6 +14,7 @@ from mi355attn import functional as F  # noqa: E402
 
 dev = torch.device("cuda", 0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+VARS = (0, 2)
 torch.manual_seed(0)
 for name, M, N, act in (("qkv", 50432, 2304, F.ACT_NONE), ("fc1", 50432, 3072, F.ACT_GELU), ("qkv_ragged", 50432 - 200 + 7, 2304, F.ACT_NONE),
                         ("fc1_small", 4096, 3072, F.ACT_GELU)):
@@ -22,7 +23,7 @@ for name, M, N, act in (("qkv", 50432, 2304, F.ACT_NONE), ("fc1", 50432, 3072, F
     w16 = F.cast16((torch.randn(N, K, device=dev) / K ** 0.5).contiguous(), 1)
     b = torch.randn(N, device=dev)
     outs, tags = {}, {}
-    for v in (0, 2):
+    for v in VARS:
         mi355attn.set_option("gemm_wst", v)
         tags[v] = [t for t, *_ in mi355attn.kernel_trace(lambda: outs.__setitem__(v, F.linear16(x16, w16, b, act=act, out16=True, precision=1)))]
     torch.cuda.synchronize()
@@ -31,13 +32,12 @@ for name, M, N, act in (("qkv", 50432, 2304, F.ACT_NONE), ("fc1", 50432, 3072, F
     if act == F.ACT_GELU:
         ref = torch.nn.functional.gelu(ref)
     errs = {v: float(((outs[v][rows].double() - ref).abs().max() / ref.abs().max())) for v in outs}
-    diff = float((outs[0].float() - outs[2].float()).abs().max() / outs[0].float().abs().max())
-    line = "%-10s M=%d N=%d  kernels %s | %s   max rel err vs fp64: tile %.2e  wst %.2e   wst vs tile (all rows) %.2e" % (
-        name, M, N, tags[0][0].split(" ")[0], tags[2][0].split(" ")[0], errs[0], errs[2], diff)
-    print(line)
+    diffs = {v: float((outs[0].float() - outs[v].float()).abs().max() / outs[0].float().abs().max()) for v in outs}
+    print("%-10s M=%d N=%d  kernels %s   max rel err vs fp64 %s   vs tile kernel (all rows) %s" % (
+        name, M, N, [tags[v][0].split(" ")[0] for v in VARS], {v: "%.2e" % e for v, e in errs.items()}, {v: "%.2e" % e for v, e in diffs.items()}))
     for r in range(rounds):
         ts = []
-        for v in (0, 2):
+        for v in VARS:
             mi355attn.set_option("gemm_wst", v)
             F.linear16(x16, w16, b, act=act, out16=True, precision=1)
             torch.cuda.synchronize()
@@ -47,5 +47,5 @@ for name, M, N, act in (("qkv", 50432, 2304, F.ACT_NONE), ("fc1", 50432, 3072, F
                 F.linear16(x16, w16, b, act=act, out16=True, precision=1)
             ts.append(tm.stop_ms() / 10 * 1e3)
         flop = 2.0 * M * N * K
-        print("    round %d: tile %.1f us (%.0f TFLOP/s)   wst %.1f us (%.0f TFLOP/s)" % (r, ts[0], flop / ts[0] / 1e6, ts[1], flop / ts[1] / 1e6))
+        print("    round %d: " % r + "   ".join("opt %d: %.1f us (%.0f TFLOP/s)" % (v, tt, flop / tt / 1e6) for v, tt in zip(VARS, ts)))
     mi355attn.set_option("gemm_wst", 0)
