@@ -152,7 +152,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *   "gemm_wst"      1 / 2 = 16-bit outputs with K = 768 and N % 192 == 0 (the qkv / fc1 products of ViT-Base) keep a 192-column slab of W in the
  *                   registers of a persistent workgroup and stream X through LDS once per slab (gemm16_wst.hip; 1 = products without activation,
  *                   2 = GELU epilogues too).  A row's K halves are added as two chains: results differ from the tile kernels by at most one unit
- *                   of the 16-bit output.  0 (default): measured slower than the tile kernels (profiles/r06_gemm_wst.md: qkv 208-219 vs 174-180 us).
+ *                   of the 16-bit output.  3 / 4 = the same products (N % 256 == 0, M % 32 == 0) on the one-wave-per-SIMD kernel that keeps W in
+ *                   AGPRs as MFMA operands: one chain per row, bit-identical to the tile kernels (3 = without activation, 4 = GELU too).
+ *                   0 (default): both measured slower than the tile kernels (profiles/r06_gemm_wst.md: qkv 200-219 vs 174-180 us, fc1 281-337
+ *                   vs 275-288).
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.

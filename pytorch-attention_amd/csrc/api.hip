@@ -57,8 +57,8 @@ static const OptDesc kOpts[O_COUNT] = {
     {"xca_tr", 1, 0, 1},                   // XCA core with 16-bit q / k / v and N <= 224: covariance on the 16-bit matrix pipe from one transposed LDS image (xcit.hip xca_tr_kernel)
     {"mlp_wide", 0, 0, 1},                 // 1 = mi355_mlp_fused_fwd takes C = 256 / 384 (hidden 4C) on the weight-split kernel (mlp_wide.hip); measured SLOWER than LayerNorm + two GEMMs
                                            // (profiles/r06_mlp_wide.md), hence opt-in; 0 (default) = those shapes are MI355_EUNSUPPORTED
-    {"gemm_wst", 0, 0, 2},                 // 16-bit outputs with K = 768, N % 192 == 0 (ViT qkv / fc1): weights stationary in registers (gemm16_wst.hip); 1 = products without
-                                           // activation, 2 = GELU epilogues too.  Measured slower than the tile kernels (profiles/r06_gemm_wst.md): opt-in
+    {"gemm_wst", 0, 0, 4},                 // 16-bit outputs with K = 768, N % 192 == 0 (ViT qkv / fc1): weights stationary in registers (gemm16_wst.hip); 1 = products without
+                                           // activation, 2 = GELU epilogues too; 3 / 4 = the same on the one-wave-per-SIMD kernel with W in AGPRs.  Measured slower than the tile kernels (profiles/r06_gemm_wst.md): opt-in
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {

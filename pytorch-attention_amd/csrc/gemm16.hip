@@ -535,7 +535,7 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant == 0 && out16 && K == 768 && (mi355::opt_gemm_wst() == 2 || (mi355::opt_gemm_wst() == 1 && g.act == MI355_ACT_NONE))) {
+    if (variant == 0 && out16 && K == 768 && (mi355::opt_gemm_wst() == 2 || mi355::opt_gemm_wst() == 4 || ((mi355::opt_gemm_wst() & 1) && g.act == MI355_ACT_NONE))) {
         // ViT qkv / fc1, opt-in: a 192-column slab of W stays in the registers of a workgroup, X streams through LDS once per slab (gemm16_wst.hip)
         const int rc = mi355::gemm16_wst(g, out16, precision, st);
         if (rc == MI355_OK) {

@@ -14,7 +14,7 @@ from mi355attn import functional as F  # noqa: E402
 
 dev = torch.device("cuda", 0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-VARS = (0, 2)
+VARS = (0, 2, 4)
 torch.manual_seed(0)
 for name, M, N, act in (("qkv", 50432, 2304, F.ACT_NONE), ("fc1", 50432, 3072, F.ACT_GELU), ("qkv_ragged", 50432 - 200 + 7, 2304, F.ACT_NONE),
                         ("fc1_small", 4096, 3072, F.ACT_GELU)):
