@@ -26,6 +26,9 @@ def main(path, per, title):
     rows = c.execute(f"select {sel} from kernels order by start").fetchall()
     rows = [r for r in rows if not any(t in r[0] for t in ("at::", "rocclr", "stream_copy", "elementwise_kernel"))]
     names = [r[0] for r in rows]
+    if not rows:
+        print(f"# {title}: no kernel launches in {path}")
+        return
     if per <= 0:                                    # smallest period of the tail of the launch sequence
         n = len(names)
         per = n
