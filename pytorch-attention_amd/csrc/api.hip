@@ -18,7 +18,7 @@ static thread_local char g_err[512] = "";
 // or, in a test, sabotage -- one device without the others seeing it.  A block starts from the defaults below.
 constexpr int MAX_DEV = 64;
 enum Opt { O_CHUNK_IMAGES, O_NT, O_REVERSE, O_GEMM_VARIANT, O_ECA_SINGLE, O_SE_SINGLE, O_CBAM_SINGLE, O_WS_PERSISTENT, O_STEM_DIRECT,
-           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_RANGE_FALLBACK, O_GEMM_WREG, O_XCA_TR, O_MLP_WIDE, O_GEMM_WST, O_COUNT };
+           O_ZOO_SINGLE, O_SPIN_LIMIT, O_GEMM_PA, O_GEMM_SPLITK, O_DA_FUSED, O_DA_RANGES, O_SE_OCC, O_LN_FOLD, O_GEMM_PA16, O_GEMM_PA_BLOCK, O_GEMM_PA_TAIL, O_LPI_PATCH, O_MIXER_FUSED, O_MIXER_EARLY, O_GEMM_SMALL, O_MLP_TT4, O_MIXER_STATS, O_ATTN_NW, O_GEMM_W4, O_RANGE_FALLBACK, O_GEMM_WREG, O_XCA_TR, O_MLP_WIDE, O_GEMM_WST, O_GEMM_WSLAB, O_COUNT };
 struct OptDesc { const char* key; long def, lo, hi; };
 // key, default, accepted range.  spin_limit additionally accepts 0 (forces the time-out path in tests: every exchange then fails on
 // its first unsuccessful poll; real budgets start at 1024 sweeps)
@@ -59,6 +59,8 @@ static const OptDesc kOpts[O_COUNT] = {
                                            // (profiles/r06_mlp_wide.md), hence opt-in; 0 (default) = those shapes are MI355_EUNSUPPORTED
     {"gemm_wst", 0, 0, 4},                 // 16-bit outputs with K = 768, N % 192 == 0 (ViT qkv / fc1): weights stationary in registers (gemm16_wst.hip); 1 = products without
                                            // activation, 2 = GELU epilogues too; 3 / 4 = the same on the one-wave-per-SIMD kernel with W in AGPRs.  Measured slower than the tile kernels (profiles/r06_gemm_wst.md): opt-in
+    {"gemm_wslab", 0, 0, 2},               // 16-bit outputs with K = 256 / 384 / 512 (XCiT / CSWin stage 3-4 / Mixer qkv and fc1): a column slab of W stationary in
+                                           // registers (gemm16_wslab.hip); 1 = four waves, two workgroups per CU; 2 = eight waves, one
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {
@@ -118,6 +120,7 @@ long opt_gemm_wreg() { return opt(O_GEMM_WREG); }
 long opt_xca_tr() { return opt(O_XCA_TR); }
 long opt_mlp_wide() { return opt(O_MLP_WIDE); }
 long opt_gemm_wst() { return opt(O_GEMM_WST); }
+long opt_gemm_wslab() { return opt(O_GEMM_WSLAB); }
 
 // ---- workspaces of the granule-exchange kernels (chan_fused.hip, cbam_single.hip, chan_stat.hip) ---------------------------------
 // A granule is valid when it carries the tag of the CURRENT launch = the workspace's epoch word + 1 (advanced on the device by the

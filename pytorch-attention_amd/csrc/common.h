@@ -40,6 +40,7 @@ long  opt_gemm_wreg();
 long  opt_xca_tr();
 long  opt_mlp_wide();
 long  opt_gemm_wst();
+long  opt_gemm_wslab();
 // fused LayerNorm + MLP for C = 256 / 384 (mlp_wide.hip): waves split the weights, fragments go global -> VGPR
 bool  mlp_wide_applicable(int C, int hidden);
 int   mlp_wide(const float* x, const void* w1_16, const float* b1, const void* w2_16, const float* b2, const float* gamma, float* y, long M, int C,

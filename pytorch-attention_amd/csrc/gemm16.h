@@ -54,5 +54,6 @@ int gemm16_pa(const g16::G16Args& g, int out16, int precision, hipStream_t st, i
 int gemm16_w4(const g16::G16Args& g, int out16, int precision, hipStream_t st);                        // gemm16_w4.hip
 int gemm16_wreg(const g16::G16Args& g, int out16, int precision, hipStream_t st);                      // gemm16_wreg.hip
 int gemm16_wst(const g16::G16Args& g, int out16, int precision, hipStream_t st);                       // gemm16_wst.hip
+int gemm16_wslab(const g16::G16Args& g, int out16, int precision, hipStream_t st);                     // gemm16_wslab.hip
 int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }

@@ -569,6 +569,16 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
+    if (variant == 0 && out16 && (K == 256 || K == 384 || K == 512) && !g.gamma && !g.resid && mi355::opt_gemm_wslab()) {
+        // short reductions, 16-bit output (XCiT / CSWin stage 3-4 / Mixer qkv and fc1): a column slab of W stationary in registers, X through LDS
+        // once per slab, 32-row tiles (gemm16_wslab.hip; bit-identical to the tile kernels)
+        const int rc = mi355::gemm16_wslab(g, out16, precision, st);
+        if (rc == MI355_OK) {
+            MI355_LAUNCH_CHECK();
+            return MI355_OK;
+        }
+        if (rc != MI355_EUNSUPPORTED) return rc;
+    }
     if (variant == 0 && out16 && K >= 256 && !g.gamma && !g.resid && mi355::opt_gemm_pa() &&
         (K <= 512 || (mi355::opt_gemm_pa16() >= 1 && g.act == MI355_ACT_GELU) || mi355::opt_gemm_pa16() >= 2)) {
         // 16-bit outputs with a SHORT reduction (4 .. 8 K-tiles: CSWin stage 3 / 4, XCiT, the Mixer's token mixing): on the persistent
