@@ -156,6 +156,10 @@ const char* mi355_last_error(void);         /* thread-local message of the last 
  *                   AGPRs as MFMA operands: one chain per row, bit-identical to the tile kernels (3 = without activation, 4 = GELU too).
  *                   0 (default): both measured slower than the tile kernels (profiles/r06_gemm_wst.md: qkv 200-219 vs 174-180 us, fc1 281-337
  *                   vs 275-288).
+ *   "gemm_wslab"    1 (default) = 16-bit outputs with K = 256 / 384 / 512 and N a multiple of the slab width (256 / 192 / 256 columns) keep a column slab
+ *                   of W in the registers of a persistent workgroup and stream 32-row tiles of X (gemm16_wslab.hip) when the epilogue is a GELU or M is
+ *                   not a multiple of 256 -- the products it measured faster on (5-12 % / 88-96 -> 65-69 us; profiles/r06_gemm_wslab.md); 2 = every
+ *                   product it takes (plain epilogues: a tie); 0 = the tile kernels.  Bit-identical results either way.
  *   "range_fallback" 1 (default) = the host mirror's modules re-run a forward whose fp16 operands saturated in precision 0 (one warning;
  *                   mi355_range_arm / mi355_range_wait below: no device synchronisation unless it fires); 0 = they do not wait and the NEXT call
  *                   reports MI355_ERANGE (the round-3 contract).  Host policy: the C entries themselves never re-run anything.

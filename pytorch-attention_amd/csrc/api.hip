@@ -59,8 +59,8 @@ static const OptDesc kOpts[O_COUNT] = {
                                            // (profiles/r06_mlp_wide.md), hence opt-in; 0 (default) = those shapes are MI355_EUNSUPPORTED
     {"gemm_wst", 0, 0, 4},                 // 16-bit outputs with K = 768, N % 192 == 0 (ViT qkv / fc1): weights stationary in registers (gemm16_wst.hip); 1 = products without
                                            // activation, 2 = GELU epilogues too; 3 / 4 = the same on the one-wave-per-SIMD kernel with W in AGPRs.  Measured slower than the tile kernels (profiles/r06_gemm_wst.md): opt-in
-    {"gemm_wslab", 0, 0, 2},               // 16-bit outputs with K = 256 / 384 / 512 (XCiT / CSWin stage 3-4 / Mixer qkv and fc1): a column slab of W stationary in
-                                           // registers (gemm16_wslab.hip); 1 = four waves, two workgroups per CU; 2 = eight waves, one
+    {"gemm_wslab", 1, 0, 2},               // 16-bit outputs with K = 256 / 384 / 512 (XCiT / CSWin stage 3-4 / Mixer qkv and fc1): a column slab of W stationary in
+                                           // registers (gemm16_wslab.hip); 1 = GELU epilogues and M % 256 != 0 (where it measured faster), 2 = every product it takes
 };
 static_assert(sizeof(kOpts) / sizeof(kOpts[0]) == O_COUNT, "one table row per option, in enum order");
 namespace {

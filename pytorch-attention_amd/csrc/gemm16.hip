@@ -569,9 +569,11 @@ int mi355::linear16_dispatch(const G16Args& g, int out16, int precision, void* w
         MI355_LAUNCH_CHECK();
         return MI355_OK;
     }
-    if (variant == 0 && out16 && (K == 256 || K == 384 || K == 512) && !g.gamma && !g.resid && mi355::opt_gemm_wslab()) {
+    if (variant == 0 && out16 && (K == 256 || K == 384 || K == 512) && !g.gamma && !g.resid &&
+        (mi355::opt_gemm_wslab() == 2 || (mi355::opt_gemm_wslab() == 1 && (g.act == MI355_ACT_GELU || (M & 255))))) {
         // short reductions, 16-bit output (XCiT / CSWin stage 3-4 / Mixer qkv and fc1): a column slab of W stationary in registers, X through LDS
-        // once per slab, 32-row tiles (gemm16_wslab.hip; bit-identical to the tile kernels)
+        // once per slab, 32-row tiles (gemm16_wslab.hip; bit-identical to the tile kernels).  Default policy: where it measured faster -- GELU
+        // epilogues (5-12 %) and row counts off the 256-row grid (which otherwise fall to gemm16_p8: 88-96 -> 65-69 us); plain epilogues are a tie.
         const int rc = mi355::gemm16_wslab(g, out16, precision, st);
         if (rc == MI355_OK) {
             MI355_LAUNCH_CHECK();

@@ -6,7 +6,7 @@
 // tile kernels (gemm16_pa) spend as long in a tile's epilogue as in its main loop and round M x N up to 128 x 256 tiles (CSWin stage 4: 588
 // tiles on 256 workgroups = 0.77 full); they reach 0.43-0.74 PFLOP/s on these shapes (profiles/r06_*_kernel_seq.txt) against 1.0 at K = 768.
 //
-//   workgroup  = NW waves (4: two workgroups per CU that run out of phase, so one's epilogue VALU work meets the other's MFMAs; 8: one), persistent,
+//   workgroup  = NW waves (4 at K = 256 / 384: two workgroups per CU with their own barriers; 8 at K = 512: one), persistent,
 //                owns ONE slab of NW x NT x 16 columns for the whole kernel: wave w holds the NT x 16 columns [w NT 16, (w + 1) NT 16) of the slab
 //                x the whole K as MFMA A-operand fragments (NT x K/32 x 4 registers: 128 ... 192), loaded once;
 //   stream     = the workgroups of the slabs 0 .. nslab-1 with the same stream index sit next to each other on one XCD and walk the SAME 32-row
@@ -17,7 +17,13 @@
 //                fragment slot, so that a lane's NT accumulator quads are 4 NT CONSECUTIVE output columns: one 8 NT-byte piece per row tile and
 //                lane, the four lane groups of a wave complete 32 NT-byte row segments (128 B at NT = 4).
 // A row's K steps are added in ascending order on the same MFMA instruction and the epilogue is gelu16_fast(acc + bias): the bits of the tile
-// kernels.  Rows beyond M come back as zeros from the buffer range check and are never stored.
+// kernels (tests/test_round6_kernels_gpu.py).  Rows beyond M come back as zeros from the buffer range check and are never stored.
+// MEASURED (profiles/r06_gemm_wslab.md, same process, interleaved): GELU epilogues 5-12 % faster than gemm16_pa (XCiT fc1 97-119 -> 89-105 us, CSWin
+// stage-3 fc1 57 -> 51, stage-4 fc1 44 -> 40, Mixer fc1 131-150 -> 128-136), plain epilogues a tie (XCiT qkv 57-67 vs 59-71, CSWin s3 qkv 31 vs 32) or
+// slower (CSWin s4 qkv 28.5 vs 31), row counts off the 256-row grid 88-96 -> 65-69 (those fall from gemm16_pa to gemm16_p8).  Hence option
+// "gemm_wslab" = 1 (default): GELU epilogues and M % 256 != 0; 2: every product it takes; 0: none.  A ring of three LDS-DMA'ed tiles instead of the
+// register staging was built and measured 3-8 % SLOWER on the GELU shapes (removed); the ablation says the kernel is bound by its epilogue VALU
+// work + LDS fragment reads, not by the X stream.
 #include "gemm16.h"
 #include "bufops.h"
 #include <type_traits>
@@ -105,10 +111,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void gemm16_wslab_kernel(const G16
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+        // row tile by row tile: the epilogue arithmetic of row tile 0 has no dependence on the MFMAs of row tile 1 and is scheduled among them
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const v8 xf = *reinterpret_cast<const v8*>(&s_x[buf][(rt * 16 + l15) * XP + ks * 32 + gq * 8]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mma16<T>(wfr[nt][ks], xf, acc[rt][nt]);
@@ -156,8 +163,7 @@ int gemm16_wslab(const G16Args& g, int out16, int precision, hipStream_t st) {
     if ((g.lda & 7) || (g.ldb & 7) || (g.ldc & 7) || g.ldb < g.K || g.lda < g.K || g.ldc < g.N) return MI355_EUNSUPPORTED;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.bias && !aligned16(g.bias))) return MI355_EUNSUPPORTED;
     if ((long)32 * g.ldc * 2 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
-    const int mode = (int)opt_gemm_wslab();          // 1 = four waves, two workgroups per CU; 2 = eight waves, one
-    const int nw = mode == 2 ? 8 : 4;
+    const int nw = g.K == 512 ? 8 : 4;               // measured: K = 512 30.8 / 40.3 us on eight waves against 32.0 / 42.0 on four (CSWin stage 4 qkv / fc1)
     int nt;
     if (g.K == 256) nt = 4; else if (g.K == 384) nt = 3; else if (g.K == 512) nt = 2; else return MI355_EUNSUPPORTED;
     const int slabw = nw * nt * 16;
@@ -174,12 +180,11 @@ int gemm16_wslab(const G16Args& g, int out16, int precision, hipStream_t st) {
         if (g.act == MI355_ACT_GELU) gemm16_wslab_kernel<T_, K_, NT_, NW_, true><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream);  \
         else                         gemm16_wslab_kernel<T_, K_, NT_, NW_, false><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream); \
     } while (0)
-#define GO2(T_, NW_)                                                                                              \
+#define GO2(T_)                                                                                                   \
     do {                                                                                                          \
-        if (g.K == 256) GO3(T_, 256, 4, NW_); else if (g.K == 384) GO3(T_, 384, 3, NW_); else GO3(T_, 512, 2, NW_); \
+        if (g.K == 256) GO3(T_, 256, 4, 4); else if (g.K == 384) GO3(T_, 384, 3, 4); else GO3(T_, 512, 2, 8);     \
     } while (0)
-    if (precision == MI355_PREC_FP16) { if (nw == 4) GO2(_Float16, 4); else GO2(_Float16, 8); }
-    else                              { if (nw == 4) GO2(__bf16, 4); else GO2(__bf16, 8); }
+    if (precision == MI355_PREC_FP16) GO2(_Float16); else GO2(__bf16);
 #undef GO2
 #undef GO3
     return MI355_OK;

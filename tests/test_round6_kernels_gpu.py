@@ -364,3 +364,69 @@ def test_weight_stationary_k768_gemm_is_correct_when_opted_in(M, N, act, prec):
     if one_wave:                                                  # one chain per row, like the tile kernels: the same bits
         assert any("gemm16_wst_kernel" in t for t in tags[4]), tags[4]
         assert torch.equal(outs[4], outs[0]), "the one-wave-per-SIMD kernel adds a row's K steps in the tile kernels' order"
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K,act", [(50176, 1536, 384, 1), (50176, 1152, 384, 0), (50176 - 45, 1152, 384, 0), (50176, 1024, 256, 1),
+                                       (12544, 2048, 512, 1), (12544 + 7, 1536, 512, 0), (50176, 768, 256, 0), (1000, 768, 256, 1)])
+def test_slab_stationary_short_k_gemm_has_the_tile_kernels_bits(M, N, K, act, prec):
+    """gemm16_wslab.hip (round 6, default for GELU epilogues and row counts off the 256-row grid): the same bits as the tile kernels for every row,
+    ragged row counts included; an fp64 product of sampled rows; run to run; the default policy takes exactly the products it measured faster on;
+    too few rows fall back to the tile kernels (nothing unsupported is launched)."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(M + N + K + prec)
+    x16 = F.cast16(torch.randn(M, K, device="cuda"), prec)
+    w16 = F.cast16((torch.randn(N, K, device="cuda") / K ** 0.5).contiguous(), prec)
+    b = torch.randn(N, device="cuda")
+    a = F.ACT_GELU if act else F.ACT_NONE
+    outs, tags = {}, {}
+    old = mi355attn.get_option("gemm_wslab")
+    try:
+        for v in (2, 1, 0):
+            mi355attn.set_option("gemm_wslab", v)
+            tags[v] = _tags(lambda: outs.__setitem__(v, F.linear16(x16, w16, b, act=a, out16=True, precision=prec)))
+        mi355attn.set_option("gemm_wslab", 2)
+        again = F.linear16(x16, w16, b, act=a, out16=True, precision=prec)
+        nob = F.linear16(x16, w16, None, act=a, out16=True, precision=prec)
+        mi355attn.set_option("gemm_wslab", 0)
+        nob0 = F.linear16(x16, w16, None, act=a, out16=True, precision=prec)
+    finally:
+        mi355attn.set_option("gemm_wslab", old)
+    torch.cuda.synchronize()
+    on = {v: any("gemm16_wslab_kernel" in t for t in tags[v]) for v in tags}
+    enough_rows = M >= 4 * 32 * (512 if K != 512 else 256) // (N // (192 if K == 384 else 256))
+    assert not on[0]
+    assert on[2] == enough_rows, (tags[2], enough_rows)
+    assert on[1] == (enough_rows and (bool(act) or M % 256 != 0)), tags[1]
+    assert torch.equal(outs[2], outs[0]) and torch.equal(outs[1], outs[0]), "one ascending chain per row and the same epilogue: the same bits"
+    assert torch.equal(again, outs[2]), "run-to-run"
+    assert torch.equal(nob, nob0), "bias == None"
+    rows = torch.tensor([0, 1, 15, 16, 31, 32, M // 2, M - 33, M - 32, M - 2, M - 1], device="cuda")
+    ref = x16[rows].double() @ w16.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    assert_parity(outs[2][rows].float().cpu(), ref.float().cpu(), 1e-3 if prec == 1 else 8e-3, "gemm16_wslab vs fp64")
+
+
+def test_slab_stationary_gemm_reports_fp16_saturation():
+    """The 16-bit epilogue of gemm16_wslab feeds the range word like the tile kernels' (the `range_fallback` contract of the modules rests on it)."""
+    import mi355attn
+    from mi355attn import functional as F
+    M, N, K = 50176, 1536, 384
+    x16 = F.cast16(torch.full((M, K), 8.0, device="cuda"), 1)
+    w16 = F.cast16(torch.full((N, K), 32.0, device="cuda"), 1)          # 8 * 32 * 384 = 98 304 > 65 504
+    mi355attn.range_status(wait=True)
+    old = mi355attn.get_option("gemm_wslab")
+    try:
+        mi355attn.set_option("gemm_wslab", 2)
+        tags = _tags(lambda: F.linear16(x16, w16, None, act=F.ACT_GELU, out16=True, precision=1))
+        assert any("gemm16_wslab_kernel" in t for t in tags), tags
+        with pytest.raises(mi355attn.Mi355RangeError):
+            mi355attn.range_status(wait=True)
+    finally:
+        mi355attn.set_option("gemm_wslab", old)
+        try:
+            mi355attn.range_status(wait=True)
+        except mi355attn.Mi355RangeError:
+            pass
