@@ -15,7 +15,7 @@ O=$R/gpurun_out/r6f
 rm -f $O/*
 cd $R
 export MI355_MARGIN_OUT=$O/r06_parity_margin.md
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
 echo "rc=$?" >> $O/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_all -o all -- python $R/bench.py --no-cpu --no-strict --no-calib --steps 3 --warmup 1 > $O/prof_all.log 2>&1
