@@ -14,7 +14,6 @@
 // residual / position-embedding fused (the C/D fragment layout would otherwise write 64-byte pieces).
 // Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (n fastest): the A panel of a tile row
 // is fetched into one L2 instead of eight.
-#include <type_traits>
 #include "common.h"
 #include "mma.h"
 #include "gemm16.h"
@@ -121,14 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     }
 
-    // Strict mode stages TWO K-steps ahead (two register sets): one K-step of 48 MFMAs per wave (0.4 us) does not cover a global load, and with
-    // one set the kernel waited for L2 / HBM every K-step (742 us for the ViT qkv product = 0.37 of its own MFMA time: profiles/r06_strict_mode.md).
-    // The 16-bit modes keep one set (152 VGPRs = three workgroups per CU; a second set would cost the third).
-    constexpr int NSET = (PREC == 0) ? 2 : 1;
-    f4 ra_[NSET][4], rb_[NSET][4];
-    auto load_tile = [&](int k0, auto SET) {
-        f4 (&ra)[4] = ra_[decltype(SET)::value];
-        f4 (&rb)[4] = rb_[decltype(SET)::value];
+    f4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + lk;
@@ -171,9 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             }
         }
     };
-    auto store_tile = [&](int buf, auto SET) {
-        f4 (&ra)[4] = ra_[decltype(SET)::value];
-        f4 (&rb)[4] = rb_[decltype(SET)::value];
+    auto store_tile = [&](int buf) {
         unsigned short* hiA = lds + (buf * NS + 0) * TILE;
         unsigned short* loA = lds + (buf * NS + (NS - 1)) * TILE;
         unsigned short* hiB = hiA + BM * PITCH;
@@ -202,10 +193,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (g.K + BK - 1) / BK;
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, NSET - 1>;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
     const int frow = lane & 15, fk = (lane >> 4) * 8;
-    auto mma_tile = [&](int buf) {
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);           // next tile in flight under the MFMAs
         const unsigned short* sA = lds + (buf * NS) * TILE + (wr * 64 + frow) * PITCH + fk;
         const unsigned short* sB = lds + (buf * NS) * TILE + BM * PITCH + (wc * 64 + frow) * PITCH + fk;
         v8 fa[4][NS], fb[4][NS];
@@ -220,35 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mma_step<PREC>(fa[i], fb[j], acc[i][j]);
-    };
-    load_tile(0, S0{});
-    if constexpr (NSET == 2) {
-        if (nk > 1) load_tile(BK, S1{});
-    }
-    store_tile(0, S0{});
-    __syncthreads();
-    if constexpr (NSET == 2) {
-        // K-step kt lives in LDS buffer kt & 1 and came through register set kt & 1; the set is free again once its tile is in LDS
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) load_tile((kt + 2) * BK, S0{});
-            mma_tile(0);
-            if (kt + 1 < nk) store_tile(1, S1{});
-            __syncthreads();
-            if (kt + 1 < nk) {
-                if (kt + 3 < nk) load_tile((kt + 3) * BK, S1{});
-                mma_tile(1);
-                if (kt + 2 < nk) store_tile(0, S0{});
-                __syncthreads();
-            }
-        }
-    } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) load_tile((kt + 1) * BK, S0{});     // next tile in flight under the MFMAs
-            mma_tile(buf);
-            if (kt + 1 < nk) store_tile(buf ^ 1, S0{});
-            __syncthreads();
-        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue: 2 passes of 32 rows per wave through a private LDS slab ---------------------------------
