@@ -658,21 +658,39 @@ def dominant_kernel_tally(block, run_block, args, ms_block):
     return out
 
 
-def make_comm(dist, dev, rank, world):
+def make_comm(dist, dev, rank, world, timeout_s=120.0):
     """C-ABI communicator + a self-test all-gather checked on every rank (outside the timed region).  Returns (comm, None) when every
-    rank passed, else (None, reason) -- bench.py then gathers through torch.distributed and says so in its JSON line."""
+    rank passed, else (None, reason) -- bench.py then gathers through torch.distributed and says so in its JSON line.
+    The construction (a host-blocking ncclCommInitRank inside mi355_comm_init) and the self-test run on a helper thread that is given
+    `timeout_s`: a rank whose RCCL bootstrap never returns reports "timed out" and every rank falls back together (the verdict is an
+    all-reduce over the torch.distributed group, which does not depend on the communicator under test) instead of the job hanging."""
+    import threading
     import torch
-    comm, why = None, ""
-    try:
-        from mi355attn.dist import RcclComm
-        comm = RcclComm(device=dev)
-        got = comm.all_gather(torch.full((3, 5), float(rank + 1), device=dev))
-        torch.cuda.synchronize()
-        want = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(3)[:, None].expand(-1, 5)
-        if not torch.equal(got, want):
-            why = "self-test all-gather returned wrong data on rank %d" % rank
-    except Exception as e:                                   # noqa: BLE001  (reported, not swallowed: see config.gather)
-        why = "%s: %s" % (type(e).__name__, str(e)[:200])
+    state = {"comm": None, "why": "", "abandon": False}
+
+    def build():
+        try:
+            torch.cuda.set_device(dev)
+            from mi355attn.dist import RcclComm
+            comm = RcclComm(device=dev, check="never")   # no torch.distributed collective on this thread behind the id broadcast: a rank that
+            if state["abandon"]:                          # timed out must not find its peers inside one when it enters the verdict all-reduce
+                return
+            got = comm.all_gather(torch.full((3, 5), float(rank + 1), device=dev))
+            torch.cuda.synchronize()
+            want = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(3)[:, None].expand(-1, 5)
+            if not torch.equal(got, want):
+                state["why"] = "self-test all-gather returned wrong data on rank %d" % rank
+            state["comm"] = comm
+        except Exception as e:                               # noqa: BLE001  (reported, not swallowed: see config.gather)
+            state["why"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+
+    th = threading.Thread(target=build, name="mi355-comm-selftest", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        state["abandon"] = True
+        state["why"] = "C-ABI communicator self-test timed out after %.0f s on rank %d" % (timeout_s, rank)
+    comm, why = state["comm"], state["why"]
     flag = torch.tensor([1.0 if why else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if float(flag.item()) > 0:

@@ -50,12 +50,22 @@ class RcclComm:
             self.rank, self.world = 0, 1
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         buf = ctypes.create_string_buffer(128)
+        err = None
         if self.rank == 0:
-            _ffi.check(_ffi.lib().mi355_comm_unique_id(buf, 128), "mi355_comm_unique_id")
+            try:
+                _ffi.check(_ffi.lib().mi355_comm_unique_id(buf, 128), "mi355_comm_unique_id")
+            except Exception as e:                         # noqa: BLE001  (re-raised below, on EVERY rank)
+                err = e
         if self.world > 1:
-            box = [bytes(buf.raw)]
+            # rank 0 always enters the broadcast -- with None when it has no id to hand out -- so that its failure is an exception on every
+            # rank instead of rank 0 raising while the others wait in the broadcast for ever
+            box = [None if err is not None else bytes(buf.raw)]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if box[0] is None:
+                raise err if err is not None else RuntimeError("RcclComm: rank 0 could not create the RCCL unique id (see its log)")
             buf = ctypes.create_string_buffer(box[0], 128)
+        elif err is not None:
+            raise err
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(_ffi.lib().mi355_comm_init(buf, 128, self.rank, self.world, ctypes.byref(self._h)), "mi355_comm_init")

@@ -283,3 +283,36 @@ def test_ragged_gather_over_gloo_with_device_tensors(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29733", str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and r.stdout.count("RAGGED_OK") == 2, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_comm_selftest_passes_and_times_out_without_hanging(monkeypatch):
+    """bench.make_comm: the C-ABI communicator self-test runs on a helper thread with a deadline; the verdict is an all-reduce over the
+    torch.distributed group.  One rank, nccl backend: the real communicator passes; a construction that never returns is reported as a
+    time-out and the caller falls back (on an 8-GPU node a stuck RCCL bootstrap must not hang the scaling run)."""
+    import socket
+    import time
+    import torch.distributed as dist
+    import bench
+    import mi355attn.dist as mdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        comm, why = bench.make_comm(dist, dev, 0, 1, timeout_s=60.0)
+        assert comm is not None and why is None, why
+        got = comm.all_gather(torch.ones(2, 3, device=dev))
+        assert got.shape == (2, 3)
+        comm.close()
+
+        class Stuck:
+            def __init__(self, *a, **k):
+                time.sleep(30)
+        monkeypatch.setattr(mdist, "RcclComm", Stuck)
+        t0 = time.time()
+        comm, why = bench.make_comm(dist, dev, 0, 1, timeout_s=1.0)
+        assert comm is None and "timed out" in why and time.time() - t0 < 10
+    finally:
+        dist.destroy_process_group()
