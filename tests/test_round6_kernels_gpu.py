@@ -430,3 +430,40 @@ def test_slab_stationary_gemm_reports_fp16_saturation():
             mi355attn.range_status(wait=True)
         except mi355attn.Mi355RangeError:
             pass
+
+
+def test_slab_stationary_gemm_under_graph_capture_and_on_a_side_stream():
+    """gemm16_wslab has no inter-workgroup exchange, no workspace and no host-side state per launch: a captured launch replays on changed
+    inputs bit for bit like an eager one, and a launch on a non-default stream gives the same bits."""
+    import mi355attn
+    from mi355attn import functional as F
+    M, N, K = 50176, 1536, 384
+    torch.manual_seed(6)
+    x16 = torch.randn(M, K, device="cuda").half()
+    w16 = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda")
+    run = lambda: F.linear16(x16, w16, b, act=F.ACT_GELU, out16=True, precision=1)      # noqa: E731
+    tags = _tags(run)
+    assert any("gemm16_wslab_kernel" in t for t in tags), tags                # the default policy sends a GELU epilogue at K = 384 here
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            y_cap = run()
+    torch.cuda.current_stream().wait_stream(s)
+    for rep in range(3):
+        x16.copy_(torch.randn(M, K, device="cuda").half())
+        g.replay()
+        torch.cuda.synchronize()
+        y_ref = run()
+        torch.cuda.synchronize()
+        assert torch.equal(y_cap, y_ref), "replay %d" % rep
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y_side = run()
+    side.synchronize()
+    assert torch.equal(y_side, y_ref)
+    mi355attn.range_status(wait=True)
