@@ -431,6 +431,13 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
  * mi355_linear16_fwd only where the split does not apply; with it the fp32 summation order over K changes (covered by the same
  * tolerance).  ws may be NULL / too small: identical to mi355_linear16_fwd. */
 size_t mi355_linear16_workspace_bytes(int M, int N, int K);
+/* Y16 = act(T(X32) W16^T + bias) with the fp32 -> 16-bit cast of the activation inside the GEMM's X staging (round 6, gemm16_wslab.hip): one
+ * launch and no 16-bit copy of X in HBM where a caller would otherwise run mi355_cast16_fwd + mi355_linear16_fwd (XCA.forward on an fp32
+ * input, xcit.py:251; Mlp.forward, ViT.py:59); the same bits, the same fp16 range report for X (code 1) and for Y (code 3).
+ * Built for K = 256 / 384 / 512, N a multiple of 256 / 384 / 256, ldx % 4 == 0, ldy % 8 == 0 and at least 4 x 32 rows per resident workgroup;
+ * anything else, or option "gemm_wslab" = 0: MI355_EUNSUPPORTED with nothing launched and no error text -- cast and call mi355_linear16_fwd. */
+int mi355_linear16_x32_fwd(const float* X32, const void* W16, const float* bias, void* Y16, int M, int N, int K, int ldx, int ldy, int act,
+                           int precision, mi355_stream_t stream);
 /* Y = resid + X16 W16^T + bias (fp32) AND the LayerNorm statistics of every row of Y: row_stats[2 m] = mean, row_stats[2 m + 1] =
  * 1 / sqrt(var + eps) (two-pass, biased variance -- what mi355_ln_lpi_fwd computes with a pass of its own).  Built where a workgroup owns
  * whole output rows: N = K = 256 / 384, M >= 32 (the weight-stationary kernel, option "gemm_wreg"); other shapes MI355_EUNSUPPORTED.

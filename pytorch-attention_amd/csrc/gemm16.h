@@ -55,5 +55,6 @@ int gemm16_w4(const g16::G16Args& g, int out16, int precision, hipStream_t st); 
 int gemm16_wreg(const g16::G16Args& g, int out16, int precision, hipStream_t st);                      // gemm16_wreg.hip
 int gemm16_wst(const g16::G16Args& g, int out16, int precision, hipStream_t st);                       // gemm16_wst.hip
 int gemm16_wslab(const g16::G16Args& g, int out16, int precision, hipStream_t st);                     // gemm16_wslab.hip
+int gemm16_wslab_check(const g16::G16Args& g, int precision);                                            // would gemm16_wslab take it? (nothing launched)
 int linear16_dispatch(const g16::G16Args& g, int out16, int precision, void* ws, size_t ws_bytes, hipStream_t st);    // gemm16.hip
 }

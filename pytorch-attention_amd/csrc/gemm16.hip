@@ -448,6 +448,29 @@ int mi355_linear16_fwd(const void* X16, const void* W16, const float* bias, cons
     return mi355_linear16_ws_fwd(X16, W16, bias, gamma, resid, Y, M, N, K, ldx, ldy, act, out16, precision, nullptr, 0, stream);
 }
 
+// Y16 = act(T(X32) . W16^T + bias): the fp32 -> 16-bit cast of the activation rides in the X staging of gemm16_wslab (no 16-bit copy of X in HBM,
+// one launch instead of mi355_cast16_fwd + mi355_linear16_fwd; the same bits).  MI355_EUNSUPPORTED -- nothing launched, no error text -- for
+// shapes the slab-stationary kernel does not take or with "gemm_wslab" = 0: the caller casts and calls mi355_linear16_fwd.
+int mi355_linear16_x32_fwd(const float* X32, const void* W16, const float* bias, void* Y16, int M, int N, int K, int ldx, int ldy, int act,
+                           int precision, mi355_stream_t stream) {
+    MI355_CHECK_ARG(X32 && W16 && Y16 && M > 0 && N > 0 && K > 0 && ldx >= K && ldy >= N);
+    MI355_CHECK_ARG(act == MI355_ACT_NONE || act == MI355_ACT_GELU);
+    MI355_CHECK_ARG(precision == MI355_PREC_FP16 || precision == MI355_PREC_BF16);
+    if (!mi355::opt_gemm_wslab()) return MI355_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    G16Args g{};
+    g.Af = X32; g.B = W16; g.C = Y16; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy; g.act = act;
+    // validate BEFORE touching the range word: an unsupported shape must leave no trace (the caller's cast16 + linear16 then count as two producers)
+    const int rc = mi355::gemm16_wslab_check(g, precision);
+    if (rc != MI355_OK) return rc;
+    if (precision == MI355_PREC_FP16) g.ovf = mi355::range_word(st);
+    const int rc2 = mi355::gemm16_wslab(g, 1, precision, st);
+    if (rc2 != MI355_OK) return rc2;
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+}
+
 int mi355_linear16_ws_fwd(const void* X16, const void* W16, const float* bias, const float* gamma, const float* resid, void* Y, int M,
                           int N, int K, int ldx, int ldy, int act, int out16, int precision, void* ws, size_t ws_bytes,
                           mi355_stream_t stream) {

@@ -32,7 +32,7 @@ namespace {
 
 using namespace g16;
 
-template <typename T, int K, int NT, int NW, bool GELU>
+template <typename T, int K, int NT, int NW, bool GELU, bool A32 = false>     // A32: X arrives as fp32 rows (g.Af) and is rounded to T on its way into LDS
 __global__ __launch_bounds__(NW * 64, 8 / NW) void gemm16_wslab_kernel(const G16Args g, int nslab, int nstream) {
     using v8 = typename Vec8<T>::t;
     typedef T t4 __attribute__((ext_vector_type(4)));
@@ -41,9 +41,6 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void gemm16_wslab_kernel(const G16
     constexpr int NCW = NT * 16;                  // columns per wave
     constexpr int SLAB = NW * NCW;
     constexpr int XP = K + 8;                     // LDS row pitch (elements)
-    constexpr int CH = ROWS * (K / 8);            // 16-byte chunks of a row tile
-    constexpr int NLD = CH / NTHR;                // chunks per thread
-    static_assert(CH % NTHR == 0, "row tile must split evenly over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned short s_x[2][ROWS * XP];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, gq = lane >> 4;
@@ -70,26 +67,45 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void gemm16_wslab_kernel(const G16
 
     float rgmax = 0.f;
     const long ntile = ((long)g.M + ROWS - 1) / ROWS;
-    int crow[NLD], ccol[NLD];                     // chunk c of a row tile: row c / (K/8), 8 elements at column (c % (K/8)) * 8
+    // chunk c of a row tile: 16 bytes of row c / CPR16 -- eight 16-bit elements, or (A32) four fp32 elements that become 8 bytes of the LDS image
+    constexpr int EPC = A32 ? 4 : 8, NCH = ROWS * (K / EPC) / NTHR;
+    static_assert((ROWS * (K / EPC)) % NTHR == 0, "row tile must split evenly over the workgroup");
+    int crow[NCH], ccol[NCH];
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int c = t + j * NTHR;
-        crow[j] = c / (K / 8);
-        ccol[j] = (c % (K / 8)) * 8;
+        crow[j] = c / (K / EPC);
+        ccol[j] = (c % (K / EPC)) * EPC;
     }
-    v8 areg[NLD];
+    typename std::conditional<A32, f4, v8>::type areg[NCH];
+    float rgin = 0.f;                             // A32: the range guard of the conversion (what mi355_cast16_fwd reports)
     auto fetch = [&](long tile) {
         const long r0 = tile * ROWS;
         const long left = (long)g.M - r0;
         const int rows = (int)(left < ROWS ? left : ROWS);
-        const rsrc_t rs = make_rsrc(A + r0 * g.lda, (bufops_u32)(((long)(rows - 1) * g.lda + K) * 2));
+        if constexpr (A32) {
+            const rsrc_t rs = make_rsrc(g.Af + r0 * g.lda, (bufops_u32)(((long)(rows - 1) * g.lda + K) * 4));
 #pragma unroll
-        for (int j = 0; j < NLD; ++j)
-            areg[j] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rs, (bufops_u32)((crow[j] * g.lda + ccol[j]) * 2), 0, 0));
+            for (int j = 0; j < NCH; ++j)
+                areg[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (bufops_u32)((crow[j] * g.lda + ccol[j]) * 4), 0, 0));
+        } else {
+            const rsrc_t rs = make_rsrc(A + r0 * g.lda, (bufops_u32)(((long)(rows - 1) * g.lda + K) * 2));
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                areg[j] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rs, (bufops_u32)((crow[j] * g.lda + ccol[j]) * 2), 0, 0));
+        }
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) *reinterpret_cast<v8*>(&s_x[buf][crow[j] * XP + ccol[j]]) = areg[j];
+        for (int j = 0; j < NCH; ++j) {
+            if constexpr (A32) {
+                const f4 v = areg[j];
+                if constexpr (std::is_same<T, _Float16>::value) rgin = rg_absmax4(rgin, v);
+                *reinterpret_cast<t4*>(&s_x[buf][crow[j] * XP + ccol[j]]) = t4{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+            } else {
+                *reinterpret_cast<v8*>(&s_x[buf][crow[j] * XP + ccol[j]]) = areg[j];
+            }
+        }
     };
 
     long tile = stream;
@@ -147,7 +163,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void gemm16_wslab_kernel(const G16
         __syncthreads();                              // next tile's rows complete in s_x[buf ^ 1]; everybody is done reading s_x[buf]
         buf ^= 1;
     }
-    if constexpr (std::is_same<T, _Float16>::value) rg_report_f(rgmax, g.ovf, 3u);
+    if constexpr (std::is_same<T, _Float16>::value) {
+        rg_report_f(rgmax, g.ovf, 3u);
+        if constexpr (A32) rg_report(rgin, g.ovf, 1u);
+    }
 }
 
 }  // namespace
@@ -156,14 +175,21 @@ namespace mi355 {
 
 // MI355_EUNSUPPORTED (nothing launched) unless the product is one this schedule is built for: 16-bit output, bias / GELU epilogue only,
 // K = 256 / 384 / 512, N a multiple of the slab width of that K, enough rows that every stream walks several tiles.
-int gemm16_wslab(const G16Args& g, int out16, int precision, hipStream_t st) {
+namespace {
+struct WslabPlan { int nw, nt, nslab, nstream, slots; bool a32; };
+// MI355_OK + the launch geometry, or MI355_EUNSUPPORTED; touches nothing
+int wslab_plan(const G16Args& g, int out16, int precision, WslabPlan* p) {
     if (!out16 || g.resid || g.gamma || g.resid_period || g.rowtau || g.lnc_a || g.row_stats || g.ln16_out) return MI355_EUNSUPPORTED;
     if (g.act != MI355_ACT_NONE && g.act != MI355_ACT_GELU) return MI355_EUNSUPPORTED;
     if (precision != MI355_PREC_FP16 && precision != MI355_PREC_BF16) return MI355_EUNSUPPORTED;
-    if ((g.lda & 7) || (g.ldb & 7) || (g.ldc & 7) || g.ldb < g.K || g.lda < g.K || g.ldc < g.N) return MI355_EUNSUPPORTED;
-    if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.bias && !aligned16(g.bias))) return MI355_EUNSUPPORTED;
-    if ((long)32 * g.ldc * 2 >= (1L << 31) || (long)32 * g.lda * 2 >= (1L << 31)) return MI355_EUNSUPPORTED;
-    const int nw = g.K == 512 ? 8 : 4;               // measured: K = 512 30.8 / 40.3 us on eight waves against 32.0 / 42.0 on four (CSWin stage 4 qkv / fc1)
+    const bool a32 = g.Af != nullptr;                // X as fp32 rows: the cast rides in the staging (mi355_linear16_x32_fwd)
+    if ((g.lda & (a32 ? 3 : 7)) || (g.ldb & 7) || (g.ldc & 7) || g.ldb < g.K || g.lda < g.K || g.ldc < g.N) return MI355_EUNSUPPORTED;
+    if (!aligned16(a32 ? static_cast<const void*>(g.Af) : g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.bias && !aligned16(g.bias)))
+        return MI355_EUNSUPPORTED;
+    if ((long)32 * g.ldc * 2 >= (1L << 31) || (long)32 * g.lda * 4 >= (1L << 31)) return MI355_EUNSUPPORTED;
+    // measured: K = 512 30.8 / 40.3 us on eight waves against 32.0 / 42.0 on four (CSWin stage 4 qkv / fc1); fp32 rows at K = 384 need eight waves
+    // (a 32-row tile is 12 float4 per thread on four: no registers left for them next to 144 of weights)
+    const int nw = (g.K == 512 || (a32 && g.K == 384)) ? 8 : 4;
     int nt;
     if (g.K == 256) nt = 4; else if (g.K == 384) nt = 3; else if (g.K == 512) nt = 2; else return MI355_EUNSUPPORTED;
     const int slabw = nw * nt * 16;
@@ -173,20 +199,36 @@ int gemm16_wslab(const G16Args& g, int out16, int precision, hipStream_t st) {
     const int nstream = slots / nslab;
     const long ntile = ((long)g.M + 31) / 32;
     if (nstream < 1 || ntile < 4L * nstream) return MI355_EUNSUPPORTED;      // too few rows to amortise the resident weights
-    MI355_TRACE(st, "gemm16_wslab_kernel<%s,K%d,%dw> M=%d N=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.K, nw, g.M, g.N,
-                g.act == MI355_ACT_GELU ? " gelu" : "");
-#define GO3(T_, K_, NT_, NW_)                                                                                      \
+    *p = WslabPlan{nw, nt, nslab, nstream, slots, a32};
+    return MI355_OK;
+}
+}  // namespace
+
+int gemm16_wslab_check(const G16Args& g, int precision) {
+    WslabPlan p;
+    return wslab_plan(g, 1, precision, &p);
+}
+
+int gemm16_wslab(const G16Args& g, int out16, int precision, hipStream_t st) {
+    WslabPlan p;
+    if (wslab_plan(g, out16, precision, &p) != MI355_OK) return MI355_EUNSUPPORTED;
+    const int nw = p.nw, nslab = p.nslab, nstream = p.nstream, slots = p.slots;
+    const bool a32 = p.a32;
+    MI355_TRACE(st, "gemm16_wslab_kernel<%s,K%d,%dw%s> M=%d N=%d%s", precision == MI355_PREC_FP16 ? "f16" : "bf16", g.K, nw, a32 ? ",x32" : "", g.M,
+                g.N, g.act == MI355_ACT_GELU ? " gelu" : "");
+#define GO4(T_, K_, NT_, NW_, A32_)                                                                               \
     do {                                                                                                          \
-        if (g.act == MI355_ACT_GELU) gemm16_wslab_kernel<T_, K_, NT_, NW_, true><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream);  \
-        else                         gemm16_wslab_kernel<T_, K_, NT_, NW_, false><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream); \
+        if (g.act == MI355_ACT_GELU) gemm16_wslab_kernel<T_, K_, NT_, NW_, true, A32_><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream);  \
+        else                         gemm16_wslab_kernel<T_, K_, NT_, NW_, false, A32_><<<slots, NW_ * 64, 0, st>>>(g, nslab, nstream); \
     } while (0)
 #define GO2(T_)                                                                                                   \
     do {                                                                                                          \
-        if (g.K == 256) GO3(T_, 256, 4, 4); else if (g.K == 384) GO3(T_, 384, 3, 4); else GO3(T_, 512, 2, 8);     \
+        if (a32) { if (g.K == 256) GO4(T_, 256, 4, 4, true); else if (g.K == 384) GO4(T_, 384, 3, 8, true); else GO4(T_, 512, 2, 8, true); }      \
+        else     { if (g.K == 256) GO4(T_, 256, 4, 4, false); else if (g.K == 384) GO4(T_, 384, 3, 4, false); else GO4(T_, 512, 2, 8, false); }  \
     } while (0)
     if (precision == MI355_PREC_FP16) GO2(_Float16); else GO2(__bf16);
 #undef GO2
-#undef GO3
+#undef GO4
     return MI355_OK;
 }
 

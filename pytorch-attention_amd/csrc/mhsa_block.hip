@@ -1,4 +1,5 @@
-// mhsa_block.hip -- ViT Attention.forward (ViT.py:79-89) as ONE C call: cast -> qkv GEMM -> attention core -> proj GEMM (+ residual).
+// mhsa_block.hip -- ViT Attention.forward (ViT.py:79-89) as ONE C call: cast -> qkv GEMM (one launch at C = 256 / 384 / 512) -> attention core ->
+// proj GEMM (+ residual).
 // SURVEY 8(b) lists `mhsa` among the ops the boundary exports; a host that is not Python gets the block without re-implementing
 // the dispatch rules of mi355attn/modules/vit.py.  Nothing new runs on the device: the entry composes the library's own entry
 // points on the caller's stream, with q / k / v / context in the caller's workspace in the 16-bit operand format.
@@ -32,12 +33,10 @@ int mi355_mhsa_fwd(const void* x, int x_is16, const void* Wqkv16, const float* b
     const size_t M = (size_t)B * N;
     if (M > (size_t)0x7fffffff) return mi355::fail(MI355_EUNSUPPORTED, "mi355_mhsa_fwd: B * N too large");
     char* w = static_cast<char*>(workspace);
-    const void* x16 = x;
+    void* xb = nullptr;
     if (!x_is16) {
-        void* xb = w;
+        xb = w;
         w += up256(M * C * 2);
-        if (int rc = mi355_cast16_fwd(static_cast<const float*>(x), xb, M * C, precision, stream)) return rc;
-        x16 = xb;
     }
     void* qkv16 = w;
     w += up256(M * 3 * C * 2);
@@ -45,9 +44,21 @@ int mi355_mhsa_fwd(const void* x, int x_is16, const void* Wqkv16, const float* b
     w += up256(M * C * 2);
     void* lws = w;
     size_t lbytes = mi355_linear16_workspace_bytes((int)M, 3 * C, C);
-    if (int rc = mi355_linear16_ws_fwd(x16, Wqkv16, b_qkv, nullptr, nullptr, qkv16, (int)M, 3 * C, C, C, 3 * C, MI355_ACT_NONE, 1, precision,
-                                       lbytes ? lws : nullptr, lbytes, stream))
-        return rc;
+    // fp32 x at C = 256 / 384 / 512: the cast rides in the qkv GEMM's staging (round 6, mi355_linear16_x32_fwd: one launch, no 16-bit copy of x);
+    // MI355_EUNSUPPORTED there = nothing launched: cast, then the 16-bit entry
+    int rc_qkv = MI355_EUNSUPPORTED;
+    if (!x_is16)
+        rc_qkv = mi355_linear16_x32_fwd(static_cast<const float*>(x), Wqkv16, b_qkv, qkv16, (int)M, 3 * C, C, C, 3 * C, MI355_ACT_NONE, precision, stream);
+    if (rc_qkv == MI355_EUNSUPPORTED) {
+        const void* x16 = x;
+        if (!x_is16) {
+            if (int rc = mi355_cast16_fwd(static_cast<const float*>(x), xb, M * C, precision, stream)) return rc;
+            x16 = xb;
+        }
+        rc_qkv = mi355_linear16_ws_fwd(x16, Wqkv16, b_qkv, nullptr, nullptr, qkv16, (int)M, 3 * C, C, C, 3 * C, MI355_ACT_NONE, 1, precision,
+                                       lbytes ? lws : nullptr, lbytes, stream);
+    }
+    if (rc_qkv) return rc_qkv;
     if ((d == 32 || d == 64) && N <= 224) {
         if (int rc = mi355_sdpa16_fwd(qkv16, ctx16, B, N, heads, d, scale, precision, stream)) return rc;
     } else {

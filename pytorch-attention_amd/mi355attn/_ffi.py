@@ -132,6 +132,7 @@ SIGNATURES = {
     "mi355_mfma_yardstick": (c_int, [c_int, c_int, c_vp, c_vp, c_vp]),
     "mi355_event_time_begin": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "mi355_event_time_end": (c_int, [c_vp, c_vp, ctypes.POINTER(c_float)]),
+    "mi355_linear16_x32_fwd": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "mi355_linear16_stats_fwd": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp, c_float, c_vp]),
     "mi355_linear16_ln16_fwd": (c_int, [c_vp] * 7 + [c_float, c_vp] + [c_int] * 7 + [c_vp]),
     "mi355_ln_lpi_stats_fwd": (c_int, [c_vp] * 10 + [c_float] + [c_vp] * 5 + [c_int] * 4 + [c_vp]),
@@ -181,6 +182,9 @@ def lib():
         handle.mi355_set_default_option(b"ws_persistent", 1)
         _lib = handle
     return _lib
+
+
+MI355_EUNSUPPORTED = -2          # include/mi355attn.h: shape outside the kernel's envelope, nothing launched
 
 
 def check(code, what):

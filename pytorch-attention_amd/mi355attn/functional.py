@@ -852,6 +852,30 @@ def linear16(x16, w16, bias=None, act=ACT_NONE, gamma=None, resid=None, out16=Fa
     return y
 
 
+def cast_linear16(x, w16, bias=None, act=ACT_NONE, precision=None):
+    """act(T(x) @ w16^T + bias) in the 16-bit operand format for an fp32 OR 16-bit x: an fp32 x goes through mi355_linear16_x32_fwd (the cast
+    inside the GEMM's staging: one launch, no 16-bit copy of x in HBM) where that entry takes the shape, else through cast16 + linear16;
+    the same bits either way."""
+    p = _prec(precision)
+    if x.dtype != torch.float32:
+        return linear16(x, w16, bias, act=act, out16=True, precision=p)
+    _range_check()
+    x = require_device_f32(x, "x")
+    w16 = _require16(w16, "w16", p)
+    N, K = w16.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"cast_linear16: x last dim {x.shape[-1]} != weight in_features {K}")
+    M = x.numel() // K
+    if K in (256, 384, 512) and M >= 128:
+        bias_ = _opt(bias, "bias")
+        y = torch.empty(*x.shape[:-1], N, dtype=dtype16(p), device=x.device)
+        rc = lib().mi355_linear16_x32_fwd(dptr(x), dptr(w16), dptr(bias_), dptr(y), M, N, K, K, N, act, p, stream_ptr(x.device))
+        if rc != _ffi.MI355_EUNSUPPORTED:
+            check(rc, "mi355_linear16_x32_fwd")
+            return y
+    return linear16(cast16(x, p), w16, bias, act=act, out16=True, precision=p)
+
+
 def linear16_stats(x16, w16, bias, resid, eps, precision=None):
     """(Y, stats) with Y = resid + x16 @ w16^T + bias (fp32) and stats (rows, 2) = (mean, 1 / sqrt(var + eps)) of every row of Y -- the
     LayerNorm statistics the next block needs, written by the GEMM that owns whole rows (mi355_linear16_stats_fwd: N = K = 256 / 384).

@@ -27,8 +27,7 @@ def _fast(precision, *linears):
 def _mlp16(x, fc1, fc2, precision, second_gelu, gamma=None, resid=None):
     """fc1 -> GELU -> fc2 (-> GELU) with the hidden activation kept in the MFMA operand format; x is fp32 or 16-bit."""
     p = F._prec(precision)
-    x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
-    h16 = F.linear16(x16, F.weight16(fc1.weight, p), fc1.bias, act=F.ACT_GELU, out16=True, precision=p)
+    h16 = F.cast_linear16(x, F.weight16(fc1.weight, p), fc1.bias, act=F.ACT_GELU, precision=p)    # fp32 x: the cast rides in the GEMM where it can
     folded = F.weight16_scaled(fc2.weight, fc2.bias, gamma, p) if gamma is not None and not second_gelu else None
     if folded is not None:                                    # LayerScale folded into fc2 (XCiT: no activation behind fc2); None =
         w16, b = folded                                       # gamma * W would leave the fp16 normal range: gamma stays in the epilogue

@@ -83,8 +83,7 @@ class XCA(nn.Module):
             if ln is not None:
                 qkv = F.ln_linear16(x, ln, self.qkv, out16=True, precision=p)
             else:
-                x16 = x if x.dtype != torch.float32 else F.cast16(x, p)
-                qkv = F.linear16(x16, F.weight16(self.qkv.weight, p), self.qkv.bias, out16=True, precision=p)
+                qkv = F.cast_linear16(x, F.weight16(self.qkv.weight, p), self.qkv.bias, precision=p)    # fp32 x: the cast rides in the GEMM
             ctx16 = F.xca_core(qkv, self.temperature, self.num_heads, precision=p, out16=True)
             folded = F.weight16_scaled(self.proj.weight, self.proj.bias, gamma, p) if gamma is not None else None
             if folded is not None:                            # LayerScale folded into the projection (no activation in between)

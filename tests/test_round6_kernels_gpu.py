@@ -467,3 +467,48 @@ def test_slab_stationary_gemm_under_graph_capture_and_on_a_side_stream():
     side.synchronize()
     assert torch.equal(y_side, y_ref)
     mi355attn.range_status(wait=True)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("M,N,K,act", [(50176, 1152, 384, 0), (50176 - 45, 1536, 384, 1), (50176, 768, 256, 0), (12544, 1536, 512, 1),
+                                       (50176, 1000, 384, 0), (100, 1152, 384, 0)])
+def test_cast_rides_in_the_gemm_staging_with_the_same_bits(M, N, K, act, prec):
+    """mi355_linear16_x32_fwd (round 6): act(T(x32) W16^T + b) in ONE launch equals cast16 + linear16 bit for bit; shapes the slab-stationary
+    kernel does not take come back as MI355_EUNSUPPORTED with nothing launched and the host helper composes the two calls."""
+    import mi355attn
+    from mi355attn import functional as F
+    torch.manual_seed(M + N + K + prec)
+    x = torch.randn(M, K, device="cuda")
+    w16 = F.cast16((torch.randn(N, K, device="cuda") / K ** 0.5).contiguous(), prec)
+    b = torch.randn(N, device="cuda")
+    a = F.ACT_GELU if act else F.ACT_NONE
+    out = {}
+    tags = _tags(lambda: out.__setitem__("fused", F.cast_linear16(x, w16, b, act=a, precision=prec)))
+    two = F.linear16(F.cast16(x, prec), w16, b, act=a, out16=True, precision=prec)
+    torch.cuda.synchronize()
+    slabw = {256: 256, 384: 384, 512: 256}[K]                    # fp32 rows: eight waves at K = 384 / 512, four at K = 256
+    slots = 256 * (2 if K == 256 else 1)
+    takes = N % slabw == 0 and M >= 128 and (M + 31) // 32 >= 4 * (slots // (N // slabw))
+    assert any(",x32>" in t for t in tags) == takes, (tags, takes)
+    assert (len(tags) == 1) == takes, tags
+    assert torch.equal(out["fused"], two)
+
+
+def test_cast_in_the_gemm_staging_reports_input_saturation():
+    """The fused cast keeps mi355_cast16_fwd's range report: a finite |x| >= 65520 is an fp16 inf the fp32 reference does not have."""
+    import mi355attn
+    from mi355attn import functional as F
+    x = torch.randn(50176, 384, device="cuda")
+    x[12345, 17] = 7.0e4
+    w16 = F.cast16(torch.randn(1152, 384, device="cuda") / 20, 1)
+    mi355attn.range_status(wait=True)
+    try:
+        tags = _tags(lambda: F.cast_linear16(x, w16, None, precision=1))
+        assert any(",x32>" in t for t in tags), tags
+        with pytest.raises(mi355attn.Mi355RangeError):
+            mi355attn.range_status(wait=True)
+    finally:
+        try:
+            mi355attn.range_status(wait=True)
+        except mi355attn.Mi355RangeError:
+            pass
