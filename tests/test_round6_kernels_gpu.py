@@ -512,3 +512,45 @@ def test_cast_in_the_gemm_staging_reports_input_saturation():
             mi355attn.range_status(wait=True)
         except mi355attn.Mi355RangeError:
             pass
+
+
+def test_block_entries_use_the_fused_cast_and_keep_their_bits():
+    """mi355_mhsa_fwd and XCA.forward on an fp32 input at C = 384: no cast16 launch (the qkv GEMM takes the fp32 rows), the result equals the
+    composition cast16 -> linear16 -> core -> linear16 bit for bit and the oracle within 1e-3."""
+    import oracle as O
+    import mi355attn
+    from mi355attn import functional as F
+    from mi355attn.modules import Attention
+    B, N, C, heads = 64, 196, 384, 6
+    torch.manual_seed(1234)
+    m = Attention(C, heads, qkv_bias=True).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(B, N, C)
+    ref = O.vit_attention_forward(x[:2], sd, heads)
+    m, xd = m.cuda(), x.cuda()
+    p = F._prec(None)
+    out = {}
+    with torch.no_grad():
+        m(xd)                                                       # first call converts the weights (cached 16-bit copies)
+        tags = _tags(lambda: out.__setitem__("y", m(xd)))
+        qkv16 = F.linear16(F.cast16(xd, p), F.weight16(m.qkv.weight, p), m.qkv.bias, out16=True, precision=p)
+        yc = F.linear16(m._core(qkv16, True), F.weight16(m.proj.weight, p), m.proj.bias, precision=p)
+    assert any(",x32>" in t for t in tags) and not any("cast16" in t for t in tags), tags
+    assert torch.equal(out["y"], yc)
+    assert_parity(out["y"][:2].cpu(), ref, 1e-3, "mhsa block (fused cast) vs oracle")
+    from mi355attn.modules import XCA
+    torch.manual_seed(7)
+    xca = XCA(C, 8).eval().cuda()
+    with torch.no_grad():
+        xca(xd)
+        tags = _tags(lambda: out.__setitem__("x", xca(xd)))
+        old = mi355attn.get_option("gemm_wslab")
+        try:
+            mi355attn.set_option("gemm_wslab", 0)
+            tags0 = _tags(lambda: out.__setitem__("x0", xca(xd)))
+        finally:
+            mi355attn.set_option("gemm_wslab", old)
+    assert any(",x32>" in t for t in tags) and not any("cast16" in t for t in tags), tags
+    assert any("cast16" in t for t in tags0) and len(tags0) == len(tags) + 1, (tags, tags0)
+    assert torch.equal(out["x"], out["x0"])
